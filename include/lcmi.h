@@ -1,0 +1,165 @@
+/*
+ * lcmi.h - C ABI of liblcmi.so, the MI355X (gfx950) implementation of lightcurver's
+ * PSF-fit + joint forward-model hot path.
+ *
+ * The reference (duxfrederic/lightcurver) has no FFI for this path: it calls the third-party
+ * STARRED/JAX package from Python.  Each entry point below therefore cites the reference *call
+ * site* whose arithmetic it replaces (paths relative to the reference repository root); the
+ * ctypes stub a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, int status (0 = ok, < 0 = error; message through
+ *     lc_last_error()).  No torch / numpy types.
+ *   - All array arguments are HOST pointers unless the name ends in _dev.  Inputs are copied at
+ *     call time, outputs are written into caller-allocated buffers.  float = IEEE fp32, the
+ *     arithmetic type of the path (the reference stores stamps as float32:
+ *     lightcurver/processes/cutout_making.py:48-49).
+ *   - One context per device, one thread per context.
+ *   - Layouts are C-contiguous; images are [row = y][col = x]; c_x, dx, x0 run along columns.
+ */
+#ifndef LCMI_H
+#define LCMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LC_OK 0
+#define LC_ERR_INVALID (-1)
+#define LC_ERR_DEVICE (-2)
+#define LC_ERR_UNSUPPORTED (-3)
+#define LC_ERR_NONFINITE (-4)
+
+typedef struct lc_ctx lc_ctx;
+typedef struct lc_psf_batch lc_psf_batch;
+typedef struct lc_joint lc_joint;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int lc_version(void);
+int lc_ctx_create(int device, lc_ctx **out);
+void lc_ctx_destroy(lc_ctx *ctx);
+const char *lc_last_error(const lc_ctx *ctx); /* ctx may be NULL: last error of a failed create */
+int lc_ctx_synchronize(lc_ctx *ctx);
+/* HIP-event timer on the context's stream (the stream every kernel of this library runs on). */
+int lc_timer_start(lc_ctx *ctx);
+int lc_timer_stop(lc_ctx *ctx, float *elapsed_ms);
+/* device name + CU count, for reports */
+int lc_device_info(lc_ctx *ctx, char *name, int name_len, int *n_cu, int64_t *hbm_bytes);
+
+/* ---- optimiser settings shared by both fits ----------------------------------------------- */
+/* optax.adabelief as driven by STARRED's Optimizer(method='adabelief'):
+ * lightcurver/processes/star_photometry.py:113-122, roi_modelling.py:326-334. */
+typedef struct {
+  float init_learning_rate;
+  int32_t schedule_learning_rate; /* 0/1: lr_t = lr0 * decay_rate^(t / transition_steps) */
+  float decay_rate;               /* default 0.99 */
+  int32_t transition_steps;       /* default 10 */
+  float b1, b2, eps, eps_root;    /* defaults 0.9, 0.999, 1e-16, 1e-16 */
+} lc_adabelief_cfg;
+void lc_adabelief_defaults(lc_adabelief_cfg *cfg);
+
+/* ---- PSF fit: replaces starred.procedures.psf_routines.build_psf ----------------------------
+ * Reference call site: lightcurver/processes/psf_modelling.py:164-171 (one call per frame inside
+ * the serial loop at :92).  Here a whole batch of F frames is fitted at once, one workgroup per
+ * frame.  S_max stars per frame; frames with fewer usable stars (the 40 % mask filter at
+ * psf_modelling.py:144-153) pass weight == 0 for the padding stamps.
+ *
+ *   data    [F][S_max][n][n]  stamps, already divided by the caller's normalisation
+ *   weight  [F][S_max][n][n]  mask / sigma^2 (0 where masked, NaN or padding)
+ *   model per star i of a frame:  a_i * D_ss[ G(x0_i, y0_i) (*) (Moffat + B) ] + sky_i
+ */
+int lc_psf_supported(int n, int ss); /* 1 if a kernel is instantiated for this stamp size */
+int lc_psf_batch_create(lc_ctx *ctx, int F, int S_max, int n, int ss, const float *data,
+                        const float *weight, lc_psf_batch **out);
+void lc_psf_batch_destroy(lc_psf_batch *b);
+/* Moffat parameters [F][4] = fwhm_x, fwhm_y (data px), phi (rad), beta; rasterises the unit-sum
+ * Moffat of every frame on the N x N grid (N = ss * n). */
+int lc_psf_batch_set_moffat(lc_psf_batch *b, const float *moffat);
+int lc_psf_batch_get_moffat(lc_psf_batch *b, float *moffat);
+/* per-star parameters [F][S_max][4] = a, x0, y0, sky */
+int lc_psf_batch_set_stars(lc_psf_batch *b, const float *stars);
+int lc_psf_batch_get_stars(lc_psf_batch *b, float *stars);
+/* pixel grid B [F][N*N]; NULL resets it (and the optimiser moments) to zero */
+int lc_psf_batch_set_grid(lc_psf_batch *b, const float *grid);
+int lc_psf_batch_get_grid(lc_psf_batch *b, float *grid);
+/* starlet weights W [F][J][N][N] (J = floor(log2 N) detail scales) and strengths; W == NULL
+ * selects the starlet scale norms ("lambda is not normalized" case of STARRED). */
+int lc_psf_batch_set_regularization(lc_psf_batch *b, const float *W, float lam_scales, float lam_hf);
+/* noise propagation of the chi2 gradient into the starlet domain of B (replaces the
+ * propagate_noise call inside build_psf), using the current a, x0, y0.  Writes device W. */
+int lc_psf_batch_propagate_noise(lc_psf_batch *b);
+int lc_psf_batch_get_weights(lc_psf_batch *b, float *W);
+/* One evaluation at the current parameters.  Any output may be NULL.
+ *   loss [F] (0.5 chi2 + l1), chi2 [F], grad_moffat [F][4], grad_stars [F][S_max][4] (a,x0,y0,sky),
+ *   grad_grid [F][N*N] (d loss / d B, regularisation included), model [F][S_max][n][n]. */
+int lc_psf_batch_eval(lc_psf_batch *b, float *loss, float *chi2, float *grad_moffat,
+                      float *grad_stars, float *grad_grid, float *model);
+/* Stage A of build_psf: Moffat + a, x0, y0 by bounded L-BFGS with B = 0 (n_iter_analytic). */
+int lc_psf_batch_fit_moffat(lc_psf_batch *b, int n_iter, float *final_loss /* [F] or NULL */);
+/* Stage B: n_iter AdaBelief steps on B, a, x0, y0, state and loop on device (the hot loop).
+ * Asynchronous on the context stream.  loss history accumulates across calls. */
+int lc_psf_batch_run_adabelief(lc_psf_batch *b, int n_iter, const lc_adabelief_cfg *cfg);
+int lc_psf_batch_iterations_done(lc_psf_batch *b);
+/* loss at theta_0 .. theta_T (T + 1 values per frame; history[f][t] is the loss BEFORE update t,
+ * the last entry the loss of the final parameters) */
+int lc_psf_batch_get_loss_history(lc_psf_batch *b, float *history, int stride);
+/* narrow_psf, full_psf [F][N][N] (unit sum), residuals = data - model [F][S_max][n][n],
+ * reduced chi2 [F] over unmasked pixels. */
+int lc_psf_batch_get_results(lc_psf_batch *b, float *narrow_psf, float *full_psf, float *residuals,
+                             float *chi2);
+
+/* ---- joint multi-epoch forward model: replaces starred Deconv / Loss / Optimizer ------------
+ * Reference call sites: lightcurver/processes/star_photometry.py:66-137 (one star, all epochs)
+ * and lightcurver/processes/roi_modelling.py:213-334 (ROI, M point sources + background).
+ *   data, sigma2 [E][n][n];  psf [E][N][N] narrow PSF per epoch;  N = ss * n
+ * Parameter blocks follow STARRED's kwargs: a [E*M] epoch-major (roi_modelling.py:462),
+ * c_x, c_y [M], dx, dy, alpha [E] (alpha in degrees, never free), h [N*N], mean [E].
+ */
+enum { LC_P_A = 0, LC_P_CX = 1, LC_P_CY = 2, LC_P_DX = 3, LC_P_DY = 4, LC_P_ALPHA = 5, LC_P_H = 6,
+       LC_P_MEAN = 7, LC_P_COUNT = 8 };
+
+typedef struct {
+  float lam_scales, lam_hf;  /* regularization_strength_scales / _hf (l1_starlet on h) */
+  float lam_positivity;      /* regularization_strength_positivity (h) */
+  float lam_positivity_ps;   /* regularization_strength_positivity_ps (a) */
+  float lam_pts_source;      /* regularization_strength_pts_source */
+  float lam_flux_uniformity; /* regularization_strength_flux_uniformity */
+  int32_t n_prior;           /* Gaussian prior terms on c_x / c_y: arrays below, length M each */
+  const float *prior_cx_mean, *prior_cx_sigma, *prior_cy_mean, *prior_cy_sigma; /* may be NULL */
+} lc_joint_loss_cfg;
+
+int lc_joint_supported(int n, int ss);
+int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data, const float *sigma2,
+                    const float *psf, lc_joint **out);
+void lc_joint_destroy(lc_joint *j);
+int lc_joint_set_param(lc_joint *j, int which, const float *values, int count);
+int lc_joint_get_param(lc_joint *j, int which, float *values, int count);
+/* free_mask[LC_P_COUNT]: 1 = optimised, 0 = fixed (ParametersDeconv kwargs_fixed) */
+int lc_joint_set_free(lc_joint *j, const int32_t *free_mask);
+int lc_joint_set_loss(lc_joint *j, const lc_joint_loss_cfg *cfg, const float *W /* [J][N][N] or NULL */);
+/* propagate_noise(method='SLIT', likelihood_type='chi2')[0]  ->  W [J+1][N][N] */
+int lc_joint_propagate_noise(lc_joint *j, float *W_out /* may be NULL: keep on device only */);
+/* loss and gradient at the current parameters; grads[which] may be NULL.  For L-BFGS drivers. */
+int lc_joint_loss_grad(lc_joint *j, float *loss, float *const grads[LC_P_COUNT]);
+/* Deconv.model(kwargs) -> [E][n][n];  chi2_per_epoch [E] = sum res^2/sigma2 (not normalised) */
+int lc_joint_model(lc_joint *j, float *model, float *chi2_per_epoch);
+/* Deconv.getDeconvolved(kwargs, epoch) -> high-res scene and background, [N][N] each */
+int lc_joint_deconvolved(lc_joint *j, int epoch, float *scene, float *background);
+int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg);
+int lc_joint_get_loss_history(lc_joint *j, float *history, int count);
+int lc_joint_iterations_done(lc_joint *j);
+/* FisherCovariance(diagonal_only=True) with only `a` free -> sigma(a) [E*M]
+ * (lightcurver/utilities/starred_utilities.py:36-38). */
+int lc_joint_fisher_flux_sigma(lc_joint *j, float *sigma_a);
+/* Multi-GPU epoch sharding: split one optimiser step around the caller's all-reduce of the
+ * shared block [dL/dh (N*N) | dL/dc_x (M) | dL/dc_y (M) | loss (1)] living in device memory. */
+int lc_joint_step_local(lc_joint *j);                      /* forward/backward of local epochs */
+int lc_joint_shared_buffer_dev(lc_joint *j, void **dev_ptr, int *count);
+int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg); /* regularise + AdaBelief */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCMI_H */

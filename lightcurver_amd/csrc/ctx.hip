@@ -1,0 +1,95 @@
+// Context, stream, event timer and device queries of liblcmi (include/lcmi.h, "context" section).
+#include <cstring>
+
+#include "lc_common.h"
+
+static thread_local std::string g_create_error;
+
+extern "C" {
+
+int lc_version(void) { return 100; }
+
+void lc_adabelief_defaults(lc_adabelief_cfg *cfg) {
+  if (!cfg) return;
+  cfg->init_learning_rate = 1e-3f;
+  cfg->schedule_learning_rate = 1;
+  cfg->decay_rate = 0.99f;
+  cfg->transition_steps = 10;
+  cfg->b1 = 0.9f;
+  cfg->b2 = 0.999f;
+  cfg->eps = 1e-16f;
+  cfg->eps_root = 1e-16f;
+}
+
+int lc_ctx_create(int device, lc_ctx **out) {
+  if (!out) return LC_ERR_INVALID;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+    return LC_ERR_DEVICE;
+  }
+  if (device < 0 || device >= count) {
+    g_create_error = "device index out of range";
+    return LC_ERR_INVALID;
+  }
+  lc_ctx *c = new lc_ctx();
+  c->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
+      (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+    g_create_error = std::string("context creation failed: ") + hipGetErrorString(e);
+    delete c;
+    return LC_ERR_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+  *out = c;
+  return LC_OK;
+}
+
+void lc_ctx_destroy(lc_ctx *ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  hipEventDestroy(ctx->ev0);
+  hipEventDestroy(ctx->ev1);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *lc_last_error(const lc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int lc_ctx_synchronize(lc_ctx *ctx) {
+  if (!ctx) return LC_ERR_INVALID;
+  LC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LC_OK;
+}
+
+int lc_timer_start(lc_ctx *ctx) {
+  if (!ctx) return LC_ERR_INVALID;
+  LC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return LC_OK;
+}
+
+int lc_timer_stop(lc_ctx *ctx, float *elapsed_ms) {
+  if (!ctx || !elapsed_ms) return LC_ERR_INVALID;
+  LC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  LC_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  LC_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+  return LC_OK;
+}
+
+int lc_device_info(lc_ctx *ctx, char *name, int name_len, int *n_cu, int64_t *hbm_bytes) {
+  if (!ctx) return LC_ERR_INVALID;
+  hipDeviceProp_t prop;
+  LC_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  if (name && name_len > 0) {
+    std::strncpy(name, prop.name, name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  if (n_cu) *n_cu = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  return LC_OK;
+}
+
+}  // extern "C"

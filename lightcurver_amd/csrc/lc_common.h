@@ -1,0 +1,49 @@
+// Shared host/device definitions of liblcmi (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/lcmi.h"
+
+namespace lc {
+
+// Target resolution of the two-channel (MCS-style) scheme: Gaussian of FWHM 2 high-res pixels.
+constexpr float kGaussFwhm = 2.0f;
+constexpr float kSigmaG = 0.84932180028801907f;  // 2 / (2 sqrt(2 ln 2))
+constexpr int kRg = 6;                           // half support of the sampled Gaussian (7 sigma)
+constexpr int kWave = 64;
+
+__host__ __device__ constexpr int ntaps(int ss) { return 2 * kRg + 1 + 2 * (ss - 1); }
+__host__ __device__ constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace lc
+
+struct lc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  int n_cu = 0;
+};
+
+#define LC_HIP(ctx, call)                                                                  \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+      return LC_ERR_DEVICE;                                                                \
+    }                                                                                      \
+  } while (0)
+
+#define LC_FAIL(ctx, code, msg) \
+  do {                          \
+    (ctx)->err = (msg);         \
+    return (code);              \
+  } while (0)

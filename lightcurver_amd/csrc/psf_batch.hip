@@ -1,0 +1,657 @@
+// PSF-fit batch object behind the C ABI (include/lcmi.h, "PSF fit" section).
+#include <cmath>
+#include <cstring>
+
+#include "lbfgs_host.h"
+#include "psf_kernels.h"
+
+using namespace lc;
+
+struct lc_psf_batch {
+  lc_ctx *ctx = nullptr;
+  int F = 0, S = 0, n = 0, ss = 0, N = 0, J = 0;
+  float *data = nullptr, *wgt = nullptr, *W = nullptr, *norms = nullptr, *Tm = nullptr;
+  float *B = nullptr, *mB = nullptr, *sB = nullptr;
+  float *stars = nullptr, *stars_m = nullptr, *stars_s = nullptr, *moffat = nullptr;
+  float *hist = nullptr, *qscratch = nullptr;
+  float *o_loss = nullptr, *o_chi2 = nullptr, *o_gstars = nullptr, *o_ggrid = nullptr, *o_gT = nullptr,
+        *o_model = nullptr, *o_gmoffat = nullptr;
+  float *narrow = nullptr, *full = nullptr, *resid = nullptr, *redchi2 = nullptr;
+  float *atoms = nullptr;  // [J+1][3][N] separable factors of psi_j^2 (noise propagation)
+  float *V = nullptr;      // [F][N*N]
+  bool have_W = false;
+  float lam_sc = 0.f, lam_hf = 0.f;
+  int hist_stride = 0, iters_done = 0;
+  std::vector<void *> allocs;
+};
+
+namespace {
+
+template <class T>
+int dmalloc(lc_psf_batch *b, T **p, size_t count) {
+  LC_HIP(b->ctx, hipMalloc((void **)p, count * sizeof(T)));
+  b->allocs.push_back(*p);
+  LC_HIP(b->ctx, hipMemsetAsync(*p, 0, count * sizeof(T), b->ctx->stream));
+  return LC_OK;
+}
+
+// ---- Moffat rasterisation and its parameter gradient (double precision, one block per frame) ----
+__device__ inline void moffat_terms(int N, int ss, const float *par, int u, int v, double &M, double dM[4]) {
+  const double fx = par[0], fy = par[1], phi = par[2], beta = par[3];
+  const int c = (N - 1) / 2;
+  const double x = v - c, y = u - c;
+  const double p2 = pow(2.0, 1.0 / beta);
+  const double kb = 2.0 * sqrt(p2 - 1.0);
+  const double ax = ss * fx / kb, ay = ss * fy / kb;
+  const double cs = cos(phi), sn = sin(phi);
+  const double xr = x * cs + y * sn, yr = -x * sn + y * cs;
+  const double A = xr * xr / (ax * ax) + yr * yr / (ay * ay);
+  M = pow(1.0 + A, -beta);
+  const double Mb1 = M / (1.0 + A);  // (1+A)^(-beta-1)
+  const double dM_dax = 2.0 * beta * Mb1 * xr * xr / (ax * ax * ax);
+  const double dM_day = 2.0 * beta * Mb1 * yr * yr / (ay * ay * ay);
+  const double dkb_db = (1.0 / sqrt(p2 - 1.0)) * p2 * log(2.0) * (-1.0 / (beta * beta));
+  dM[0] = dM_dax * ss / kb;
+  dM[1] = dM_day * ss / kb;
+  dM[2] = -beta * Mb1 * 2.0 * xr * yr * (1.0 / (ax * ax) - 1.0 / (ay * ay));
+  dM[3] = -log(1.0 + A) * M + dM_dax * (-ss * fx / (kb * kb)) * dkb_db + dM_day * (-ss * fy / (kb * kb)) * dkb_db;
+}
+
+__device__ inline double block_sum_d(double v, double *sh) {
+  const int tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (tid < s) sh[tid] += sh[tid + s];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ void moffat_raster_kernel(int N, int ss, const float *par, float *Tm) {
+  __shared__ double sh[256];
+  const int f = blockIdx.x;
+  const float *p = par + f * 4;
+  double acc = 0;
+  for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
+    double M, dM[4];
+    moffat_terms(N, ss, p, i / N, i % N, M, dM);
+    acc += M;
+  }
+  const double S = block_sum_d(acc, sh);
+  for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
+    double M, dM[4];
+    moffat_terms(N, ss, p, i / N, i % N, M, dM);
+    Tm[(size_t)f * N * N + i] = (float)(M / S);
+  }
+}
+
+__global__ void moffat_grad_kernel(int N, int ss, const float *par, const float *gT, float *gmoffat) {
+  __shared__ double sh[256];
+  const int f = blockIdx.x;
+  const float *p = par + f * 4;
+  double sM = 0, sdM[4] = {0, 0, 0, 0}, gM = 0, gdM[4] = {0, 0, 0, 0};
+  for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
+    double M, dM[4];
+    moffat_terms(N, ss, p, i / N, i % N, M, dM);
+    const double g = gT[(size_t)f * N * N + i];
+    sM += M;
+    gM += g * M;
+    for (int k = 0; k < 4; ++k) {
+      sdM[k] += dM[k];
+      gdM[k] += g * dM[k];
+    }
+  }
+  const double S = block_sum_d(sM, sh);
+  const double G = block_sum_d(gM, sh);
+  for (int k = 0; k < 4; ++k) {
+    const double a = block_sum_d(sdM[k], sh);
+    const double b = block_sum_d(gdM[k], sh);
+    if (threadIdx.x == 0) gmoffat[f * 4 + k] = (float)((b - G * a / S) / S);
+  }
+}
+
+// ---- outputs: narrow / full PSF, residuals, reduced chi2 ------------------------------------------
+__global__ void psf_finalize_kernel(int N, const float *Tm, const float *B, float *narrow, float *full) {
+  __shared__ double sh[256];
+  const int f = blockIdx.x;
+  const size_t o = (size_t)f * N * N;
+  double acc = 0;
+  for (int i = threadIdx.x; i < N * N; i += blockDim.x) acc += (double)Tm[o + i] + (double)B[o + i];
+  const double S = block_sum_d(acc, sh);
+  for (int i = threadIdx.x; i < N * N; i += blockDim.x) narrow[o + i] = (float)(((double)Tm[o + i] + (double)B[o + i]) / S);
+  __syncthreads();
+  // full = conv_same(G(centre), narrow): separable taps phi(t) = N(t; delta, sigma), delta = (N-1)/2 - (N-1)//2
+  const double delta = (N % 2 == 0) ? 0.5 : 0.0;
+  double tp[2 * kRg + 2];
+  const int o0 = (int)nearbyint(delta);
+  for (int k = 0; k <= 2 * kRg; ++k) {
+    const double x = (o0 - kRg + k) - delta;
+    tp[k] = exp(-0.5 * x * x / ((double)kSigmaG * kSigmaG)) / (sqrt(2.0 * M_PI) * kSigmaG);
+  }
+  acc = 0;
+  for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
+    const int u = i / N, v = i % N;
+    double a = 0;
+    for (int ku = 0; ku <= 2 * kRg; ++ku) {
+      const int uu = u - (o0 - kRg + ku);
+      if (uu < 0 || uu >= N) continue;
+      double r = 0;
+      for (int kv = 0; kv <= 2 * kRg; ++kv) {
+        const int vv = v - (o0 - kRg + kv);
+        if (vv < 0 || vv >= N) continue;
+        r += tp[kv] * narrow[o + (size_t)uu * N + vv];
+      }
+      a += tp[ku] * r;
+    }
+    full[o + i] = (float)a;
+    acc += a;
+  }
+  const double SF = block_sum_d(acc, sh);
+  for (int i = threadIdx.x; i < N * N; i += blockDim.x) full[o + i] = (float)(full[o + i] / SF);
+}
+
+__global__ void psf_residual_kernel(int S, int n, const float *data, const float *wgt, const float *model,
+                                    float *resid, float *redchi2) {
+  __shared__ double sh[256];
+  const int f = blockIdx.x;
+  const size_t o = (size_t)f * S * n * n;
+  double chi = 0, cnt = 0;
+  for (int i = threadIdx.x; i < S * n * n; i += blockDim.x) {
+    const float r = data[o + i] - model[o + i];
+    resid[o + i] = r;
+    chi += (double)wgt[o + i] * r * r;
+    cnt += wgt[o + i] > 0.f ? 1.0 : 0.0;
+  }
+  const double C = block_sum_d(chi, sh);
+  const double K = block_sum_d(cnt, sh);
+  if (threadIdx.x == 0) redchi2[f] = (float)(C / (K > 0 ? K : 1.0));
+}
+
+// ---- noise propagation of the chi2 gradient w.r.t. B into starlet space ---------------------------
+// V[u'][v'] = sum_s a_s^2 sum_{u,v} up(w_s)[u][v] phi_y^2(u - u') phi_x^2(v - v')
+__global__ void psf_noise_v_kernel(int S, int n, int ss, const float *wgt, const float *stars, float *V) {
+  const int N = n * ss, f = blockIdx.x;
+  const double c_off = (N % 2 == 0) ? 0.5 : 0.0;
+  const double is2 = 1.0 / ((double)kSigmaG * kSigmaG), nrm = 1.0 / (sqrt(2.0 * M_PI) * kSigmaG);
+  for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
+    const int up = i / N, vp = i % N;
+    double acc = 0;
+    for (int s = 0; s < S; ++s) {
+      const float *st = stars + ((size_t)f * S + s) * 4;
+      const double a = st[0], dx = ss * (double)st[1] + c_off, dy = ss * (double)st[2] + c_off;
+      const int ox = (int)nearbyint(dx), oy = (int)nearbyint(dy);
+      double r = 0;
+      for (int tu = oy - kRg; tu <= oy + kRg; ++tu) {
+        const int u = up + tu;
+        if (u < 0 || u >= N) continue;
+        const double py = nrm * exp(-0.5 * (tu - dy) * (tu - dy) * is2);
+        double rr = 0;
+        for (int tv = ox - kRg; tv <= ox + kRg; ++tv) {
+          const int v = vp + tv;
+          if (v < 0 || v >= N) continue;
+          const double px = nrm * exp(-0.5 * (tv - dx) * (tv - dx) * is2);
+          rr += px * px * wgt[((size_t)f * S + s) * n * n + (size_t)(u / ss) * n + v / ss];
+        }
+        r += py * py * rr;
+      }
+      acc += a * a * r;
+    }
+    V[(size_t)f * N * N + i] = (float)acc;
+  }
+}
+
+// W_j = sqrt( sum_{term} c_term * (k_term (x) k_term) (*) V ), 'same' with zero lag at (N-1)//2.
+// atoms: [J+1][3][N] 1-D factors; coefficients {+1, -2, +1}.  One block per (frame, scale).
+__global__ void psf_noise_w_kernel(int N, int J, const float *V, const float *atoms, float *W, float *tmp) {
+  const int f = blockIdx.x, j = blockIdx.y;
+  const int c = (N - 1) / 2;
+  const float *Vf = V + (size_t)f * N * N;
+  float *t = tmp + ((size_t)f * J + j) * N * N;
+  float *Wf = W + ((size_t)f * J + j) * N * N;
+  const float coef[3] = {1.f, -2.f, 1.f};
+  for (int i = threadIdx.x; i < N * N; i += blockDim.x) Wf[i] = 0.f;
+  for (int term = 0; term < 3; ++term) {
+    const float *k = atoms + ((size_t)j * 3 + term) * N;
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * N; i += blockDim.x) {  // rows
+      const int u = i / N, v = i % N;
+      double acc = 0;
+      for (int vp = 0; vp < N; ++vp) {
+        const int kk = v - vp + c;
+        if (kk >= 0 && kk < N) acc += (double)Vf[u * N + vp] * k[kk];
+      }
+      t[i] = (float)acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * N; i += blockDim.x) {  // columns
+      const int u = i / N, v = i % N;
+      double acc = 0;
+      for (int upp = 0; upp < N; ++upp) {
+        const int kk = u - upp + c;
+        if (kk >= 0 && kk < N) acc += (double)t[upp * N + v] * k[kk];
+      }
+      Wf[i] += coef[term] * (float)acc;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N * N; i += blockDim.x) Wf[i] = sqrtf(fmaxf(Wf[i], 0.f));
+}
+
+// 1-D starlet cascade of a dirac at the zero-lag index with edge replication: p_j = A_j delta_c.
+void starlet_atoms_1d(int N, int J, std::vector<std::vector<double>> &p) {
+  const double b3[5] = {1. / 16, 4. / 16, 6. / 16, 4. / 16, 1. / 16};
+  p.assign(J + 1, std::vector<double>(N, 0.0));
+  p[0][(N - 1) / 2] = 1.0;
+  for (int j = 0; j < J; ++j) {
+    const int d = 1 << j;
+    for (int i = 0; i < N; ++i) {
+      double acc = 0;
+      for (int t = -2; t <= 2; ++t) acc += b3[t + 2] * p[j][std::min(std::max(i + t * d, 0), N - 1)];
+      p[j + 1][i] = acc;
+    }
+  }
+}
+
+typedef void (*psf_kernel_fn)(PsfArgs);
+struct PsfVariant {
+  int n, ss;
+  psf_kernel_fn fn;
+  int nthr, lds_bytes;
+};
+
+template <class C>
+PsfVariant make_variant() {
+  return PsfVariant{C::n, C::SS, psf_fit_kernel<C>, C::NTHR, (int)(C::LDS_FLOATS * sizeof(float))};
+}
+
+const PsfVariant *find_variant(int n, int ss) {
+  static const PsfVariant table[] = {
+      make_variant<PsfCfg<16, 1, 4, 4>>(),    // n = 16, ss = 1 (reference test fixture size)
+      make_variant<PsfCfg<32, 2, 4, 4>>(),    // n = 16, ss = 2
+      make_variant<PsfCfg<48, 2, 4, 4>>(),    // n = 24 (lightcurver default stamp_size_stars)
+      make_variant<PsfCfg<64, 2, 4, 4>>(),    // n = 32 (C1, C2)
+      make_variant<PsfCfg<128, 2, 16, 1>>(),  // n = 64 (C3)
+  };
+  for (const auto &v : table)
+    if (v.n == n && v.ss == ss) return &v;
+  return nullptr;
+}
+
+int launch_psf(lc_psf_batch *b, int mode, int n_iter, const lc_adabelief_cfg *cfg, bool want_outputs,
+               bool reg) {
+  const PsfVariant *v = find_variant(b->n, b->ss);
+  if (!v) LC_FAIL(b->ctx, LC_ERR_UNSUPPORTED, "no PSF kernel instantiated for this stamp size");
+  PsfArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.F = b->F;
+  A.S = b->S;
+  A.n_iter = n_iter;
+  A.t0 = b->iters_done;
+  A.hist_stride = b->hist_stride;
+  A.mode = mode;
+  A.data = b->data;
+  A.wgt = b->wgt;
+  A.W = b->have_W ? b->W : nullptr;
+  A.norms = b->norms;
+  A.Tm = b->Tm;
+  A.B = b->B;
+  A.mB = b->mB;
+  A.sB = b->sB;
+  A.stars = b->stars;
+  A.stars_m = b->stars_m;
+  A.stars_s = b->stars_s;
+  A.hist = b->hist;
+  A.qscratch = b->qscratch;
+  if (want_outputs) {
+    A.out_loss = b->o_loss;
+    A.out_chi2 = b->o_chi2;
+    A.out_gstars = b->o_gstars;
+    A.out_ggrid = b->o_ggrid;
+    A.out_gT = b->o_gT;
+    A.out_model = b->o_model;
+  }
+  A.lam_sc = reg ? b->lam_sc : 0.f;
+  A.lam_hf = reg ? b->lam_hf : 0.f;
+  if (cfg) A.ab = *cfg; else lc_adabelief_defaults(&A.ab);
+  LC_HIP(b->ctx, hipFuncSetAttribute((const void *)v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes));
+  hipLaunchKernelGGL(v->fn, dim3(b->F), dim3(v->nthr), v->lds_bytes, b->ctx->stream, A);
+  LC_HIP(b->ctx, hipGetLastError());
+  return LC_OK;
+}
+
+int ensure_hist(lc_psf_batch *b, int needed) {
+  if (needed <= b->hist_stride) return LC_OK;
+  int ns = std::max(needed, 2 * b->hist_stride + 64);
+  float *nh = nullptr;
+  LC_HIP(b->ctx, hipMalloc((void **)&nh, (size_t)b->F * ns * sizeof(float)));
+  LC_HIP(b->ctx, hipMemsetAsync(nh, 0, (size_t)b->F * ns * sizeof(float), b->ctx->stream));
+  if (b->hist) {
+    LC_HIP(b->ctx, hipMemcpy2DAsync(nh, ns * sizeof(float), b->hist, b->hist_stride * sizeof(float),
+                                     b->hist_stride * sizeof(float), b->F, hipMemcpyDeviceToDevice, b->ctx->stream));
+    LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    hipFree(b->hist);
+  }
+  b->hist = nh;
+  b->hist_stride = ns;
+  return LC_OK;
+}
+
+int h2d(lc_psf_batch *b, void *dst, const void *src, size_t bytes) {
+  LC_HIP(b->ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->ctx->stream));
+  LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
+  return LC_OK;
+}
+int d2h(lc_psf_batch *b, void *dst, const void *src, size_t bytes) {
+  LC_HIP(b->ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b->ctx->stream));
+  LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
+  return LC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lc_psf_supported(int n, int ss) { return find_variant(n, ss) != nullptr; }
+
+int lc_psf_batch_create(lc_ctx *ctx, int F, int S_max, int n, int ss, const float *data, const float *weight,
+                        lc_psf_batch **out) {
+  if (!ctx || !out || !data || !weight || F <= 0 || S_max <= 0) {
+    if (ctx) ctx->err = "lc_psf_batch_create: invalid argument";
+    return LC_ERR_INVALID;
+  }
+  if (S_max > 16) LC_FAIL(ctx, LC_ERR_UNSUPPORTED, "at most 16 stars per frame");
+  if (!find_variant(n, ss)) LC_FAIL(ctx, LC_ERR_UNSUPPORTED, "no PSF kernel instantiated for this stamp size");
+  LC_HIP(ctx, hipSetDevice(ctx->device));
+  lc_psf_batch *b = new lc_psf_batch();
+  b->ctx = ctx;
+  b->F = F;
+  b->S = S_max;
+  b->n = n;
+  b->ss = ss;
+  b->N = n * ss;
+  b->J = ilog2(b->N);
+  const size_t NN = (size_t)b->N * b->N, nn = (size_t)n * n;
+  int rc = 0;
+#define TRY(x)            \
+  if ((rc = (x)) != 0) {  \
+    lc_psf_batch_destroy(b); \
+    return rc;            \
+  }
+  TRY(dmalloc(b, &b->data, F * S_max * nn));
+  TRY(dmalloc(b, &b->wgt, F * S_max * nn));
+  TRY(dmalloc(b, &b->W, F * (size_t)b->J * NN));
+  TRY(dmalloc(b, &b->norms, b->J + 1));
+  TRY(dmalloc(b, &b->Tm, F * NN));
+  TRY(dmalloc(b, &b->B, F * NN));
+  TRY(dmalloc(b, &b->mB, F * NN));
+  TRY(dmalloc(b, &b->sB, F * NN));
+  TRY(dmalloc(b, &b->stars, (size_t)F * S_max * 4));
+  TRY(dmalloc(b, &b->stars_m, (size_t)F * S_max * 4));
+  TRY(dmalloc(b, &b->stars_s, (size_t)F * S_max * 4));
+  TRY(dmalloc(b, &b->moffat, (size_t)F * 4));
+  TRY(dmalloc(b, &b->qscratch, F * (size_t)b->J * NN));
+  TRY(dmalloc(b, &b->o_loss, F));
+  TRY(dmalloc(b, &b->o_chi2, F));
+  TRY(dmalloc(b, &b->o_gstars, (size_t)F * S_max * 4));
+  TRY(dmalloc(b, &b->o_ggrid, F * NN));
+  TRY(dmalloc(b, &b->o_gT, F * NN));
+  TRY(dmalloc(b, &b->o_model, F * S_max * nn));
+  TRY(dmalloc(b, &b->o_gmoffat, (size_t)F * 4));
+  TRY(dmalloc(b, &b->narrow, F * NN));
+  TRY(dmalloc(b, &b->full, F * NN));
+  TRY(dmalloc(b, &b->resid, F * S_max * nn));
+  TRY(dmalloc(b, &b->redchi2, F));
+  TRY(dmalloc(b, &b->atoms, (size_t)(b->J + 1) * 3 * b->N));
+  TRY(dmalloc(b, &b->V, F * NN));
+  TRY(ensure_hist(b, 64));
+  // sanitise inputs: non-finite data or weight -> weight 0 (NaN handling of psf_modelling.py:136-140)
+  {
+    std::vector<float> d(data, data + F * S_max * nn), w(weight, weight + F * S_max * nn);
+    for (size_t i = 0; i < d.size(); ++i)
+      if (!std::isfinite(d[i]) || !std::isfinite(w[i]) || w[i] < 0.f) {
+        d[i] = 0.f;
+        w[i] = 0.f;
+      }
+    TRY(h2d(b, b->data, d.data(), d.size() * sizeof(float)));
+    TRY(h2d(b, b->wgt, w.data(), w.size() * sizeof(float)));
+  }
+  // starlet scale norms and the separable factors of psi_j^2
+  {
+    std::vector<std::vector<double>> p;
+    starlet_atoms_1d(b->N, b->J, p);
+    std::vector<float> norms(b->J + 1), atoms((size_t)(b->J + 1) * 3 * b->N, 0.f);
+    for (int j = 0; j <= b->J; ++j) {
+      // 2-D atom: psi_j = p_j (x) p_j - p_{j+1} (x) p_{j+1} (detail), coarse: p_J (x) p_J
+      double s_pp = 0, s_qq = 0, s_pq = 0;
+      for (int i = 0; i < b->N; ++i) {
+        const double pj = p[j][i], qj = (j < b->J) ? p[j + 1][i] : 0.0;
+        s_pp += pj * pj;
+        s_qq += qj * qj;
+        s_pq += pj * qj;
+        atoms[((size_t)j * 3 + 0) * b->N + i] = (float)(pj * pj);
+        atoms[((size_t)j * 3 + 1) * b->N + i] = (float)(pj * qj);
+        atoms[((size_t)j * 3 + 2) * b->N + i] = (float)(qj * qj);
+      }
+      norms[j] = (float)std::sqrt(std::max(s_pp * s_pp - 2.0 * s_pq * s_pq + s_qq * s_qq, 0.0));
+    }
+    TRY(h2d(b, b->norms, norms.data(), norms.size() * sizeof(float)));
+    TRY(h2d(b, b->atoms, atoms.data(), atoms.size() * sizeof(float)));
+  }
+#undef TRY
+  *out = b;
+  return LC_OK;
+}
+
+void lc_psf_batch_destroy(lc_psf_batch *b) {
+  if (!b) return;
+  hipStreamSynchronize(b->ctx->stream);
+  for (void *p : b->allocs) hipFree(p);
+  if (b->hist) hipFree(b->hist);
+  delete b;
+}
+
+int lc_psf_batch_set_moffat(lc_psf_batch *b, const float *moffat) {
+  if (!b || !moffat) return LC_ERR_INVALID;
+  int rc = h2d(b, b->moffat, moffat, (size_t)b->F * 4 * sizeof(float));
+  if (rc) return rc;
+  hipLaunchKernelGGL(moffat_raster_kernel, dim3(b->F), dim3(256), 0, b->ctx->stream, b->N, b->ss, b->moffat, b->Tm);
+  LC_HIP(b->ctx, hipGetLastError());
+  return LC_OK;
+}
+int lc_psf_batch_get_moffat(lc_psf_batch *b, float *moffat) {
+  if (!b || !moffat) return LC_ERR_INVALID;
+  return d2h(b, moffat, b->moffat, (size_t)b->F * 4 * sizeof(float));
+}
+int lc_psf_batch_set_stars(lc_psf_batch *b, const float *stars) {
+  if (!b || !stars) return LC_ERR_INVALID;
+  return h2d(b, b->stars, stars, (size_t)b->F * b->S * 4 * sizeof(float));
+}
+int lc_psf_batch_get_stars(lc_psf_batch *b, float *stars) {
+  if (!b || !stars) return LC_ERR_INVALID;
+  return d2h(b, stars, b->stars, (size_t)b->F * b->S * 4 * sizeof(float));
+}
+int lc_psf_batch_set_grid(lc_psf_batch *b, const float *grid) {
+  if (!b) return LC_ERR_INVALID;
+  const size_t bytes = (size_t)b->F * b->N * b->N * sizeof(float);
+  if (grid) return h2d(b, b->B, grid, bytes);
+  LC_HIP(b->ctx, hipMemsetAsync(b->B, 0, bytes, b->ctx->stream));
+  LC_HIP(b->ctx, hipMemsetAsync(b->mB, 0, bytes, b->ctx->stream));
+  LC_HIP(b->ctx, hipMemsetAsync(b->sB, 0, bytes, b->ctx->stream));
+  LC_HIP(b->ctx, hipMemsetAsync(b->stars_m, 0, (size_t)b->F * b->S * 4 * sizeof(float), b->ctx->stream));
+  LC_HIP(b->ctx, hipMemsetAsync(b->stars_s, 0, (size_t)b->F * b->S * 4 * sizeof(float), b->ctx->stream));
+  b->iters_done = 0;
+  return LC_OK;
+}
+int lc_psf_batch_get_grid(lc_psf_batch *b, float *grid) {
+  if (!b || !grid) return LC_ERR_INVALID;
+  return d2h(b, grid, b->B, (size_t)b->F * b->N * b->N * sizeof(float));
+}
+int lc_psf_batch_set_regularization(lc_psf_batch *b, const float *W, float lam_scales, float lam_hf) {
+  if (!b) return LC_ERR_INVALID;
+  b->lam_sc = lam_scales;
+  b->lam_hf = lam_hf;
+  if (W) {
+    int rc = h2d(b, b->W, W, (size_t)b->F * b->J * b->N * b->N * sizeof(float));
+    if (rc) return rc;
+    b->have_W = true;
+  }
+  return LC_OK;
+}
+int lc_psf_batch_propagate_noise(lc_psf_batch *b) {
+  if (!b) return LC_ERR_INVALID;
+  hipLaunchKernelGGL(psf_noise_v_kernel, dim3(b->F), dim3(256), 0, b->ctx->stream, b->S, b->n, b->ss, b->wgt,
+                     b->stars, b->V);
+  // qscratch doubles as the row-pass temporary ([F][J][N*N])
+  hipLaunchKernelGGL(psf_noise_w_kernel, dim3(b->F, b->J), dim3(256), 0, b->ctx->stream, b->N, b->J, b->V, b->atoms,
+                     b->W, b->qscratch);
+  LC_HIP(b->ctx, hipGetLastError());
+  b->have_W = true;
+  return LC_OK;
+}
+int lc_psf_batch_get_weights(lc_psf_batch *b, float *W) {
+  if (!b || !W) return LC_ERR_INVALID;
+  return d2h(b, W, b->W, (size_t)b->F * b->J * b->N * b->N * sizeof(float));
+}
+
+int lc_psf_batch_eval(lc_psf_batch *b, float *loss, float *chi2, float *grad_moffat, float *grad_stars,
+                      float *grad_grid, float *model) {
+  if (!b) return LC_ERR_INVALID;
+  int rc = ensure_hist(b, b->iters_done + 1);
+  if (rc) return rc;
+  rc = launch_psf(b, 0, 1, nullptr, true, true);
+  if (rc) return rc;
+  if (grad_moffat) {
+    hipLaunchKernelGGL(moffat_grad_kernel, dim3(b->F), dim3(256), 0, b->ctx->stream, b->N, b->ss, b->moffat, b->o_gT,
+                       b->o_gmoffat);
+    LC_HIP(b->ctx, hipGetLastError());
+  }
+  const size_t NN = (size_t)b->N * b->N, nn = (size_t)b->n * b->n;
+  if (loss && (rc = d2h(b, loss, b->o_loss, b->F * sizeof(float)))) return rc;
+  if (chi2 && (rc = d2h(b, chi2, b->o_chi2, b->F * sizeof(float)))) return rc;
+  if (grad_moffat && (rc = d2h(b, grad_moffat, b->o_gmoffat, (size_t)b->F * 4 * sizeof(float)))) return rc;
+  if (grad_stars && (rc = d2h(b, grad_stars, b->o_gstars, (size_t)b->F * b->S * 4 * sizeof(float)))) return rc;
+  if (grad_grid && (rc = d2h(b, grad_grid, b->o_ggrid, b->F * NN * sizeof(float)))) return rc;
+  if (model && (rc = d2h(b, model, b->o_model, b->F * b->S * nn * sizeof(float)))) return rc;
+  LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
+  return LC_OK;
+}
+
+int lc_psf_batch_fit_moffat(lc_psf_batch *b, int n_iter, float *final_loss) {
+  if (!b || n_iter < 0) return LC_ERR_INVALID;
+  const int F = b->F, S = b->S, D = 4 + 3 * S;
+  std::vector<float> mof((size_t)F * 4), st((size_t)F * S * 4);
+  int rc;
+  if ((rc = d2h(b, mof.data(), b->moffat, mof.size() * sizeof(float)))) return rc;
+  if ((rc = d2h(b, st.data(), b->stars, st.size() * sizeof(float)))) return rc;
+  std::vector<double> x((size_t)F * D), lo((size_t)F * D), hi((size_t)F * D);
+  const double inf = std::numeric_limits<double>::infinity();
+  for (int f = 0; f < F; ++f) {
+    double *xf = &x[(size_t)f * D], *l = &lo[(size_t)f * D], *h = &hi[(size_t)f * D];
+    for (int k = 0; k < 4; ++k) xf[k] = mof[f * 4 + k];
+    l[0] = l[1] = 0.5 / b->ss;
+    h[0] = h[1] = b->n / 2.0;
+    l[2] = -M_PI;
+    h[2] = M_PI;
+    l[3] = 1.1;
+    h[3] = 50.0;
+    for (int s = 0; s < S; ++s) {
+      xf[4 + s] = st[((size_t)f * S + s) * 4 + 0];
+      xf[4 + S + s] = st[((size_t)f * S + s) * 4 + 1];
+      xf[4 + 2 * S + s] = st[((size_t)f * S + s) * 4 + 2];
+      l[4 + s] = 0.0;
+      h[4 + s] = inf;
+      l[4 + S + s] = l[4 + 2 * S + s] = -b->n / 4.0;
+      h[4 + S + s] = h[4 + 2 * S + s] = b->n / 4.0;
+    }
+  }
+  std::vector<float> loss(F), gm((size_t)F * 4), gs((size_t)F * S * 4);
+  const bool had_W = b->have_W;
+  auto eval = [&](const std::vector<double> &X, std::vector<double> &Fv, std::vector<double> &G) -> int {
+    for (int f = 0; f < F; ++f) {
+      const double *xf = &X[(size_t)f * D];
+      for (int k = 0; k < 4; ++k) mof[f * 4 + k] = (float)xf[k];
+      for (int s = 0; s < S; ++s) {
+        st[((size_t)f * S + s) * 4 + 0] = (float)xf[4 + s];
+        st[((size_t)f * S + s) * 4 + 1] = (float)xf[4 + S + s];
+        st[((size_t)f * S + s) * 4 + 2] = (float)xf[4 + 2 * S + s];
+      }
+    }
+    int r;
+    if ((r = lc_psf_batch_set_moffat(b, mof.data()))) return r;
+    if ((r = lc_psf_batch_set_stars(b, st.data()))) return r;
+    if ((r = ensure_hist(b, b->iters_done + 1))) return r;
+    if ((r = launch_psf(b, 0, 1, nullptr, true, false))) return r;  // stage A: no regularisation (B fixed)
+    hipLaunchKernelGGL(moffat_grad_kernel, dim3(F), dim3(256), 0, b->ctx->stream, b->N, b->ss, b->moffat, b->o_gT,
+                       b->o_gmoffat);
+    if ((r = d2h(b, loss.data(), b->o_loss, F * sizeof(float)))) return r;
+    if ((r = d2h(b, gm.data(), b->o_gmoffat, gm.size() * sizeof(float)))) return r;
+    if ((r = d2h(b, gs.data(), b->o_gstars, gs.size() * sizeof(float)))) return r;
+    for (int f = 0; f < F; ++f) {
+      Fv[f] = loss[f];
+      double *g = &G[(size_t)f * D];
+      for (int k = 0; k < 4; ++k) g[k] = gm[f * 4 + k];
+      for (int s = 0; s < S; ++s) {
+        g[4 + s] = gs[((size_t)f * S + s) * 4 + 0];
+        g[4 + S + s] = gs[((size_t)f * S + s) * 4 + 1];
+        g[4 + 2 * S + s] = gs[((size_t)f * S + s) * 4 + 2];
+      }
+    }
+    return 0;
+  };
+  LbfgsResult res;
+  rc = batched_lbfgs(F, D, x, lo, hi, n_iter, eval, res);
+  if (rc) return rc;
+  // leave the device at the accepted optimum
+  std::vector<double> Fv(F), G((size_t)F * D);
+  if ((rc = eval(x, Fv, G))) return rc;
+  b->have_W = had_W;
+  if (final_loss)
+    for (int f = 0; f < F; ++f) final_loss[f] = (float)Fv[f];
+  return LC_OK;
+}
+
+int lc_psf_batch_run_adabelief(lc_psf_batch *b, int n_iter, const lc_adabelief_cfg *cfg) {
+  if (!b || n_iter <= 0) return LC_ERR_INVALID;
+  int rc = ensure_hist(b, b->iters_done + n_iter + 1);
+  if (rc) return rc;
+  rc = launch_psf(b, 1, n_iter, cfg, false, true);
+  if (rc) return rc;
+  b->iters_done += n_iter;
+  return LC_OK;
+}
+int lc_psf_batch_iterations_done(lc_psf_batch *b) { return b ? b->iters_done : LC_ERR_INVALID; }
+
+int lc_psf_batch_get_loss_history(lc_psf_batch *b, float *history, int stride) {
+  if (!b || !history || stride < b->iters_done + 1) return LC_ERR_INVALID;
+  int rc = launch_psf(b, 0, 1, nullptr, false, true);  // loss of the final parameters -> hist[T]
+  if (rc) return rc;
+  LC_HIP(b->ctx, hipMemcpy2DAsync(history, stride * sizeof(float), b->hist, b->hist_stride * sizeof(float),
+                                   (b->iters_done + 1) * sizeof(float), b->F, hipMemcpyDeviceToHost, b->ctx->stream));
+  LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
+  return LC_OK;
+}
+
+int lc_psf_batch_get_results(lc_psf_batch *b, float *narrow_psf, float *full_psf, float *residuals, float *chi2) {
+  if (!b) return LC_ERR_INVALID;
+  int rc = ensure_hist(b, b->iters_done + 1);
+  if (rc) return rc;
+  rc = launch_psf(b, 0, 1, nullptr, true, true);
+  if (rc) return rc;
+  hipLaunchKernelGGL(psf_finalize_kernel, dim3(b->F), dim3(256), 0, b->ctx->stream, b->N, b->Tm, b->B, b->narrow,
+                     b->full);
+  hipLaunchKernelGGL(psf_residual_kernel, dim3(b->F), dim3(256), 0, b->ctx->stream, b->S, b->n, b->data, b->wgt,
+                     b->o_model, b->resid, b->redchi2);
+  LC_HIP(b->ctx, hipGetLastError());
+  const size_t NN = (size_t)b->N * b->N, nn = (size_t)b->n * b->n;
+  if (narrow_psf && (rc = d2h(b, narrow_psf, b->narrow, b->F * NN * sizeof(float)))) return rc;
+  if (full_psf && (rc = d2h(b, full_psf, b->full, b->F * NN * sizeof(float)))) return rc;
+  if (residuals && (rc = d2h(b, residuals, b->resid, b->F * b->S * nn * sizeof(float)))) return rc;
+  if (chi2 && (rc = d2h(b, chi2, b->redchi2, b->F * sizeof(float)))) return rc;
+  LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
+  return LC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,628 @@
+// PSF-fit device code: one persistent workgroup per frame (gfx950, wave64).
+//
+// Replaces the arithmetic of starred.procedures.psf_routines.build_psf as called at
+// lightcurver/processes/psf_modelling.py:164-171 (reference).  Model of star i of a frame:
+//     f_i = a_i * D_ss[ G(x0_i, y0_i) (*) (Moffat + B) ] + sky_i
+// G is the separable FWHM-2 Gaussian, so the forward is a 1-D row pass fused with the column
+// down-sampling followed by a 1-D column pass fused with the row down-sampling; the backward is
+// the two transposed passes.  T = Moffat + B, the per-star intermediates and the weighted
+// residuals live in LDS; B's chi2 gradient stays in registers through the starlet phase.
+#pragma once
+#include "lc_common.h"
+
+namespace lc {
+
+struct PsfArgs {
+  int F, S, n_iter, t0, hist_stride, mode;  // mode 0 = evaluate, 1 = AdaBelief loop
+  const float *data, *wgt;                  // [F][S][n][n]
+  const float *W;                           // [F][J][N*N] or null
+  const float *norms;                       // [J] starlet scale norms (used when W == null)
+  const float *Tm;                          // [F][N*N] unit-sum Moffat
+  float *B, *mB, *sB;                       // [F][N*N] pixel grid and AdaBelief moments
+  float *stars, *stars_m, *stars_s;         // [F][S][4] a, x0, y0, sky (+ moments)
+  float *hist;                              // [F][hist_stride]
+  float *qscratch;                          // [F][J][N*N] thread-private l1 sub-gradients
+  float *out_loss, *out_chi2, *out_gstars, *out_ggrid, *out_gT, *out_model;  // eval outputs (nullable)
+  float lam_sc, lam_hf;
+  lc_adabelief_cfg ab;
+};
+
+template <int N_, int SS_, int PX_, int SG_>
+struct PsfCfg {
+  static constexpr int N = N_, SS = SS_, PX = PX_, SG = SG_;
+  static constexpr int n = N / SS;
+  static constexpr int NTHR = N * N / PX;
+  static constexpr int NW = (NTHR + kWave - 1) / kWave;
+  static constexpr int NT = ntaps(SS);
+  static constexpr int J = ilog2(N);
+  static constexpr int LR = 8;  // row-pass strip (down-sampled columns per work item)
+  static constexpr int LC = 4;  // column-pass strip (down-sampled rows per work item)
+  static constexpr int LA = 4;  // transposed column pass: LA data rows = SS*LA high-res rows
+  static constexpr int TS = N + 1;  // padded LDS row stride of N-long rows
+  static constexpr int RS = n + 1;  // padded LDS row stride of n-long rows
+  // LDS carve-up (floats)
+  static constexpr int OFF_T = 0;
+  static constexpr int SZ_T = N * TS;
+  static constexpr int OFF_R = OFF_T + SZ_T;
+  static constexpr int SZ_R2 = SG * n * TS;  // R2t / R2xt: [SG][n][TS]
+  static constexpr int SZ_V = SG * N * RS;   // V: [SG][N][RS]
+  static constexpr int SZ_R = (2 * SZ_R2 > SZ_V) ? 2 * SZ_R2 : SZ_V;
+  static constexpr int OFF_RES = OFF_R + SZ_R;
+  static constexpr int SZ_RES = SG * n * n;
+  static constexpr int OFF_TAPS = OFF_RES + SZ_RES;
+  static constexpr int SZ_TAPS = SG * 4 * NT;
+  static constexpr int OFF_RED = OFF_TAPS + SZ_TAPS;
+  static constexpr int IPS = n * n / LC;  // column-pass items per star
+  static constexpr int IPS_PAD = (IPS + kWave - 1) / kWave * kWave;
+  static constexpr int SLOTS = IPS_PAD / kWave;
+  static constexpr int SZ_RED = SG * SLOTS * 5 + NW + 8;
+  static constexpr int OFF_STAR = OFF_RED + SZ_RED;  // star params, grads, moments, ints
+  static constexpr int MAXS = 16;
+  static constexpr int SZ_STAR = MAXS * 20 + 16;
+  static constexpr int LDS_FLOATS = OFF_STAR + SZ_STAR;
+  static_assert(2 * N * TS <= SZ_T + SZ_R, "starlet ping-pong buffers must fit over T + R");
+  static_assert(PX % SS == 0 && N % PX == 0 && n % LR == 0 && n % LC == 0 && n % LA == 0, "tiling");
+  static_assert(NTHR <= 1024 && NTHR % kWave == 0, "threads");
+};
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// starred's first-generation starlet uses the B3 spline [1,4,6,4,1]/16.
+__device__ __forceinline__ float b3tap(int t) {  // t in [-2, 2]
+  return (t == 0) ? 0.375f : ((t == 1 || t == -1) ? 0.25f : 0.0625f);
+}
+
+// Build the aligned tap tables of one (star, axis): taps[k] = Phi(base' + k), dtaps[k] = dPhi/ddelta.
+// Phi(m) = sum_{dv<SS} phi(m + dv), phi(t) = N(t; delta, sigma) truncated to |t - round(delta)| <= kRg.
+template <int SS, int NT>
+__device__ inline void tap_entry(float delta, int k, float &tap, float &dtap, int &bq) {
+  const int o = (int)nearbyintf(delta);
+  const int base = o - kRg - (SS - 1);
+  int q = base / SS;
+  if (q * SS > base) --q;  // floor division
+  bq = q;
+  const int m = q * SS + k;
+  const float inv_s2 = 1.0f / (kSigmaG * kSigmaG);
+  const float nrm = 0.3989422804014327f / kSigmaG;
+  float a = 0.f, d = 0.f;
+#pragma unroll
+  for (int dv = 0; dv < SS; ++dv) {
+    const int t = m + dv;
+    if (t >= o - kRg && t <= o + kRg) {
+      const float x = (float)t - delta;
+      const float p = nrm * expf(-0.5f * x * x * inv_s2);
+      a += p;
+      d += p * x * inv_s2;
+    }
+  }
+  tap = a;
+  dtap = d;
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
+  constexpr int N = C::N, SS = C::SS, PX = C::PX, SG = C::SG, n = C::n, NT = C::NT, J = C::J;
+  constexpr int NTHR = C::NTHR, TS = C::TS, RS = C::RS, LR = C::LR, LC = C::LC, LA = C::LA;
+  extern __shared__ float lds[];
+  float *T = lds + C::OFF_T;
+  float *R2t = lds + C::OFF_R;
+  float *R2xt = R2t + C::SZ_R2;
+  float *V = lds + C::OFF_R;
+  float *RES = lds + C::OFF_RES;
+  float *TAPS = lds + C::OFF_TAPS;  // [SG][4][NT]: tx, dtx, ty, dty
+  float *RED = lds + C::OFF_RED;    // [SG][SLOTS][5] + [NW] + scalars
+  float *REDW = RED + SG * C::SLOTS * 5;
+  float *SCAL = REDW + C::NW;  // lr, bc1, bc2, l1, loss
+  float *SP = lds + C::OFF_STAR;    // star params [MAXS][4]
+  float *SGR = SP + C::MAXS * 4;    // star grads [MAXS][5]: chi2, ga, gx, gy, gsky
+  float *SM = SGR + C::MAXS * 5;    // moments m [MAXS][4]
+  float *SV = SM + C::MAXS * 4;     // moments s [MAXS][4]
+  int *BQ = (int *)(SV + C::MAXS * 4);  // [SG][2]
+  float *bufA = lds;                // starlet ping-pong, overlays T + R
+  float *bufB = lds + N * TS;
+
+  const int f = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int S = A.S;
+  const int pu = tid / (N / PX);          // owned row
+  const int pv = (tid % (N / PX)) * PX;   // first owned column
+  const size_t gpix = (size_t)f * N * N + (size_t)pu * N + pv;
+
+  const float *dataf = A.data + (size_t)f * S * n * n;
+  const float *wgtf = A.wgt + (size_t)f * S * n * n;
+
+  if (tid < S * 4) {
+    SP[tid] = A.stars[(size_t)f * S * 4 + tid];
+    SM[tid] = A.stars_m[(size_t)f * S * 4 + tid];
+    SV[tid] = A.stars_s[(size_t)f * S * 4 + tid];
+  }
+  __syncthreads();
+
+  for (int it = 0; it < A.n_iter; ++it) {
+    const int tglob = A.t0 + it;
+    if (tid == 0 && A.mode == 1) {
+      const double t1 = (double)(tglob + 1);
+      double lr = A.ab.init_learning_rate;
+      if (A.ab.schedule_learning_rate)
+        lr *= pow((double)A.ab.decay_rate, (double)tglob / (double)A.ab.transition_steps);
+      SCAL[0] = (float)lr;
+      SCAL[1] = (float)(1.0 / (1.0 - pow((double)A.ab.b1, t1)));
+      SCAL[2] = (float)(1.0 / (1.0 - pow((double)A.ab.b2, t1)));
+    }
+    // ---- P1: T = Moffat + B into LDS -----------------------------------------------------
+    float gB[PX];
+    {
+      const float4 *bp = (const float4 *)(A.B + gpix);
+      const float4 *tp = (const float4 *)(A.Tm + gpix);
+#pragma unroll
+      for (int q = 0; q < PX / 4; ++q) {
+        const float4 b = bp[q], t = tp[q];
+        T[pu * TS + pv + 4 * q + 0] = b.x + t.x;
+        T[pu * TS + pv + 4 * q + 1] = b.y + t.y;
+        T[pu * TS + pv + 4 * q + 2] = b.z + t.z;
+        T[pu * TS + pv + 4 * q + 3] = b.w + t.w;
+      }
+#pragma unroll
+      for (int p = 0; p < PX; ++p) gB[p] = 0.f;
+    }
+    if (tid < S * 5) SGR[tid] = 0.f;
+
+    for (int g0 = 0; g0 < S; g0 += SG) {
+      // ---- tap tables of the stars of this group ------------------------------------------
+      __syncthreads();  // previous group's P5 (reads TAPS, V) done; T visible
+      for (int e = tid; e < SG * 2 * NT; e += NTHR) {
+        const int sl = e / (2 * NT), ax = (e / NT) & 1, k = e % NT;
+        const int s = g0 + sl;
+        float tap = 0.f, dtap = 0.f;
+        int bq = 0;
+        if (s < S) {
+          const float c_off = (N % 2 == 0) ? 0.5f : 0.0f;  // (N-1)/2 - (N-1)//2
+          const float delta = SS * SP[s * 4 + 1 + ax] + c_off;
+          tap_entry<SS, NT>(delta, k, tap, dtap, bq);
+        }
+        TAPS[(sl * 4 + 2 * ax) * NT + k] = tap;
+        TAPS[(sl * 4 + 2 * ax + 1) * NT + k] = dtap;
+        if (k == 0) BQ[sl * 2 + ax] = bq;
+      }
+      __syncthreads();
+      // ---- P2: row pass (x taps) fused with the column down-sampling ----------------------
+      {
+        constexpr int WL = SS * (LR - 1) + NT;
+        constexpr int NSTRIP = n / LR;
+        for (int item = tid; item < SG * N * NSTRIP; item += NTHR) {
+          const int u = item % N, strip = (item / N) % NSTRIP, sl = item / (N * NSTRIP);
+          if (g0 + sl >= S) continue;
+          const float *tx = TAPS + (sl * 4 + 0) * NT, *dtx = tx + NT;
+          const int bq = BQ[sl * 2 + 0];
+          const int a0 = strip * LR;
+          const int ws = SS * (a0 - bq) - (NT - 1);
+          float win[WL];
+#pragma unroll
+          for (int i = 0; i < WL; ++i) {
+            const int idx = ws + i;
+            const int ci = min(max(idx, 0), N - 1);
+            const float v = T[u * TS + ci];
+            win[i] = (idx >= 0 && idx < N) ? v : 0.f;
+          }
+          float tk[NT], dk[NT];
+#pragma unroll
+          for (int k = 0; k < NT; ++k) {
+            tk[k] = tx[k];
+            dk[k] = dtx[k];
+          }
+#pragma unroll
+          for (int j = 0; j < LR; ++j) {
+            float acc = 0.f, accd = 0.f;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+              const float w = win[SS * j - k + NT - 1];
+              acc = fmaf(tk[k], w, acc);
+              accd = fmaf(dk[k], w, accd);
+            }
+            R2t[(sl * n + a0 + j) * TS + u] = acc;
+            R2xt[(sl * n + a0 + j) * TS + u] = accd;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- P3: column pass (y taps) fused with row down-sampling, residuals, reductions ----
+      {
+        constexpr int WL = SS * (LC - 1) + NT;
+        constexpr int NSTRIP = n / LC;
+        for (int item0 = wid * 64; item0 < SG * C::IPS_PAD; item0 += NTHR) {
+          const int item = item0 + lane;
+          const int sl = item0 / C::IPS_PAD;  // wave-uniform
+          const int within = item % C::IPS_PAD;
+          const int s = g0 + sl;
+          float chi = 0.f, ga = 0.f, gx = 0.f, gy = 0.f, gs = 0.f;
+          if (s < S && within < C::IPS) {
+            const int jd = within % n, strip = within / n;
+            const float *ty = TAPS + (sl * 4 + 2) * NT, *dty = ty + NT;
+            const int bq = BQ[sl * 2 + 1];
+            const int a0 = strip * LC;
+            const int ws = SS * (a0 - bq) - (NT - 1);
+            const float amp = SP[s * 4 + 0], sky = SP[s * 4 + 3];
+            float win[WL], winx[WL];
+#pragma unroll
+            for (int i = 0; i < WL; ++i) {
+              const int idx = ws + i;
+              const int ci = min(max(idx, 0), N - 1);
+              const bool ok = (idx >= 0 && idx < N);
+              const float v = R2t[(sl * n + jd) * TS + ci];
+              const float vx = R2xt[(sl * n + jd) * TS + ci];
+              win[i] = ok ? v : 0.f;
+              winx[i] = ok ? vx : 0.f;
+            }
+            float tk[NT], dk[NT];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+              tk[k] = ty[k];
+              dk[k] = dty[k];
+            }
+#pragma unroll
+            for (int j = 0; j < LC; ++j) {
+              float fv = 0.f, fx = 0.f, fy = 0.f;
+#pragma unroll
+              for (int k = 0; k < NT; ++k) {
+                const float w = win[SS * j - k + NT - 1];
+                fv = fmaf(tk[k], w, fv);
+                fy = fmaf(dk[k], w, fy);
+                fx = fmaf(tk[k], winx[SS * j - k + NT - 1], fx);
+              }
+              const int id = a0 + j;
+              const size_t pix = (size_t)s * n * n + (size_t)id * n + jd;
+              const float d = dataf[pix], w = wgtf[pix];
+              const float model = fmaf(amp, fv, sky);
+              const float res = model - d;
+              const float rw = w * res;
+              chi = fmaf(rw, res, chi);
+              ga = fmaf(rw, fv, ga);
+              gx = fmaf(rw, fx, gx);
+              gy = fmaf(rw, fy, gy);
+              gs += rw;
+              RES[(sl * n + id) * n + jd] = rw;
+              if (A.out_model) A.out_model[(size_t)f * S * n * n + pix] = model;
+            }
+            gx *= amp * SS;
+            gy *= amp * SS;
+          }
+          chi = wave_sum(chi);
+          ga = wave_sum(ga);
+          gx = wave_sum(gx);
+          gy = wave_sum(gy);
+          gs = wave_sum(gs);
+          if (lane == 0) {
+            float *r = RED + (sl * C::SLOTS + (item0 % C::IPS_PAD) / 64) * 5;
+            r[0] = chi;
+            r[1] = ga;
+            r[2] = gx;
+            r[3] = gy;
+            r[4] = gs;
+          }
+        }
+      }
+      __syncthreads();
+      // per-star sums in fixed slot order
+      if (tid < SG * 5) {
+        const int sl = tid / 5, q = tid % 5;
+        if (g0 + sl < S) {
+          float acc = 0.f;
+          for (int k = 0; k < C::SLOTS; ++k) acc += RED[(sl * C::SLOTS + k) * 5 + q];
+          SGR[(g0 + sl) * 5 + q] = acc;
+        }
+      }
+      // ---- P4: transposed column pass: V[u][jd] = sum_id PhiY(ss*id - u) r[id][jd] ---------
+      {
+        constexpr int WI = (SS * LA - 1 + NT - 1) / SS + 1;
+        constexpr int NSTRIP = n / LA;
+        for (int item = tid; item < SG * n * NSTRIP; item += NTHR) {
+          const int jd = item % n, strip = (item / n) % NSTRIP, sl = item / (n * NSTRIP);
+          if (g0 + sl >= S) continue;
+          const float *ty = TAPS + (sl * 4 + 2) * NT;
+          const int bq = BQ[sl * 2 + 1];
+          const int a0 = strip * LA;
+          float tk[NT];
+#pragma unroll
+          for (int k = 0; k < NT; ++k) tk[k] = ty[k];
+          float out[SS * LA];
+#pragma unroll
+          for (int r = 0; r < SS * LA; ++r) out[r] = 0.f;
+#pragma unroll
+          for (int i = 0; i < WI; ++i) {
+            const int id = i + bq + a0;
+            const int ci = min(max(id, 0), n - 1);
+            float rv = RES[(sl * n + ci) * n + jd];
+            rv = (id >= 0 && id < n) ? rv : 0.f;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+              const int rel = SS * i - k;
+              if (rel >= 0 && rel < SS * LA) out[rel] = fmaf(tk[k], rv, out[rel]);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * RS + jd] = out[r];
+        }
+      }
+      __syncthreads();
+      // ---- P5: transposed row pass, summed over the stars of the group into registers ------
+      {
+        constexpr int WJ = (PX - 1 + NT - 1) / SS + 1;
+        for (int sl = 0; sl < SG; ++sl) {
+          const int s = g0 + sl;
+          if (s >= S) break;
+          const float *tx = TAPS + (sl * 4 + 0) * NT;
+          const int bq = BQ[sl * 2 + 0];
+          const float amp = SP[s * 4 + 0];
+          float acc[PX];
+#pragma unroll
+          for (int p = 0; p < PX; ++p) acc[p] = 0.f;
+#pragma unroll
+          for (int i = 0; i < WJ; ++i) {
+            const int jd = i + bq + pv / SS;
+            const int ci = min(max(jd, 0), n - 1);
+            float vv = V[(sl * N + pu) * RS + ci];
+            vv = (jd >= 0 && jd < n) ? vv : 0.f;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+              const int rel = SS * i - k;
+              if (rel >= 0 && rel < PX) acc[rel] = fmaf(tx[k], vv, acc[rel]);
+            }
+          }
+#pragma unroll
+          for (int p = 0; p < PX; ++p) gB[p] = fmaf(amp, acc[p], gB[p]);
+        }
+      }
+    }  // groups
+    __syncthreads();
+
+    if (A.out_gT) {
+#pragma unroll
+      for (int p = 0; p < PX; ++p) A.out_gT[gpix + p] = gB[p];
+    }
+
+    // ---- P6: starlet l1 on B: forward sweep (coefficients, sub-gradients), backward sweep -----
+    float l1 = 0.f;
+    float z[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) z[p] = 0.f;
+    const bool reg_on = (A.lam_sc != 0.f || A.lam_hf != 0.f);
+    if (reg_on) {
+      float c[PX];
+      {
+        const float4 *bp = (const float4 *)(A.B + gpix);
+#pragma unroll
+        for (int q = 0; q < PX / 4; ++q) {
+          const float4 b = bp[q];
+          c[4 * q] = b.x;
+          c[4 * q + 1] = b.y;
+          c[4 * q + 2] = b.z;
+          c[4 * q + 3] = b.w;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PX; ++p) bufA[pu * TS + pv + p] = c[p];
+      __syncthreads();
+      for (int j = 0; j < J; ++j) {
+        const int d = 1 << j;
+        float r[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+          float acc = 0.f;
+#pragma unroll
+          for (int t = -2; t <= 2; ++t) {
+            const int vv = min(max(pv + p + t * d, 0), N - 1);
+            acc = fmaf(b3tap(t), bufA[pu * TS + vv], acc);
+          }
+          r[p] = acc;
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) bufB[pu * TS + pv + p] = r[p];
+        __syncthreads();
+        const float lam = (j == 0) ? A.lam_hf : A.lam_sc;
+        float wj[PX];
+        if (A.W) {
+          const float4 *wp = (const float4 *)(A.W + ((size_t)f * J + j) * N * N + (size_t)pu * N + pv);
+#pragma unroll
+          for (int q = 0; q < PX / 4; ++q) {
+            const float4 w4 = wp[q];
+            wj[4 * q] = w4.x;
+            wj[4 * q + 1] = w4.y;
+            wj[4 * q + 2] = w4.z;
+            wj[4 * q + 3] = w4.w;
+          }
+        } else {
+          const float nv = A.norms[j];
+#pragma unroll
+          for (int p = 0; p < PX; ++p) wj[p] = nv;
+        }
+        float q[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+          float acc = 0.f;
+#pragma unroll
+          for (int t = -2; t <= 2; ++t) {
+            const int uu = min(max(pu + t * d, 0), N - 1);
+            acc = fmaf(b3tap(t), bufB[uu * TS + pv + p], acc);
+          }
+          const float w = c[p] - acc;
+          const float lw = lam * wj[p];
+          l1 = fmaf(lw, fabsf(w), l1);
+          q[p] = (w > 0.f) ? lw : ((w < 0.f) ? -lw : 0.f);
+          c[p] = acc;
+        }
+        {
+          float4 *qp = (float4 *)(A.qscratch + ((size_t)f * J + j) * N * N + (size_t)pu * N + pv);
+#pragma unroll
+          for (int qq = 0; qq < PX / 4; ++qq) qp[qq] = make_float4(q[4 * qq], q[4 * qq + 1], q[4 * qq + 2], q[4 * qq + 3]);
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) bufA[pu * TS + pv + p] = c[p];
+        __syncthreads();
+      }
+      // backward: z_J = 0; z_j = q_j + H_j^T (z_{j+1} - q_j), H_j^T = Row^T Col^T (edge-replicating adjoint)
+      for (int j = J - 1; j >= 0; --j) {
+        const int d = 1 << j;
+        float q[PX];
+        {
+          const float4 *qp = (const float4 *)(A.qscratch + ((size_t)f * J + j) * N * N + (size_t)pu * N + pv);
+#pragma unroll
+          for (int qq = 0; qq < PX / 4; ++qq) {
+            const float4 v4 = qp[qq];
+            q[4 * qq] = v4.x;
+            q[4 * qq + 1] = v4.y;
+            q[4 * qq + 2] = v4.z;
+            q[4 * qq + 3] = v4.w;
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) bufA[pu * TS + pv + p] = z[p] - q[p];
+        __syncthreads();
+        // Col^T
+        float ct[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+          const int v = pv + p;
+          float acc;
+          if (pu > 0 && pu < N - 1) {
+            acc = 0.f;
+#pragma unroll
+            for (int t = -2; t <= 2; ++t) {
+              const int uu = pu - t * d;
+              if (uu >= 0 && uu <= N - 1) acc = fmaf(b3tap(t), bufA[uu * TS + v], acc);
+            }
+          } else if (pu == 0) {
+            float s1 = 0.f, s2 = 0.f;
+            const int m1 = min(d, N - 1), m2 = min(2 * d, N - 1);
+            for (int uu = 0; uu <= m2; ++uu) {
+              const float gv = bufA[uu * TS + v];
+              if (uu <= m1) s1 += gv;
+              s2 += gv;
+            }
+            acc = 0.375f * bufA[v] + 0.25f * s1 + 0.0625f * s2;
+          } else {
+            float s1 = 0.f, s2 = 0.f;
+            const int m1 = max(N - 1 - d, 0), m2 = max(N - 1 - 2 * d, 0);
+            for (int uu = m2; uu <= N - 1; ++uu) {
+              const float gv = bufA[uu * TS + v];
+              if (uu >= m1) s1 += gv;
+              s2 += gv;
+            }
+            acc = 0.375f * bufA[(N - 1) * TS + v] + 0.25f * s1 + 0.0625f * s2;
+          }
+          ct[p] = acc;
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) bufB[pu * TS + pv + p] = ct[p];
+        __syncthreads();
+        // Row^T
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+          const int v = pv + p;
+          float acc;
+          if (v > 0 && v < N - 1) {
+            acc = 0.f;
+#pragma unroll
+            for (int t = -2; t <= 2; ++t) {
+              const int vv = v - t * d;
+              if (vv >= 0 && vv <= N - 1) acc = fmaf(b3tap(t), bufB[pu * TS + vv], acc);
+            }
+          } else if (v == 0) {
+            float s1 = 0.f, s2 = 0.f;
+            const int m1 = min(d, N - 1), m2 = min(2 * d, N - 1);
+            for (int vv = 0; vv <= m2; ++vv) {
+              const float gv = bufB[pu * TS + vv];
+              if (vv <= m1) s1 += gv;
+              s2 += gv;
+            }
+            acc = 0.375f * bufB[pu * TS] + 0.25f * s1 + 0.0625f * s2;
+          } else {
+            float s1 = 0.f, s2 = 0.f;
+            const int m1 = max(N - 1 - d, 0), m2 = max(N - 1 - 2 * d, 0);
+            for (int vv = m2; vv <= N - 1; ++vv) {
+              const float gv = bufB[pu * TS + vv];
+              if (vv >= m1) s1 += gv;
+              s2 += gv;
+            }
+            acc = 0.375f * bufB[pu * TS + N - 1] + 0.25f * s1 + 0.0625f * s2;
+          }
+          z[p] = q[p] + acc;
+        }
+        // next scale writes bufA only after every thread has passed the barrier above
+      }
+    }
+    // ---- loss ------------------------------------------------------------------------------
+    {
+      const float wl = wave_sum(l1);
+      if (lane == 0) REDW[wid] = wl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float tl1 = 0.f;
+      for (int w = 0; w < C::NW; ++w) tl1 += REDW[w];
+      float chi = 0.f;
+      for (int s = 0; s < S; ++s) chi += SGR[s * 5];
+      const float loss = 0.5f * chi + tl1;
+      A.hist[(size_t)f * A.hist_stride + tglob] = loss;
+      if (A.out_loss) A.out_loss[f] = loss;
+      if (A.out_chi2) A.out_chi2[f] = chi;
+    }
+    if (A.out_ggrid) {
+#pragma unroll
+      for (int p = 0; p < PX; ++p) A.out_ggrid[gpix + p] = gB[p] + z[p];
+    }
+    if (A.out_gstars && tid < S * 4) {
+      const int s = tid / 4, q = tid % 4;
+      A.out_gstars[(size_t)f * S * 4 + tid] = SGR[s * 5 + 1 + q];
+    }
+    // ---- AdaBelief update ---------------------------------------------------------------------
+    if (A.mode == 1) {
+      const float lr = SCAL[0], bc1 = SCAL[1], bc2 = SCAL[2];
+      const float b1 = A.ab.b1, b2 = A.ab.b2, eps = A.ab.eps, eps_root = A.ab.eps_root;
+      float4 *bp = (float4 *)(A.B + gpix);
+      float4 *mp = (float4 *)(A.mB + gpix);
+      float4 *sp = (float4 *)(A.sB + gpix);
+#pragma unroll
+      for (int q = 0; q < PX / 4; ++q) {
+        float4 b = bp[q], m = mp[q], s = sp[q];
+        float *bb = &b.x, *mm = &m.x, *ss_ = &s.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = gB[4 * q + e] + z[4 * q + e];
+          const float mn = b1 * mm[e] + (1.f - b1) * g;
+          const float dg = g - mn;
+          const float sn = b2 * ss_[e] + (1.f - b2) * dg * dg + eps_root;
+          mm[e] = mn;
+          ss_[e] = sn;
+          bb[e] -= lr * (mn * bc1) / (sqrtf(sn * bc2) + eps);
+        }
+        bp[q] = b;
+        mp[q] = m;
+        sp[q] = s;
+      }
+      if (tid < S * 3) {
+        const int s = tid / 3, q = tid % 3;  // a, x0, y0
+        const float g = SGR[s * 5 + 1 + q];
+        const float mn = b1 * SM[s * 4 + q] + (1.f - b1) * g;
+        const float dg = g - mn;
+        const float sn = b2 * SV[s * 4 + q] + (1.f - b2) * dg * dg + eps_root;
+        SM[s * 4 + q] = mn;
+        SV[s * 4 + q] = sn;
+        SP[s * 4 + q] -= lr * (mn * bc1) / (sqrtf(sn * bc2) + eps);
+      }
+    }
+    __syncthreads();
+  }  // iterations
+
+  if (A.mode == 1 && tid < S * 4) {
+    A.stars[(size_t)f * S * 4 + tid] = SP[tid];
+    A.stars_m[(size_t)f * S * 4 + tid] = SM[tid];
+    A.stars_s[(size_t)f * S * 4 + tid] = SV[tid];
+  }
+}
+
+}  // namespace lc

@@ -1,0 +1,107 @@
+"""GPU parity of the PSF-fit kernels (through the C ABI) against the float64 oracle.
+
+Tolerances: the HIP path computes in fp32, the oracle in fp64.  Single evaluations (loss, model,
+gradients) must agree to 2e-5 relative to the largest element; short AdaBelief trajectories to
+1e-4 on the loss history and 2e-3 on the moved parameters (sign-like first steps amplify fp32
+rounding of near-zero gradients); converged fits are checked in test_build_psf_gpu.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om, optim as oo
+from lightcurver_amd.synthetic import make_psf_dataset
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n, ss, F, S, seed, ctx, jitter=0.3):
+    from lightcurver_amd.psf_batch import PsfBatch
+    ds = make_psf_dataset(F=F, S=S, n=n, ss=ss, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    plist = [H.psf_initial_params(ds, f, ss, rng, jitter) for f in range(F)]
+    b = PsfBatch(ds['data'], H.weights_from(ds), ss, ctx)
+    b.set_moffat(H.moffat_array(plist))
+    b.set_stars(H.stars_array(plist))
+    b.set_grid(np.stack([p['B'].numpy() for p in plist]))
+    return ds, plist, b
+
+
+@pytest.mark.parametrize('n,ss,S', [(16, 1, 3), (16, 2, 4), (24, 2, 5), (32, 2, 8)])
+def test_eval_matches_oracle(ctx, n, ss, S):
+    F = 2
+    ds, plist, b = _setup(n, ss, F, S, 11 + n + ss, ctx)
+    N = n * ss
+    J = om.n_scales(N)
+    Ws = []
+    for f in range(F):
+        data, sig2, mask = H.psf_oracle_inputs(ds, f, ss)
+        Ws.append(om.propagate_noise_psf(plist[f], sig2, mask, ss))
+    b.set_regularization(np.stack([w[:J].numpy() for w in Ws]), lam_scales=1.3, lam_hf=0.7)
+    out = b.evaluate(model=True)
+    free = ['fwhm_x', 'fwhm_y', 'phi', 'beta', 'a', 'x0', 'y0', 'sky', 'B']
+    for f in range(F):
+        data, sig2, mask = H.psf_oracle_inputs(ds, f, ss)
+        fn = lambda q: om.psf_loss(q, data, sig2, mask, ss, W=Ws[f], lam_scales=1.3, lam_hf=0.7)
+        L, g = oo.value_and_grad(fn, plist[f], free)
+        model = om.psf_model(plist[f], ss, n).numpy()
+        assert H.rel_err(out['model'][f], model) < 2e-5
+        assert abs(out['loss'][f] - L) / abs(L) < 2e-5
+        gs = np.stack([g['a'].numpy(), g['x0'].numpy(), g['y0'].numpy(), g['sky'].numpy()], axis=-1)
+        for q in range(4):
+            assert H.rel_err(out['grad_stars'][f][:, q], gs[:, q]) < 5e-5, q
+        assert H.rel_err(out['grad_grid'][f], g['B'].numpy().reshape(N, N)) < 5e-5
+        gm = np.array([float(g[k]) for k in ['fwhm_x', 'fwhm_y', 'phi', 'beta']])
+        assert H.rel_err(out['grad_moffat'][f], gm) < 1e-4
+
+
+def test_eval_without_weights_uses_scale_norms(ctx):
+    n, ss, S, F = 16, 2, 3, 1
+    ds, plist, b = _setup(n, ss, F, S, 3, ctx)
+    b.set_regularization(None, lam_scales=2.0, lam_hf=0.5)
+    out = b.evaluate()
+    data, sig2, mask = H.psf_oracle_inputs(ds, 0, ss)
+    fn = lambda q: om.psf_loss(q, data, sig2, mask, ss, W=None, lam_scales=2.0, lam_hf=0.5)
+    L, g = oo.value_and_grad(fn, plist[0], ['B'])
+    assert abs(out['loss'][0] - L) / abs(L) < 2e-5
+    assert H.rel_err(out['grad_grid'][0], g['B'].numpy().reshape(n * ss, n * ss)) < 5e-5
+
+
+def test_noise_propagation_matches_oracle(ctx):
+    n, ss, S, F = 16, 2, 4, 2
+    ds, plist, b = _setup(n, ss, F, S, 21, ctx)
+    b.propagate_noise()
+    W = b.get_weights()
+    J = om.n_scales(n * ss)
+    for f in range(F):
+        data, sig2, mask = H.psf_oracle_inputs(ds, f, ss)
+        Wo = om.propagate_noise_psf(plist[f], sig2, mask, ss)[:J].numpy()
+        assert H.rel_err(W[f], Wo) < 2e-5
+
+
+@pytest.mark.parametrize('n,ss,S', [(16, 2, 4), (32, 2, 8)])
+def test_adabelief_trajectory_matches_oracle(ctx, n, ss, S):
+    F, T = 2, 25
+    ds, plist, b = _setup(n, ss, F, S, 5 + n, ctx, jitter=0.1)
+    N = n * ss
+    J = om.n_scales(N)
+    Ws = []
+    for f in range(F):
+        data, sig2, mask = H.psf_oracle_inputs(ds, f, ss)
+        Ws.append(om.propagate_noise_psf(plist[f], sig2, mask, ss))
+    b.set_regularization(np.stack([w[:J].numpy() for w in Ws]), lam_scales=1.0, lam_hf=1.0)
+    b.run_adabelief(T, init_learning_rate=1e-4, schedule_learning_rate=True)
+    hist = b.loss_history()
+    stars = b.get_stars()
+    grid = b.get_grid()
+    assert hist.shape == (F, T + 1)
+    for f in range(F):
+        data, sig2, mask = H.psf_oracle_inputs(ds, f, ss)
+        fn = lambda q: om.psf_loss(q, data, sig2, mask, ss, W=Ws[f], lam_scales=1.0, lam_hf=1.0)
+        pf, lh, l0 = oo.adabelief(fn, plist[f], ['B', 'a', 'x0', 'y0'], 1e-4, T, schedule=True)
+        ref = np.array([l0] + lh)
+        assert np.abs(hist[f] - ref).max() / np.abs(ref).max() < 1e-4
+        assert np.abs(grid[f].ravel() - pf['B'].numpy()).max() < 2e-3 * T * 1e-4 + 1e-7
+        assert H.rel_err(stars[f][:, 0], pf['a'].numpy()) < 1e-5
+        assert np.abs(stars[f][:, 1] - pf['x0'].numpy()).max() < 2e-5
