@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Throughput of the PSF-fit hot loop (BASELINE.json metric: cutouts/sec), one rank per GPU.
+
+A *step* is one launch of the persistent PSF-fit kernel: ITERS_PER_STEP AdaBelief iterations
+(forward model + chi2 + full gradient + starlet l1 + fused update) over every stamp of the rank's
+batch.  Workload at N = 1: BASELINE.json configs[1] (C2) = 100 frames x 8 stars, 32 x 32 stamps,
+subsampling 2, starlet-regularised pixel-grid stage of the PSF fit; for N > 1 every rank gets its
+own C2-sized batch (frames shard embarrassingly, no data-path collective => weak scaling).
+Inputs are resident in HBM before the timed region; the Moffat stage and noise propagation are
+one-time setup and not timed.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ITERS_PER_STEP = 100
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_cutout_iteration(n, ss, S):
+    """B_psf = 8 n^2 + (24 + 4 J) N^2 / S  (fp32)."""
+    N = n * ss
+    J = int(math.log2(N))
+    return 8 * n * n + (24 + 4 * J) * N * N / S
+
+
+def cpu_baseline(ds, ss, n_frames=2, n_iter=40):
+    """The float64 oracle (kind 'port') timed on the host cores on a bounded sample of the same
+    workload: n_frames frames x S stamps x n_iter AdaBelief iterations of the pixel-grid stage."""
+    import torch
+    from oracle import model as om, optim as oo
+    from tests import helpers as H
+    S = ds['data'].shape[1]
+    t_total = 0.0
+    for f in range(n_frames):
+        data, sig2, mask = H.psf_oracle_inputs(ds, f, ss)
+        p = H.psf_initial_params(ds, f, ss)
+        W = om.propagate_noise_psf(p, sig2, mask, ss)
+        fn = lambda q: om.psf_loss(q, data, sig2, mask, ss, W=W, lam_scales=1.0, lam_hf=1.0)
+        t0 = time.perf_counter()
+        oo.adabelief(fn, p, ['B', 'a', 'x0', 'y0'], 1e-4, n_iter, schedule=True)
+        t_total += time.perf_counter() - t0
+    return dict(value=n_frames * S * n_iter / t_total, unit='cutouts/sec', cores=torch.get_num_threads(),
+                kind='port',
+                sample=f'{n_frames} frames x {S} stamps x {n_iter} AdaBelief iterations of the same C2 data, '
+                       'torch float64 oracle')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C3'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        # frames shard with no data-path collective: the process group only carries the barrier and
+        # the max-over-ranks of the timing, so a host-side (gloo) group is sufficient and keeps the
+        # timed region free of foreign GPU work.
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    from lightcurver_amd import _lib
+    from lightcurver_amd.psf_batch import PsfBatch
+    from lightcurver_amd.synthetic import CONFIGS, make_psf_dataset
+
+    cfg = dict(CONFIGS[args.config])
+    cfg.pop('kind')
+    cfg['seed'] += 1000 * rank
+    ds = make_psf_dataset(**cfg)
+    F, S, n, ss = cfg['F'], cfg['S'], cfg['n'], cfg['ss']
+
+    ctx = _lib.Context(local_rank)
+    weight = (ds['masks'] / ds['noisemap'].astype(np.float64) ** 2).astype(np.float32)
+    b = PsfBatch(ds['data'], weight, ss, ctx)
+    # setup (not timed): Moffat stage from the seeing guess, then noise propagation for the l1 weights
+    g = ds['fwhm_guess']
+    f0 = np.sqrt(np.maximum(g * g - (2.0 / ss) ** 2, 1.0))
+    b.set_moffat(np.stack([f0, f0, np.zeros(F), np.full(F, 2.5)], axis=-1))
+    stars = np.zeros((F, S, 4), np.float32)
+    stars[..., 0] = (ds['data'] * ds['masks']).sum(axis=(-1, -2))
+    b.set_stars(stars)
+    b.set_grid(None)
+    t0 = time.perf_counter()
+    b.fit_moffat(100)
+    b.propagate_noise()
+    ctx.synchronize()
+    setup_s = time.perf_counter() - t0
+    b.set_regularization(None, 1.0, 1.0)  # strengths; W stays the propagated one on the device
+
+    ab = dict(init_learning_rate=1e-4, schedule_learning_rate=True)
+    for _ in range(args.warmup):
+        b.run_adabelief(ITERS_PER_STEP, **ab)
+    ctx.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        b.run_adabelief(ITERS_PER_STEP, **ab)
+    kernel_ms = ctx.timer_stop()  # HIP events on the stream the kernels run on; also synchronises
+    ctx.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        import torch
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    hist = b.loss_history()
+    finite = bool(np.all(np.isfinite(hist)))
+    res = b.results()
+
+    if rank == 0:
+        cutouts = F * S * world
+        value = cutouts * ITERS_PER_STEP * args.steps / elapsed
+        bytes_per = algorithmic_bytes_per_cutout_iteration(n, ss, S)
+        launch_s = kernel_ms * 1e-3 / args.steps
+        achieved = F * S * ITERS_PER_STEP * bytes_per / launch_s / 1e9
+        N = n * ss
+        flops_per = 70.0 * N * N  # separable passes: 35 N^2 MAC per stamp-iteration
+        out = {
+            'metric': 'cutouts/sec (PSF-fit + joint forward-model iter), 32x32 & 64x64 stamps',
+            'value': value, 'unit': 'cutouts/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.config}: {F} frames x {S} stars, {n}x{n} stamps, subsampling {ss}, '
+                                   f'starlet-regularised PSF pixel-grid fit, {ITERS_PER_STEP} AdaBelief '
+                                   'iterations per step (one persistent launch)',
+                       'frames_per_gpu': F, 'stars': S, 'stamp': n, 'subsampling': ss,
+                       'iters_per_step': ITERS_PER_STEP, 'sharding': f'frames x{world} (no collective)',
+                       'setup_seconds_untimed': setup_s, 'loss_finite': finite,
+                       'median_reduced_chi2': float(np.median(res['chi2']))},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'psf_fit_kernel', 'kernel_ms_per_launch': launch_s * 1e3,
+                         'algorithmic_bytes_per_cutout_iteration': bytes_per,
+                         'note': 'state is kept on-chip across iterations, so algorithmic bytes/s may exceed '
+                                 'what HBM actually moves; fp32 VALU fraction reported beside it',
+                         'fp32_valu_tflops': F * S * ITERS_PER_STEP * flops_per / launch_s / 1e12,
+                         'fp32_valu_frac_of_157': F * S * ITERS_PER_STEP * flops_per / launch_s / 1e12 / 157.3},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out['cpu_baseline'] = cpu_baseline(ds, ss)
+            except Exception as e:  # the bench line must still be printed
+                out['cpu_baseline'] = {'value': None, 'error': repr(e)}
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -654,4 +654,10 @@ int lc_psf_batch_get_results(lc_psf_batch *b, float *narrow_psf, float *full_psf
   return LC_OK;
 }
 
+#ifdef LC_STAMPS
+int lc_debug_get_stamps(long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::g_stamps), 64 * sizeof(long long)) == hipSuccess ? 0 : -2;
+}
+#endif
+
 }  // extern "C"

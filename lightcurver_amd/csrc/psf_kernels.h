@@ -8,9 +8,24 @@
 // the two transposed passes.  T = Moffat + B, the per-star intermediates and the weighted
 // residuals live in LDS; B's chi2 gradient stays in registers through the starlet phase.
 #pragma once
+#include <utility>
+
 #include "lc_common.h"
 
 namespace lc {
+
+#ifdef LC_STAMPS
+__device__ long long g_stamps[64];
+#define LC_STAMP(k)                                                      \
+  do {                                                                   \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && it == A.n_iter - 1) g_stamps[k] = clock64(); \
+  } while (0)
+#else
+#define LC_STAMP(k) do {} while (0)
+#endif
+
+// Stops loop-invariant code motion from pre-computing (and spilling) per-thread LDS addresses.
+#define LC_LAUNDER(x) asm volatile("" : "+v"(x))
 
 struct PsfArgs {
   int F, S, n_iter, t0, hist_stride, mode;  // mode 0 = evaluate, 1 = AdaBelief loop
@@ -39,6 +54,7 @@ struct PsfCfg {
   static constexpr int LC = 4;  // column-pass strip (down-sampled rows per work item)
   static constexpr int LA = 4;  // transposed column pass: LA data rows = SS*LA high-res rows
   static constexpr int TS = N + 1;  // padded LDS row stride of N-long rows
+  static constexpr int TSS = N + 4; // 16-byte aligned row stride of the starlet forward sweep
   static constexpr int RS = n + 1;  // padded LDS row stride of n-long rows
   // LDS carve-up (floats)
   static constexpr int OFF_T = 0;
@@ -50,7 +66,7 @@ struct PsfCfg {
   static constexpr int OFF_RES = OFF_R + SZ_R;
   static constexpr int SZ_RES = SG * n * n;
   static constexpr int OFF_TAPS = OFF_RES + SZ_RES;
-  static constexpr int SZ_TAPS = SG * 4 * NT;
+  static constexpr int SZ_TAPS = 16 * 4 * NT;  // every star of the frame
   static constexpr int OFF_RED = OFF_TAPS + SZ_TAPS;
   static constexpr int IPS = n * n / LC;  // column-pass items per star
   static constexpr int IPS_PAD = (IPS + kWave - 1) / kWave * kWave;
@@ -60,7 +76,7 @@ struct PsfCfg {
   static constexpr int MAXS = 16;
   static constexpr int SZ_STAR = MAXS * 20 + 16;
   static constexpr int LDS_FLOATS = OFF_STAR + SZ_STAR;
-  static_assert(2 * N * TS <= SZ_T + SZ_R, "starlet ping-pong buffers must fit over T + R");
+  static_assert(2 * N * TSS <= SZ_T + SZ_R + SZ_RES, "starlet ping-pong buffers must fit over T + R + RES");
   static_assert(PX % SS == 0 && N % PX == 0 && n % LR == 0 && n % LC == 0 && n % LA == 0, "tiling");
   static_assert(NTHR <= 1024 && NTHR % kWave == 0, "threads");
 };
@@ -103,17 +119,157 @@ __device__ inline void tap_entry(float delta, int k, float &tap, float &dtap, in
   dtap = d;
 }
 
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// Sum over the LPR (4, 8 or 16) consecutive lanes that own one image line, result in every lane.
+// xor-1 / xor-2 butterflies as quad permutes, then the half-row and row mirrors (DPP, no LDS).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  const int r = __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xF, 0xF, false);
+  return v + __builtin_bit_cast(float, r);
+}
+template <int LPR>
+__device__ __forceinline__ float line_sum(float v) {
+  v = dpp_add<0xB1>(v);  // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);  // quad_perm [2,3,0,1]
+  if constexpr (LPR >= 8) v = dpp_add<0x141>(v);   // row_half_mirror
+  if constexpr (LPR >= 16) v = dpp_add<0x140>(v);  // row_mirror
+  return v;
+}
+
+// Zero-filling DPP lane shifts inside one image line (LPR consecutive lanes, LPR | 16).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov0(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int K, int LPR>
+__device__ __forceinline__ float line_from_lower(float v, int lil) {  // value of lane - K of the same line, else 0
+  if constexpr (K >= LPR) {
+    return 0.f;
+  } else {
+    float r = dpp_mov0<0x110 + K>(v);  // row_shr:K
+    if constexpr (LPR < 16) r = (lil >= K) ? r : 0.f;
+    return r;
+  }
+}
+template <int K, int LPR>
+__device__ __forceinline__ float line_from_upper(float v, int lil) {  // value of lane + K of the same line, else 0
+  if constexpr (K >= LPR) {
+    return 0.f;
+  } else {
+    float r = dpp_mov0<0x100 + K>(v);  // row_shl:K
+    if constexpr (LPR < 16) r = (lil + K < LPR) ? r : 0.f;
+    return r;
+  }
+}
+
+// Adjoint of one edge-replicating 5-tap a-trous pass (dilation D) along a line of N samples:
+//   out[x] = sum_t b3[t] * sum_{x'': clamp(x'' + t D) = x} g[x'']
+// The calling thread holds samples x0 .. x0+PX-1 of the line in own[]; the LPR = N / PX threads of the
+// line are consecutive lanes (lil = lane index inside the line).  Interior samples gather g[x -/+ D],
+// g[x -/+ 2D] with zero outside the line: pure DPP lane shifts, no LDS.  The two end samples also collect
+// every sample that clamps onto them: masked partial sums reduced over the line's lanes by DPP.
+template <int N, int PX, int LPR, int D>
+__device__ __forceinline__ void adjoint_line_dpp(const float own[PX], int x0, int lil, float out[PX]) {
+  if constexpr (D < PX) {
+    float w[3 * PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      w[p] = line_from_lower<1, LPR>(own[p], lil);
+      w[PX + p] = own[p];
+      w[2 * PX + p] = line_from_upper<1, LPR>(own[p], lil);
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      float acc = 0.375f * own[p];
+      acc = fmaf(0.25f, w[PX + p - D] + w[PX + p + D], acc);
+      acc = fmaf(0.0625f, w[PX + p - 2 * D] + w[PX + p + 2 * D], acc);
+      out[p] = acc;
+    }
+  } else {
+    constexpr int K1 = D / PX, K2 = 2 * D / PX;
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      float acc = 0.375f * own[p];
+      acc = fmaf(0.25f, line_from_lower<K1, LPR>(own[p], lil) + line_from_upper<K1, LPR>(own[p], lil), acc);
+      acc = fmaf(0.0625f, line_from_lower<K2, LPR>(own[p], lil) + line_from_upper<K2, LPR>(own[p], lil), acc);
+      out[p] = acc;
+    }
+  }
+  float s1 = 0.f, s2 = 0.f, e1 = 0.f, e2 = 0.f;  // head sums x <= D, x <= 2D; tail sums x >= N-1-D, x >= N-1-2D
+#pragma unroll
+  for (int p = 0; p < PX; ++p) {
+    const int x = x0 + p;
+    s1 += (x <= D) ? own[p] : 0.f;
+    s2 += (x <= 2 * D) ? own[p] : 0.f;
+    e1 += (x >= N - 1 - D) ? own[p] : 0.f;
+    e2 += (x >= N - 1 - 2 * D) ? own[p] : 0.f;
+  }
+  s1 = line_sum<LPR>(s1);
+  s2 = line_sum<LPR>(s2);
+  e1 = line_sum<LPR>(e1);
+  e2 = line_sum<LPR>(e2);
+  if (x0 == 0) out[0] = 0.375f * own[0] + 0.25f * s1 + 0.0625f * s2;
+  if (x0 + PX == N) out[PX - 1] = 0.375f * own[PX - 1] + 0.25f * e1 + 0.0625f * e2;
+}
+
+// Same operator for line layouts DPP cannot serve (LPR not in {4, 8, 16}): gathers from LDS, serial edge sums.
+template <int N, int PX>
+__device__ __forceinline__ void adjoint_line_lds(const float *in, int base, int stride, int x0, int d, float out[PX]) {
+  float own[PX];
+#pragma unroll
+  for (int p = 0; p < PX; ++p) own[p] = in[base + (x0 + p) * stride];
+  float s1 = 0.f, s2 = 0.f, e1 = 0.f, e2 = 0.f;
+  if (x0 == 0) {
+    const int m1 = min(d, N - 1), m2 = min(2 * d, N - 1);
+    for (int x = 0; x <= m2; ++x) {
+      const float gv = in[base + x * stride];
+      if (x <= m1) s1 += gv;
+      s2 += gv;
+    }
+  }
+  if (x0 + PX == N) {
+    const int m1 = max(N - 1 - d, 0), m2 = max(N - 1 - 2 * d, 0);
+    for (int x = m2; x <= N - 1; ++x) {
+      const float gv = in[base + x * stride];
+      if (x >= m1) e1 += gv;
+      e2 += gv;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PX; ++p) {
+    const int x = x0 + p;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = -2; t <= 2; ++t) {
+      const int xx = x - t * d;
+      const int cx = min(max(xx, 0), N - 1);
+      const float gv = (t == 0) ? own[p] : in[base + cx * stride];
+      acc = fmaf(b3tap(t), (xx >= 0 && xx <= N - 1) ? gv : 0.f, acc);
+    }
+    if (x == 0) acc = 0.375f * own[p] + 0.25f * s1 + 0.0625f * s2;
+    if (x == N - 1) acc = 0.375f * own[p] + 0.25f * e1 + 0.0625f * e2;
+    out[p] = acc;
+  }
+}
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F &&f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+
 template <class C>
 __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
   constexpr int N = C::N, SS = C::SS, PX = C::PX, SG = C::SG, n = C::n, NT = C::NT, J = C::J;
   constexpr int NTHR = C::NTHR, TS = C::TS, RS = C::RS, LR = C::LR, LC = C::LC, LA = C::LA;
-  extern __shared__ float lds[];
+  extern __shared__ __align__(16) float lds[];
   float *T = lds + C::OFF_T;
   float *R2t = lds + C::OFF_R;
   float *R2xt = R2t + C::SZ_R2;
   float *V = lds + C::OFF_R;
   float *RES = lds + C::OFF_RES;
-  float *TAPS = lds + C::OFF_TAPS;  // [SG][4][NT]: tx, dtx, ty, dty
+  float *TAPS = lds + C::OFF_TAPS;  // [S][4][NT]: tx, dtx, ty, dty
   float *RED = lds + C::OFF_RED;    // [SG][SLOTS][5] + [NW] + scalars
   float *REDW = RED + SG * C::SLOTS * 5;
   float *SCAL = REDW + C::NW;  // lr, bc1, bc2, l1, loss
@@ -121,30 +277,32 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
   float *SGR = SP + C::MAXS * 4;    // star grads [MAXS][5]: chi2, ga, gx, gy, gsky
   float *SM = SGR + C::MAXS * 5;    // moments m [MAXS][4]
   float *SV = SM + C::MAXS * 4;     // moments s [MAXS][4]
-  int *BQ = (int *)(SV + C::MAXS * 4);  // [SG][2]
+  int *BQ = (int *)(SV + C::MAXS * 4);  // [S][2]
   float *bufA = lds;                // starlet ping-pong, overlays T + R
   float *bufB = lds + N * TS;
 
   const int f = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
+  const int tid0 = threadIdx.x;
   const int S = A.S;
-  const int pu = tid / (N / PX);          // owned row
-  const int pv = (tid % (N / PX)) * PX;   // first owned column
-  const size_t gpix = (size_t)f * N * N + (size_t)pu * N + pv;
 
   const float *dataf = A.data + (size_t)f * S * n * n;
   const float *wgtf = A.wgt + (size_t)f * S * n * n;
 
-  if (tid < S * 4) {
-    SP[tid] = A.stars[(size_t)f * S * 4 + tid];
-    SM[tid] = A.stars_m[(size_t)f * S * 4 + tid];
-    SV[tid] = A.stars_s[(size_t)f * S * 4 + tid];
+  if (tid0 < S * 4) {
+    SP[tid0] = A.stars[(size_t)f * S * 4 + tid0];
+    SM[tid0] = A.stars_m[(size_t)f * S * 4 + tid0];
+    SV[tid0] = A.stars_s[(size_t)f * S * 4 + tid0];
   }
   __syncthreads();
 
   for (int it = 0; it < A.n_iter; ++it) {
     const int tglob = A.t0 + it;
+    int tid = tid0;
+    LC_LAUNDER(tid);  // everything derived from tid is recomputed per iteration, not kept live
+    const int lane = tid & 63, wid = tid >> 6;
+    const int pu = tid / (N / PX);         // owned row
+    const int pv = (tid % (N / PX)) * PX;  // first owned column
+    const size_t gpix = (size_t)f * N * N + (size_t)pu * N + pv;
     if (tid == 0 && A.mode == 1) {
       const double t1 = (double)(tglob + 1);
       double lr = A.ab.init_learning_rate;
@@ -154,6 +312,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       SCAL[1] = (float)(1.0 / (1.0 - pow((double)A.ab.b1, t1)));
       SCAL[2] = (float)(1.0 / (1.0 - pow((double)A.ab.b2, t1)));
     }
+    LC_STAMP(0);
     // ---- P1: T = Moffat + B into LDS -----------------------------------------------------
     float gB[PX];
     {
@@ -172,24 +331,22 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     }
     if (tid < S * 5) SGR[tid] = 0.f;
 
+    // ---- tap tables of every star of the frame (once per iteration) ----------------------------
+    for (int e = tid; e < S * 2 * NT; e += NTHR) {
+      const int s = e / (2 * NT), ax = (e / NT) & 1, k = e % NT;
+      float tap, dtap;
+      int bq;
+      const float c_off = (N % 2 == 0) ? 0.5f : 0.0f;  // (N-1)/2 - (N-1)//2
+      const float delta = SS * SP[s * 4 + 1 + ax] + c_off;
+      tap_entry<SS, NT>(delta, k, tap, dtap, bq);
+      TAPS[(s * 4 + 2 * ax) * NT + k] = tap;
+      TAPS[(s * 4 + 2 * ax + 1) * NT + k] = dtap;
+      if (k == 0) BQ[s * 2 + ax] = bq;
+    }
+
     for (int g0 = 0; g0 < S; g0 += SG) {
-      // ---- tap tables of the stars of this group ------------------------------------------
-      __syncthreads();  // previous group's P5 (reads TAPS, V) done; T visible
-      for (int e = tid; e < SG * 2 * NT; e += NTHR) {
-        const int sl = e / (2 * NT), ax = (e / NT) & 1, k = e % NT;
-        const int s = g0 + sl;
-        float tap = 0.f, dtap = 0.f;
-        int bq = 0;
-        if (s < S) {
-          const float c_off = (N % 2 == 0) ? 0.5f : 0.0f;  // (N-1)/2 - (N-1)//2
-          const float delta = SS * SP[s * 4 + 1 + ax] + c_off;
-          tap_entry<SS, NT>(delta, k, tap, dtap, bq);
-        }
-        TAPS[(sl * 4 + 2 * ax) * NT + k] = tap;
-        TAPS[(sl * 4 + 2 * ax + 1) * NT + k] = dtap;
-        if (k == 0) BQ[sl * 2 + ax] = bq;
-      }
-      __syncthreads();
+      __syncthreads();  // T and taps visible; previous group's P5 (reads V) done before P2 rewrites R
+      LC_STAMP(1 + 5 * (g0 / SG));
       // ---- P2: row pass (x taps) fused with the column down-sampling ----------------------
       {
         constexpr int WL = SS * (LR - 1) + NT;
@@ -197,8 +354,8 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         for (int item = tid; item < SG * N * NSTRIP; item += NTHR) {
           const int u = item % N, strip = (item / N) % NSTRIP, sl = item / (N * NSTRIP);
           if (g0 + sl >= S) continue;
-          const float *tx = TAPS + (sl * 4 + 0) * NT, *dtx = tx + NT;
-          const int bq = BQ[sl * 2 + 0];
+          const float *tx = TAPS + ((g0 + sl) * 4 + 0) * NT, *dtx = tx + NT;
+          const int bq = BQ[(g0 + sl) * 2 + 0];
           const int a0 = strip * LR;
           const int ws = SS * (a0 - bq) - (NT - 1);
           float win[WL];
@@ -230,6 +387,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         }
       }
       __syncthreads();
+      LC_STAMP(2 + 5 * (g0 / SG));
       // ---- P3: column pass (y taps) fused with row down-sampling, residuals, reductions ----
       {
         constexpr int WL = SS * (LC - 1) + NT;
@@ -242,8 +400,8 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           float chi = 0.f, ga = 0.f, gx = 0.f, gy = 0.f, gs = 0.f;
           if (s < S && within < C::IPS) {
             const int jd = within % n, strip = within / n;
-            const float *ty = TAPS + (sl * 4 + 2) * NT, *dty = ty + NT;
-            const int bq = BQ[sl * 2 + 1];
+            const float *ty = TAPS + (s * 4 + 2) * NT, *dty = ty + NT;
+            const int bq = BQ[s * 2 + 1];
             const int a0 = strip * LC;
             const int ws = SS * (a0 - bq) - (NT - 1);
             const float amp = SP[s * 4 + 0], sky = SP[s * 4 + 3];
@@ -307,6 +465,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         }
       }
       __syncthreads();
+      LC_STAMP(3 + 5 * (g0 / SG));
       // per-star sums in fixed slot order
       if (tid < SG * 5) {
         const int sl = tid / 5, q = tid % 5;
@@ -323,8 +482,8 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         for (int item = tid; item < SG * n * NSTRIP; item += NTHR) {
           const int jd = item % n, strip = (item / n) % NSTRIP, sl = item / (n * NSTRIP);
           if (g0 + sl >= S) continue;
-          const float *ty = TAPS + (sl * 4 + 2) * NT;
-          const int bq = BQ[sl * 2 + 1];
+          const float *ty = TAPS + ((g0 + sl) * 4 + 2) * NT;
+          const int bq = BQ[(g0 + sl) * 2 + 1];
           const int a0 = strip * LA;
           float tk[NT];
 #pragma unroll
@@ -349,14 +508,15 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         }
       }
       __syncthreads();
+      LC_STAMP(4 + 5 * (g0 / SG));
       // ---- P5: transposed row pass, summed over the stars of the group into registers ------
       {
         constexpr int WJ = (PX - 1 + NT - 1) / SS + 1;
         for (int sl = 0; sl < SG; ++sl) {
           const int s = g0 + sl;
           if (s >= S) break;
-          const float *tx = TAPS + (sl * 4 + 0) * NT;
-          const int bq = BQ[sl * 2 + 0];
+          const float *tx = TAPS + (s * 4 + 0) * NT;
+          const int bq = BQ[s * 2 + 0];
           const float amp = SP[s * 4 + 0];
           float acc[PX];
 #pragma unroll
@@ -379,6 +539,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       }
     }  // groups
     __syncthreads();
+    LC_STAMP(40);
 
     if (A.out_gT) {
 #pragma unroll
@@ -391,7 +552,12 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
 #pragma unroll
     for (int p = 0; p < PX; ++p) z[p] = 0.f;
     const bool reg_on = (A.lam_sc != 0.f || A.lam_hf != 0.f);
+    const int pu_ = pu, pv_ = pv;
     if (reg_on) {
+      constexpr bool QREG = (J * PX <= 32);  // sub-gradients stay in registers when they fit
+      constexpr int TSS = C::TSS;            // 16-byte aligned rows for the forward sweep
+      float *fA = lds, *fB = lds + N * TSS;
+      float qreg[QREG ? J : 1][PX];
       float c[PX];
       {
         const float4 *bp = (const float4 *)(A.B + gpix);
@@ -402,28 +568,19 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           c[4 * q + 1] = b.y;
           c[4 * q + 2] = b.z;
           c[4 * q + 3] = b.w;
+          *(float4 *)&fA[pu * TSS + pv + 4 * q] = b;
         }
       }
-#pragma unroll
-      for (int p = 0; p < PX; ++p) bufA[pu * TS + pv + p] = c[p];
       __syncthreads();
+#pragma unroll
       for (int j = 0; j < J; ++j) {
+        constexpr int dummy = 0;
+        (void)dummy;
         const int d = 1 << j;
-        float r[PX];
-#pragma unroll
-        for (int p = 0; p < PX; ++p) {
-          float acc = 0.f;
-#pragma unroll
-          for (int t = -2; t <= 2; ++t) {
-            const int vv = min(max(pv + p + t * d, 0), N - 1);
-            acc = fmaf(b3tap(t), bufA[pu * TS + vv], acc);
-          }
-          r[p] = acc;
-        }
-#pragma unroll
-        for (int p = 0; p < PX; ++p) bufB[pu * TS + pv + p] = r[p];
-        __syncthreads();
-        const float lam = (j == 0) ? A.lam_hf : A.lam_sc;
+        int pu = pu_, pv = pv_;
+        LC_LAUNDER(pu);
+        LC_LAUNDER(pv);
+        // weights of this scale: issued before the row pass so the latency hides behind it
         float wj[PX];
         if (A.W) {
           const float4 *wp = (const float4 *)(A.W + ((size_t)f * J + j) * N * N + (size_t)pu * N + pv);
@@ -440,35 +597,121 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
 #pragma unroll
           for (int p = 0; p < PX; ++p) wj[p] = nv;
         }
+        // row pass: r = Row_j c (edge replicating), own samples from registers, neighbours by 128-bit reads
+        float r[PX];
+        const float *row = fA + pu * TSS;
+        if (d < 4) {
+          float w[PX + 8];
+          const float4 Lc = ld4(row + max(pv - 4, 0));
+          const float4 Rc = ld4(row + min(pv + PX, N - 4));
+          const bool hl = pv > 0, hr = pv + PX < N;
+          w[0] = hl ? Lc.x : c[0];
+          w[1] = hl ? Lc.y : c[0];
+          w[2] = hl ? Lc.z : c[0];
+          w[3] = hl ? Lc.w : c[0];
+#pragma unroll
+          for (int p = 0; p < PX; ++p) w[4 + p] = c[p];
+          w[PX + 4] = hr ? Rc.x : c[PX - 1];
+          w[PX + 5] = hr ? Rc.y : c[PX - 1];
+          w[PX + 6] = hr ? Rc.z : c[PX - 1];
+          w[PX + 7] = hr ? Rc.w : c[PX - 1];
+#pragma unroll
+          for (int p = 0; p < PX; ++p) {
+            float acc = 0.375f * w[4 + p];
+            acc = fmaf(0.25f, w[4 + p - d] + w[4 + p + d], acc);
+            acc = fmaf(0.0625f, w[4 + p - 2 * d] + w[4 + p + 2 * d], acc);
+            r[p] = acc;
+          }
+        } else {
+          const float e0 = row[0], eN = row[N - 1];
+#pragma unroll
+          for (int q = 0; q < PX / 4; ++q) {
+            float a4[4] = {0.375f * c[4 * q], 0.375f * c[4 * q + 1], 0.375f * c[4 * q + 2], 0.375f * c[4 * q + 3]};
+#pragma unroll
+            for (int t = -2; t <= 2; ++t) {
+              if (t == 0) continue;
+              const int idx = pv + 4 * q + t * d;
+              const float4 v4 = ld4(row + min(max(idx, 0), N - 4));
+              const float bt = b3tap(t);
+              const bool lo = idx < 0, hi = idx > N - 4;
+              a4[0] = fmaf(bt, lo ? e0 : (hi ? eN : v4.x), a4[0]);
+              a4[1] = fmaf(bt, lo ? e0 : (hi ? eN : v4.y), a4[1]);
+              a4[2] = fmaf(bt, lo ? e0 : (hi ? eN : v4.z), a4[2]);
+              a4[3] = fmaf(bt, lo ? e0 : (hi ? eN : v4.w), a4[3]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[4 * q + e] = a4[e];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < PX / 4; ++q)
+          *(float4 *)&fB[pu * TSS + pv + 4 * q] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+        __syncthreads();
+        // column pass: c_{j+1} = Col_j r; detail coefficients, l1 value and sub-gradient
+        const float lam = (j == 0) ? A.lam_hf : A.lam_sc;
         float q[PX];
 #pragma unroll
-        for (int p = 0; p < PX; ++p) {
-          float acc = 0.f;
+        for (int qq = 0; qq < PX / 4; ++qq) {
+          float a4[4] = {0.375f * r[4 * qq], 0.375f * r[4 * qq + 1], 0.375f * r[4 * qq + 2], 0.375f * r[4 * qq + 3]};
 #pragma unroll
           for (int t = -2; t <= 2; ++t) {
+            if (t == 0) continue;
             const int uu = min(max(pu + t * d, 0), N - 1);
-            acc = fmaf(b3tap(t), bufB[uu * TS + pv + p], acc);
+            const float4 v4 = ld4(fB + uu * TSS + pv + 4 * qq);
+            const float bt = b3tap(t);
+            a4[0] = fmaf(bt, v4.x, a4[0]);
+            a4[1] = fmaf(bt, v4.y, a4[1]);
+            a4[2] = fmaf(bt, v4.z, a4[2]);
+            a4[3] = fmaf(bt, v4.w, a4[3]);
           }
-          const float w = c[p] - acc;
-          const float lw = lam * wj[p];
-          l1 = fmaf(lw, fabsf(w), l1);
-          q[p] = (w > 0.f) ? lw : ((w < 0.f) ? -lw : 0.f);
-          c[p] = acc;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int p = 4 * qq + e;
+            const float w = c[p] - a4[e];
+            const float lw = lam * wj[p];
+            l1 = fmaf(lw, fabsf(w), l1);
+            q[p] = (w > 0.f) ? lw : ((w < 0.f) ? -lw : 0.f);
+            c[p] = a4[e];
+          }
         }
-        {
+        if constexpr (QREG) {
+#pragma unroll
+          for (int p = 0; p < PX; ++p) qreg[j][p] = q[p];
+        } else {
           float4 *qp = (float4 *)(A.qscratch + ((size_t)f * J + j) * N * N + (size_t)pu * N + pv);
 #pragma unroll
           for (int qq = 0; qq < PX / 4; ++qq) qp[qq] = make_float4(q[4 * qq], q[4 * qq + 1], q[4 * qq + 2], q[4 * qq + 3]);
         }
+        if (j + 1 < J) {
 #pragma unroll
-        for (int p = 0; p < PX; ++p) bufA[pu * TS + pv + p] = c[p];
+          for (int qq = 0; qq < PX / 4; ++qq)
+            *(float4 *)&fA[pu * TSS + pv + 4 * qq] = make_float4(c[4 * qq], c[4 * qq + 1], c[4 * qq + 2], c[4 * qq + 3]);
+        }
         __syncthreads();
       }
-      // backward: z_J = 0; z_j = q_j + H_j^T (z_{j+1} - q_j), H_j^T = Row^T Col^T (edge-replicating adjoint)
-      for (int j = J - 1; j >= 0; --j) {
-        const int d = 1 << j;
+      LC_STAMP(41);
+      // backward: z_J = 0; z_j = q_j + H_j^T (z_{j+1} - q_j), H_j^T = Row^T Col^T (edge-replicating adjoint).
+      // Col^T runs with a column-major thread mapping and Row^T with the row-major one, so that each
+      // line (column resp. row) is owned by LPR consecutive lanes and both passes are lane shifts.
+      constexpr int LPR = N / PX;
+      constexpr bool FAST = (LPR == 4 || LPR == 8 || LPR == 16);
+      const int cu0_ = (tid % LPR) * PX;  // column-major mapping: first owned row ...
+      const int cv_ = tid / LPR;          // ... of this column
+      const int lil_ = tid % LPR;
+      static_for(std::make_integer_sequence<int, J>{}, [&](auto jc) {
+        constexpr int j = J - 1 - decltype(jc)::value;
+        constexpr int d = 1 << j;
+        int pu = pu_, pv = pv_, cu0 = cu0_, cv = cv_, lil = lil_;
+        LC_LAUNDER(pu);
+        LC_LAUNDER(pv);
+        LC_LAUNDER(cu0);
+        LC_LAUNDER(cv);
+        LC_LAUNDER(lil);
         float q[PX];
-        {
+        if constexpr (QREG) {
+#pragma unroll
+          for (int p = 0; p < PX; ++p) q[p] = qreg[j][p];
+        } else {
           const float4 *qp = (const float4 *)(A.qscratch + ((size_t)f * J + j) * N * N + (size_t)pu * N + pv);
 #pragma unroll
           for (int qq = 0; qq < PX / 4; ++qq) {
@@ -482,79 +725,32 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
 #pragma unroll
         for (int p = 0; p < PX; ++p) bufA[pu * TS + pv + p] = z[p] - q[p];
         __syncthreads();
-        // Col^T
         float ct[PX];
+        if constexpr (FAST) {
+          float own[PX];
 #pragma unroll
-        for (int p = 0; p < PX; ++p) {
-          const int v = pv + p;
-          float acc;
-          if (pu > 0 && pu < N - 1) {
-            acc = 0.f;
-#pragma unroll
-            for (int t = -2; t <= 2; ++t) {
-              const int uu = pu - t * d;
-              if (uu >= 0 && uu <= N - 1) acc = fmaf(b3tap(t), bufA[uu * TS + v], acc);
-            }
-          } else if (pu == 0) {
-            float s1 = 0.f, s2 = 0.f;
-            const int m1 = min(d, N - 1), m2 = min(2 * d, N - 1);
-            for (int uu = 0; uu <= m2; ++uu) {
-              const float gv = bufA[uu * TS + v];
-              if (uu <= m1) s1 += gv;
-              s2 += gv;
-            }
-            acc = 0.375f * bufA[v] + 0.25f * s1 + 0.0625f * s2;
-          } else {
-            float s1 = 0.f, s2 = 0.f;
-            const int m1 = max(N - 1 - d, 0), m2 = max(N - 1 - 2 * d, 0);
-            for (int uu = m2; uu <= N - 1; ++uu) {
-              const float gv = bufA[uu * TS + v];
-              if (uu >= m1) s1 += gv;
-              s2 += gv;
-            }
-            acc = 0.375f * bufA[(N - 1) * TS + v] + 0.25f * s1 + 0.0625f * s2;
-          }
-          ct[p] = acc;
+          for (int p = 0; p < PX; ++p) own[p] = bufA[(cu0 + p) * TS + cv];
+          adjoint_line_dpp<N, PX, LPR, d>(own, cu0, lil, ct);  // Col^T: line = column cv
+        } else {
+          adjoint_line_lds<N, PX>(bufA, cv, TS, cu0, d, ct);
         }
 #pragma unroll
-        for (int p = 0; p < PX; ++p) bufB[pu * TS + pv + p] = ct[p];
+        for (int p = 0; p < PX; ++p) bufB[(cu0 + p) * TS + cv] = ct[p];
         __syncthreads();
-        // Row^T
+        float rt[PX];
+        if constexpr (FAST) {
+          float own[PX];
 #pragma unroll
-        for (int p = 0; p < PX; ++p) {
-          const int v = pv + p;
-          float acc;
-          if (v > 0 && v < N - 1) {
-            acc = 0.f;
-#pragma unroll
-            for (int t = -2; t <= 2; ++t) {
-              const int vv = v - t * d;
-              if (vv >= 0 && vv <= N - 1) acc = fmaf(b3tap(t), bufB[pu * TS + vv], acc);
-            }
-          } else if (v == 0) {
-            float s1 = 0.f, s2 = 0.f;
-            const int m1 = min(d, N - 1), m2 = min(2 * d, N - 1);
-            for (int vv = 0; vv <= m2; ++vv) {
-              const float gv = bufB[pu * TS + vv];
-              if (vv <= m1) s1 += gv;
-              s2 += gv;
-            }
-            acc = 0.375f * bufB[pu * TS] + 0.25f * s1 + 0.0625f * s2;
-          } else {
-            float s1 = 0.f, s2 = 0.f;
-            const int m1 = max(N - 1 - d, 0), m2 = max(N - 1 - 2 * d, 0);
-            for (int vv = m2; vv <= N - 1; ++vv) {
-              const float gv = bufB[pu * TS + vv];
-              if (vv >= m1) s1 += gv;
-              s2 += gv;
-            }
-            acc = 0.375f * bufB[pu * TS + N - 1] + 0.25f * s1 + 0.0625f * s2;
-          }
-          z[p] = q[p] + acc;
+          for (int p = 0; p < PX; ++p) own[p] = bufB[pu * TS + pv + p];
+          adjoint_line_dpp<N, PX, LPR, d>(own, pv, lil, rt);  // Row^T: line = row pu
+        } else {
+          adjoint_line_lds<N, PX>(bufB, pu * TS, 1, pv, d, rt);
         }
-        // next scale writes bufA only after every thread has passed the barrier above
-      }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) z[p] = q[p] + rt[p];
+      });
     }
+    LC_STAMP(42);
     // ---- loss ------------------------------------------------------------------------------
     {
       const float wl = wave_sum(l1);
@@ -616,12 +812,13 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       }
     }
     __syncthreads();
+    LC_STAMP(43);
   }  // iterations
 
-  if (A.mode == 1 && tid < S * 4) {
-    A.stars[(size_t)f * S * 4 + tid] = SP[tid];
-    A.stars_m[(size_t)f * S * 4 + tid] = SM[tid];
-    A.stars_s[(size_t)f * S * 4 + tid] = SV[tid];
+  if (A.mode == 1 && tid0 < S * 4) {
+    A.stars[(size_t)f * S * 4 + tid0] = SP[tid0];
+    A.stars_m[(size_t)f * S * 4 + tid0] = SM[tid0];
+    A.stars_s[(size_t)f * S * 4 + tid0] = SV[tid0];
   }
 }
 

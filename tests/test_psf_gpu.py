@@ -2,8 +2,8 @@
 
 Tolerances: the HIP path computes in fp32, the oracle in fp64.  Single evaluations (loss, model,
 gradients) must agree to 2e-5 relative to the largest element; short AdaBelief trajectories to
-1e-4 on the loss history and 2e-3 on the moved parameters (sign-like first steps amplify fp32
-rounding of near-zero gradients); converged fits are checked in test_build_psf_gpu.py.
+1e-4 on the loss history; moved pixels are bounded as explained in the test (sign-like first
+steps amplify fp32 rounding of near-zero gradients); converged fits are checked in test_build_psf_gpu.py.
 """
 import numpy as np
 import pytest
@@ -102,6 +102,12 @@ def test_adabelief_trajectory_matches_oracle(ctx, n, ss, S):
         pf, lh, l0 = oo.adabelief(fn, plist[f], ['B', 'a', 'x0', 'y0'], 1e-4, T, schedule=True)
         ref = np.array([l0] + lh)
         assert np.abs(hist[f] - ref).max() / np.abs(ref).max() < 1e-4
-        assert np.abs(grid[f].ravel() - pf['B'].numpy()).max() < 2e-3 * T * 1e-4 + 1e-7
+        # AdaBelief's first steps are sign-like (|update| ~ lr whatever |g|), so a pixel whose tiny
+        # gradient rounds differently in fp32 may drift by a fraction of a step: bound the worst pixel
+        # by 2 % of the maximum travel T * lr and require the typical pixel to agree to 1e-7.
+        dB = np.abs(grid[f].ravel() - pf['B'].numpy())
+        assert dB.max() < 0.02 * T * 1e-4
+        assert np.median(dB) < 1e-7
+        assert (dB > 1e-6).mean() < 0.01
         assert H.rel_err(stars[f][:, 0], pf['a'].numpy()) < 1e-5
         assert np.abs(stars[f][:, 1] - pf['x0'].numpy()).max() < 2e-5
