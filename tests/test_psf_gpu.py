@@ -111,3 +111,36 @@ def test_adabelief_trajectory_matches_oracle(ctx, n, ss, S):
         assert (dB > 1e-6).mean() < 0.01
         assert H.rel_err(stars[f][:, 0], pf['a'].numpy()) < 1e-5
         assert np.abs(stars[f][:, 1] - pf['x0'].numpy()).max() < 2e-5
+
+
+def test_moffat_stage_reaches_oracle_optimum(ctx):
+    """Stage A (Moffat + a, x0, y0 by bounded L-BFGS): the batched device-driven L-BFGS and scipy's
+    L-BFGS-B on the oracle loss must land on the same optimum (iterates differ by construction)."""
+    import math
+    n, ss, S, F = 16, 2, 4, 2
+    ds, plist, b = _setup(n, ss, F, S, 31, ctx, jitter=0.0)
+    b.set_grid(None)
+    stars = H.stars_array(plist)
+    stars[..., 3] = 0.0
+    b.set_stars(stars)
+    final = b.fit_moffat(200)
+    mof = b.get_moffat()
+    st = b.get_stars()
+    free = ['fwhm_x', 'fwhm_y', 'phi', 'beta', 'a', 'x0', 'y0']
+    bounds = dict(fwhm_x=(0.5 / ss, n / 2), fwhm_y=(0.5 / ss, n / 2), phi=(-math.pi, math.pi), beta=(1.1, 50.),
+                  a=(0, np.inf), x0=(-n / 4, n / 4), y0=(-n / 4, n / 4))
+    for f in range(F):
+        data, sig2, mask = H.psf_oracle_inputs(ds, f, ss)
+        p0 = dict(plist[f])
+        p0['B'] = torch.zeros_like(p0['B'])
+        p0['sky'] = torch.zeros_like(p0['sky'])
+        fn = lambda q: om.psf_loss(q, data, sig2, mask, ss)
+        po, hist, res = oo.lbfgsb(fn, p0, free, 200, bounds)
+        assert final[f] <= res.fun * (1 + 2e-4) + 1e-6, (final[f], res.fun)
+        assert abs(final[f] - res.fun) / res.fun < 2e-3
+        assert H.rel_err(st[f][:, 0], po['a'].numpy()) < 5e-3
+        assert np.abs(st[f][:, 1] - po['x0'].numpy()).max() < 5e-3
+        # mean FWHM is well constrained; beta / ellipticity less so
+        fw_gpu = 0.5 * (mof[f, 0] + mof[f, 1])
+        fw_or = 0.5 * (float(po['fwhm_x']) + float(po['fwhm_y']))
+        assert abs(fw_gpu - fw_or) / fw_or < 2e-2
