@@ -1,23 +1,586 @@
-// placeholder until the joint-fit kernels land
-#include "lc_common.h"
-struct lc_joint { lc_ctx *ctx; };
-extern "C" {
-int lc_joint_supported(int, int) { return 0; }
-int lc_joint_create(lc_ctx *ctx, int, int, int, int, const float *, const float *, const float *, lc_joint **) { if (ctx) ctx->err = "joint fit not built"; return LC_ERR_UNSUPPORTED; }
-void lc_joint_destroy(lc_joint *) {}
-int lc_joint_set_param(lc_joint *, int, const float *, int) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_get_param(lc_joint *, int, float *, int) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_set_free(lc_joint *, const int32_t *) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_set_loss(lc_joint *, const lc_joint_loss_cfg *, const float *) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_propagate_noise(lc_joint *, float *) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_loss_grad(lc_joint *, float *, float *const *) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_model(lc_joint *, float *, float *) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_deconvolved(lc_joint *, int, float *, float *) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_run_adabelief(lc_joint *, int, const lc_adabelief_cfg *) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_get_loss_history(lc_joint *, float *, int) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_iterations_done(lc_joint *) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_fisher_flux_sigma(lc_joint *, float *) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_step_local(lc_joint *) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_shared_buffer_dev(lc_joint *, void **, int *) { return LC_ERR_UNSUPPORTED; }
-int lc_joint_step_update(lc_joint *, const lc_adabelief_cfg *) { return LC_ERR_UNSUPPORTED; }
+// Joint multi-epoch forward-model object behind the C ABI (include/lcmi.h, "joint" section).
+#include <cmath>
+#include <complex>
+#include <cstring>
+
+#include "joint_kernels.h"
+#include "noise_kernels.h"
+
+using namespace lc;
+
+struct lc_joint {
+  lc_ctx *ctx = nullptr;
+  int E = 0, M = 0, n = 0, ss = 0, N = 0, L = 0, J = 0, KH = 0;
+  float *data = nullptr, *wgt = nullptr;
+  float2 *St = nullptr, *twid = nullptr;
+  float *par[LC_P_COUNT] = {}, *pm[LC_P_COUNT] = {}, *ps[LC_P_COUNT] = {}, *gout[LC_P_COUNT] = {};
+  int psize[LC_P_COUNT] = {};
+  float *tabs = nullptr, *GS = nullptr, *HG = nullptr;
+  float *chi2_e = nullptr, *g_a = nullptr, *g_cx_e = nullptr, *g_cy_e = nullptr, *g_dx = nullptr, *g_dy = nullptr,
+        *g_mean = nullptr;
+  float *model = nullptr, *fisher = nullptr, *shared = nullptr, *W = nullptr, *norms = nullptr, *atoms = nullptr,
+        *qscr = nullptr, *V = nullptr, *out_loss = nullptr, *hist = nullptr, *scene2 = nullptr;
+  float *prior = nullptr;  // [4][M]
+  int shared_count = 0, hist_cap = 0, iters_done = 0, n_prior = 0;
+  int free_mask[LC_P_COUNT] = {};
+  bool have_W = false, h_nonzero = false;
+  lc_joint_loss_cfg cfg{};
+  std::vector<float> h_sigma2, h_psf;  // host copies for the one-time noise propagation
+  std::vector<void *> allocs;
+};
+
+namespace {
+
+template <class T>
+int dmalloc(lc_joint *j, T **p, size_t count) {
+  LC_HIP(j->ctx, hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+  j->allocs.push_back(*p);
+  LC_HIP(j->ctx, hipMemsetAsync(*p, 0, std::max<size_t>(count, 1) * sizeof(T), j->ctx->stream));
+  return LC_OK;
 }
+int h2d(lc_joint *j, void *dst, const void *src, size_t bytes) {
+  LC_HIP(j->ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, j->ctx->stream));
+  LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+  return LC_OK;
+}
+int d2h(lc_joint *j, void *dst, const void *src, size_t bytes) {
+  LC_HIP(j->ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, j->ctx->stream));
+  LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+  return LC_OK;
+}
+
+// ---- small host FFT (double) for the one-time PSF spectra and noise propagation -------------------
+typedef std::complex<double> cd;
+void fft1d(cd *x, int L, bool inv) {
+  for (int i = 1, j = 0; i < L; ++i) {
+    int bit = L >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(x[i], x[j]);
+  }
+  for (int len = 2; len <= L; len <<= 1) {
+    const double ang = 2.0 * M_PI / len * (inv ? 1.0 : -1.0);
+    const cd wl(std::cos(ang), std::sin(ang));
+    for (int i = 0; i < L; i += len) {
+      cd w(1.0, 0.0);
+      for (int k = 0; k < len / 2; ++k) {
+        const cd u = x[i + k], v = x[i + k + len / 2] * w;
+        x[i + k] = u + v;
+        x[i + k + len / 2] = u - v;
+        w *= wl;
+      }
+    }
+  }
+}
+// 2-D FFT of an L x L array whose non-zero rows are [r0, r0 + nr)
+void fft2d(std::vector<cd> &a, int L, int r0, int nr, bool inv) {
+  if (!inv) {
+    for (int r = r0; r < r0 + nr; ++r) fft1d(&a[(size_t)r * L], L, false);
+  }
+  std::vector<cd> col(L);
+  for (int c = 0; c < L; ++c) {
+    for (int r = 0; r < L; ++r) col[r] = a[(size_t)r * L + c];
+    fft1d(col.data(), L, inv);
+    for (int r = 0; r < L; ++r) a[(size_t)r * L + c] = col[r];
+  }
+  if (inv)
+    for (int r = 0; r < L; ++r) fft1d(&a[(size_t)r * L], L, true);
+}
+
+int fft_length(int N) {
+  const int c = (N - 1) / 2;
+  int L = 1;
+  while (L < 2 * N - 1 - c) L <<= 1;
+  return L;
+}
+
+typedef void (*epoch_fn)(JointArgs);
+typedef void (*update_fn)(JointUpdArgs);
+struct JointVariant {
+  int n, ss, L;
+  epoch_fn ek;
+  int e_lds;
+  update_fn uk;
+  int u_thr, u_lds;
+};
+template <int N, int SS, int L, int PX>
+JointVariant make_jv() {
+  typedef JointCfg<N, SS, L> C;
+  return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, joint_update_kernel<N, PX>, N * N / PX,
+                      (int)(StarletLds<N>::FLOATS * sizeof(float))};
+}
+const JointVariant *find_jv(int n, int ss) {
+  static const JointVariant table[] = {
+      make_jv<16, 1, 32, 4>(),     // n = 16, ss = 1 (reference test fixture)
+      make_jv<32, 2, 64, 4>(),     // n = 16, ss = 2
+      make_jv<48, 2, 128, 4>(),    // n = 24 (default stamp_size_stars)
+      make_jv<64, 2, 128, 8>(),    // n = 32 (default stamp_size_ROI)
+      make_jv<128, 2, 256, 16>(),  // n = 64 (C4)
+  };
+  for (const auto &v : table)
+    if (v.n == n && v.ss == ss) return &v;
+  return nullptr;
+}
+
+__global__ void joint_scene_kernel(int N, int ss, int M, int e, const float *a, const float *cx, const float *cy,
+                                   const float *dx, const float *dy, const float *alpha, const float *h, float *scene,
+                                   float *background) {
+  const float c0 = (N - 1) * 0.5f;
+  const float al = alpha[e] * 0.017453292519943295f;
+  const float ca = cosf(al), sa = sinf(al);
+  const float sdx = ss * dx[e], sdy = ss * dy[e];
+  const float inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm2 = 0.15915494309189535f * inv_s2;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < N * N; k += gridDim.x * blockDim.x) {
+    const int u = k / N, v = k % N;
+    float Xs, Ys;
+    sample_coords(u, v, c0, ca, sa, sdx, sdy, Xs, Ys);
+    const float x0f = floorf(Xs), y0f = floorf(Ys);
+    const float fx = Xs - x0f, fy = Ys - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int xa = min(max(x0, 0), N - 1), xb = min(max(x0 + 1, 0), N - 1);
+    const int ya = min(max(y0, 0), N - 1), yb = min(max(y0 + 1, 0), N - 1);
+    const float top = h[ya * N + xa] + fx * (h[ya * N + xb] - h[ya * N + xa]);
+    const float bot = h[yb * N + xa] + fx * (h[yb * N + xb] - h[yb * N + xa]);
+    const float bg = top + fy * (bot - top);
+    float ps = 0.f;
+    for (int i = 0; i < M; ++i) {
+      const float X = c0 + ss * (ca * cx[i] - sa * cy[i] + dx[e]);
+      const float Y = c0 + ss * (sa * cx[i] + ca * cy[i] + dy[e]);
+      const float tx = v - X, ty = u - Y;
+      ps += a[e * M + i] * nrm2 * expf(-0.5f * (tx * tx + ty * ty) * inv_s2);
+    }
+    scene[k] = ps + bg;
+    background[k] = bg;
+  }
+}
+
+int ensure_hist(lc_joint *j, int needed) {
+  if (needed <= j->hist_cap) return LC_OK;
+  const int nc = std::max(needed, 2 * j->hist_cap + 64);
+  float *nh = nullptr;
+  LC_HIP(j->ctx, hipMalloc((void **)&nh, (size_t)nc * sizeof(float)));
+  LC_HIP(j->ctx, hipMemsetAsync(nh, 0, (size_t)nc * sizeof(float), j->ctx->stream));
+  if (j->hist) {
+    LC_HIP(j->ctx, hipMemcpyAsync(nh, j->hist, (size_t)j->hist_cap * sizeof(float), hipMemcpyDeviceToDevice, j->ctx->stream));
+    LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+    hipFree(j->hist);
+  }
+  j->hist = nh;
+  j->hist_cap = nc;
+  return LC_OK;
+}
+
+bool reg_h_on(const lc_joint *j) {
+  const bool lam = (j->cfg.lam_scales != 0.f || j->cfg.lam_hf != 0.f || j->cfg.lam_positivity != 0.f);
+  return lam && (j->free_mask[LC_P_H] || j->h_nonzero);
+}
+
+int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model_out) {
+  const JointVariant *v = find_jv(j->n, j->ss);
+  JointArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.E = j->E;
+  A.M = j->M;
+  A.mode = mode;
+  A.isrc = isrc;
+  A.h_active = (j->free_mask[LC_P_H] || j->h_nonzero || want_hgrad) ? 1 : 0;
+  A.need_hgrad = (mode == 0 && (j->free_mask[LC_P_H] || want_hgrad)) ? 1 : 0;
+  A.data = j->data;
+  A.wgt = j->wgt;
+  A.St = j->St;
+  A.twid = j->twid;
+  A.a = j->par[LC_P_A];
+  A.cx = j->par[LC_P_CX];
+  A.cy = j->par[LC_P_CY];
+  A.dx = j->par[LC_P_DX];
+  A.dy = j->par[LC_P_DY];
+  A.alpha = j->par[LC_P_ALPHA];
+  A.h = j->par[LC_P_H];
+  A.mean = j->par[LC_P_MEAN];
+  A.tabs = j->tabs;
+  A.GS = j->GS;
+  A.HG = j->HG;
+  A.chi2_e = j->chi2_e;
+  A.g_a = j->g_a;
+  A.g_cx_e = j->g_cx_e;
+  A.g_cy_e = j->g_cy_e;
+  A.g_dx = j->g_dx;
+  A.g_dy = j->g_dy;
+  A.g_mean = j->g_mean;
+  A.model_out = model_out;
+  A.fisher_out = j->fisher;
+  LC_HIP(j->ctx, hipFuncSetAttribute((const void *)v->ek, hipFuncAttributeMaxDynamicSharedMemorySize, v->e_lds));
+  hipLaunchKernelGGL(v->ek, dim3(j->E), dim3(256), v->e_lds, j->ctx->stream, A);
+  LC_HIP(j->ctx, hipGetLastError());
+  return A.need_hgrad;
+}
+
+int launch_reduce(lc_joint *j, int need_h) {
+  const int NN = j->N * j->N, total = NN + 4 * j->M + 2;
+  hipLaunchKernelGGL(joint_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, j->ctx->stream, j->E, j->M, NN,
+                     need_h, j->HG, j->g_cx_e, j->g_cy_e, j->chi2_e, j->par[LC_P_A], j->shared);
+  LC_HIP(j->ctx, hipGetLastError());
+  return LC_OK;
+}
+
+int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, bool write_hist, bool all_grads) {
+  const JointVariant *v = find_jv(j->n, j->ss);
+  JointUpdArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.E = j->E;
+  A.M = j->M;
+  A.mode = mode;
+  A.t = t;
+  for (int k = 0; k < LC_P_COUNT; ++k) {
+    A.free_mask[k] = j->free_mask[k];
+    A.par[k] = j->par[k];
+    A.pm[k] = j->pm[k];
+    A.ps[k] = j->ps[k];
+    A.gout[k] = (mode == 0 && all_grads) ? j->gout[k] : nullptr;
+  }
+  A.shared = j->shared;
+  A.h = j->par[LC_P_H];
+  A.mh = j->pm[LC_P_H];
+  A.sh = j->ps[LC_P_H];
+  A.W = j->have_W ? j->W : nullptr;
+  A.norms = j->norms;
+  A.qscr = j->qscr;
+  A.g_a = j->g_a;
+  A.g_dx = j->g_dx;
+  A.g_dy = j->g_dy;
+  A.g_mean = j->g_mean;
+  A.hist = write_hist ? j->hist : nullptr;
+  A.out_loss = j->out_loss;
+  const bool rh = reg_h_on(j);
+  A.lam_sc = rh ? j->cfg.lam_scales : 0.f;
+  A.lam_hf = rh ? j->cfg.lam_hf : 0.f;
+  A.lam_pos = rh ? j->cfg.lam_positivity : 0.f;
+  A.lam_pos_ps = j->cfg.lam_positivity_ps;
+  A.lam_pts = j->cfg.lam_pts_source;
+  A.lam_fu = j->cfg.lam_flux_uniformity;
+  A.n_prior = j->n_prior;
+  A.prior_cx_mean = j->prior;
+  A.prior_cx_sigma = j->prior + j->M;
+  A.prior_cy_mean = j->prior + 2 * j->M;
+  A.prior_cy_sigma = j->prior + 3 * j->M;
+  if (cfg) A.ab = *cfg; else lc_adabelief_defaults(&A.ab);
+  LC_HIP(j->ctx, hipFuncSetAttribute((const void *)v->uk, hipFuncAttributeMaxDynamicSharedMemorySize, v->u_lds));
+  hipLaunchKernelGGL(v->uk, dim3(1), dim3(v->u_thr), v->u_lds, j->ctx->stream, A);
+  LC_HIP(j->ctx, hipGetLastError());
+  return LC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lc_joint_supported(int n, int ss) { return find_jv(n, ss) != nullptr; }
+
+int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data, const float *sigma2,
+                    const float *psf, lc_joint **out) {
+  if (!ctx || !out || !data || !sigma2 || !psf || E <= 0 || M < 0) {
+    if (ctx) ctx->err = "lc_joint_create: invalid argument";
+    return LC_ERR_INVALID;
+  }
+  if (M > kMaxSources) LC_FAIL(ctx, LC_ERR_UNSUPPORTED, "at most 8 point sources");
+  const JointVariant *v = find_jv(n, ss);
+  if (!v) LC_FAIL(ctx, LC_ERR_UNSUPPORTED, "no joint-fit kernel instantiated for this stamp size");
+  LC_HIP(ctx, hipSetDevice(ctx->device));
+  lc_joint *j = new lc_joint();
+  j->ctx = ctx;
+  j->E = E;
+  j->M = M;
+  j->n = n;
+  j->ss = ss;
+  j->N = n * ss;
+  j->L = v->L;
+  j->KH = j->L / 2 + 1;
+  j->J = ilog2(j->N);
+  const int N = j->N, L = j->L, KH = j->KH;
+  const size_t NN = (size_t)N * N, nn = (size_t)n * n;
+  int rc = 0;
+#define TRY(x)             \
+  if ((rc = (x)) != 0) {   \
+    lc_joint_destroy(j);   \
+    return rc;             \
+  }
+  const int sizes[LC_P_COUNT] = {E * M, M, M, E, E, E, (int)NN, E};
+  for (int k = 0; k < LC_P_COUNT; ++k) {
+    j->psize[k] = sizes[k];
+    TRY(dmalloc(j, &j->par[k], sizes[k]));
+    TRY(dmalloc(j, &j->pm[k], sizes[k]));
+    TRY(dmalloc(j, &j->ps[k], sizes[k]));
+    TRY(dmalloc(j, &j->gout[k], sizes[k]));
+  }
+  TRY(dmalloc(j, &j->data, E * nn));
+  TRY(dmalloc(j, &j->wgt, E * nn));
+  TRY(dmalloc(j, &j->St, (size_t)E * KH * L));
+  TRY(dmalloc(j, &j->twid, L / 2));
+  TRY(dmalloc(j, &j->tabs, (size_t)E * 4 * std::max(M, 1) * N));
+  TRY(dmalloc(j, &j->GS, E * NN));
+  TRY(dmalloc(j, &j->HG, E * NN));
+  TRY(dmalloc(j, &j->chi2_e, E));
+  TRY(dmalloc(j, &j->g_a, E * M));
+  TRY(dmalloc(j, &j->g_cx_e, E * M));
+  TRY(dmalloc(j, &j->g_cy_e, E * M));
+  TRY(dmalloc(j, &j->g_dx, E));
+  TRY(dmalloc(j, &j->g_dy, E));
+  TRY(dmalloc(j, &j->g_mean, E));
+  TRY(dmalloc(j, &j->model, E * nn));
+  TRY(dmalloc(j, &j->fisher, E * M));
+  j->shared_count = (int)NN + 4 * M + 2;
+  TRY(dmalloc(j, &j->shared, j->shared_count));
+  TRY(dmalloc(j, &j->W, (size_t)(j->J + 1) * NN));
+  TRY(dmalloc(j, &j->norms, j->J + 1));
+  TRY(dmalloc(j, &j->atoms, (size_t)(j->J + 1) * 3 * N));
+  TRY(dmalloc(j, &j->qscr, (size_t)(j->J + 1) * NN));
+  TRY(dmalloc(j, &j->V, NN));
+  TRY(dmalloc(j, &j->out_loss, 4));
+  TRY(dmalloc(j, &j->scene2, 2 * NN));
+  TRY(dmalloc(j, &j->prior, 4 * std::max(M, 1)));
+  TRY(ensure_hist(j, 64));
+  {
+    std::vector<float> d(data, data + E * nn), w(E * nn);
+    j->h_sigma2.assign(sigma2, sigma2 + E * nn);
+    for (size_t i = 0; i < d.size(); ++i) {
+      const float s2 = sigma2[i];
+      if (!std::isfinite(d[i]) || !std::isfinite(s2) || s2 <= 0.f) {
+        d[i] = 0.f;
+        w[i] = 0.f;
+      } else {
+        w[i] = 1.0f / s2;
+      }
+    }
+    TRY(h2d(j, j->data, d.data(), d.size() * sizeof(float)));
+    TRY(h2d(j, j->wgt, w.data(), w.size() * sizeof(float)));
+  }
+  {
+    std::vector<float2> tw(L / 2);
+    for (int k = 0; k < L / 2; ++k) tw[k] = make_float2((float)std::cos(-2.0 * M_PI * k / L), (float)std::sin(-2.0 * M_PI * k / L));
+    TRY(h2d(j, j->twid, tw.data(), tw.size() * sizeof(float2)));
+    std::vector<float> norms, atoms;
+    starlet_noise_tables(N, j->J, norms, atoms);
+    TRY(h2d(j, j->norms, norms.data(), norms.size() * sizeof(float)));
+    TRY(h2d(j, j->atoms, atoms.data(), atoms.size() * sizeof(float)));
+  }
+  {
+    // PSF spectra: FFT2 of the zero-padded narrow PSF, stored transposed and pre-divided by L^2
+    j->h_psf.assign(psf, psf + E * NN);
+    std::vector<cd> a((size_t)L * L);
+    std::vector<float2> st((size_t)KH * L);
+    const double sc = 1.0 / ((double)L * L);
+    for (int e = 0; e < E; ++e) {
+      std::fill(a.begin(), a.end(), cd(0, 0));
+      for (int r = 0; r < N; ++r)
+        for (int c = 0; c < N; ++c) a[(size_t)r * L + c] = psf[(size_t)e * NN + (size_t)r * N + c];
+      fft2d(a, L, 0, N, false);
+      for (int k = 0; k < KH; ++k)
+        for (int r = 0; r < L; ++r) st[(size_t)k * L + r] = make_float2((float)(a[(size_t)r * L + k].real() * sc), (float)(a[(size_t)r * L + k].imag() * sc));
+      TRY(h2d(j, j->St + (size_t)e * KH * L, st.data(), st.size() * sizeof(float2)));
+    }
+  }
+  for (int k = 0; k < LC_P_COUNT; ++k) j->free_mask[k] = 0;
+#undef TRY
+  *out = j;
+  return LC_OK;
+}
+
+void lc_joint_destroy(lc_joint *j) {
+  if (!j) return;
+  hipStreamSynchronize(j->ctx->stream);
+  for (void *p : j->allocs) hipFree(p);
+  if (j->hist) hipFree(j->hist);
+  delete j;
+}
+
+int lc_joint_set_param(lc_joint *j, int which, const float *values, int count) {
+  if (!j || which < 0 || which >= LC_P_COUNT || !values) return LC_ERR_INVALID;
+  if (count != j->psize[which]) LC_FAIL(j->ctx, LC_ERR_INVALID, "lc_joint_set_param: wrong element count");
+  if (which == LC_P_H) {
+    j->h_nonzero = false;
+    for (int i = 0; i < count; ++i)
+      if (values[i] != 0.f) {
+        j->h_nonzero = true;
+        break;
+      }
+  }
+  return h2d(j, j->par[which], values, (size_t)count * sizeof(float));
+}
+int lc_joint_get_param(lc_joint *j, int which, float *values, int count) {
+  if (!j || which < 0 || which >= LC_P_COUNT || !values) return LC_ERR_INVALID;
+  if (count != j->psize[which]) LC_FAIL(j->ctx, LC_ERR_INVALID, "lc_joint_get_param: wrong element count");
+  return d2h(j, values, j->par[which], (size_t)count * sizeof(float));
+}
+int lc_joint_set_free(lc_joint *j, const int32_t *free_mask) {
+  if (!j || !free_mask) return LC_ERR_INVALID;
+  if (free_mask[LC_P_ALPHA]) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "alpha is never optimised (roi_modelling.py:221-222)");
+  for (int k = 0; k < LC_P_COUNT; ++k) j->free_mask[k] = free_mask[k] ? 1 : 0;
+  // a new optimisation starts: reset the moments and the iteration counter
+  for (int k = 0; k < LC_P_COUNT; ++k) {
+    LC_HIP(j->ctx, hipMemsetAsync(j->pm[k], 0, (size_t)std::max(j->psize[k], 1) * sizeof(float), j->ctx->stream));
+    LC_HIP(j->ctx, hipMemsetAsync(j->ps[k], 0, (size_t)std::max(j->psize[k], 1) * sizeof(float), j->ctx->stream));
+  }
+  j->iters_done = 0;
+  return LC_OK;
+}
+int lc_joint_set_loss(lc_joint *j, const lc_joint_loss_cfg *cfg, const float *W) {
+  if (!j || !cfg) return LC_ERR_INVALID;
+  if (cfg->lam_pts_source != 0.f) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "regularization_strength_pts_source is not built yet");
+  j->cfg = *cfg;
+  j->n_prior = 0;
+  if (cfg->n_prior > 0) {
+    if (!cfg->prior_cx_mean || !cfg->prior_cx_sigma || !cfg->prior_cy_mean || !cfg->prior_cy_sigma || cfg->n_prior != j->M)
+      LC_FAIL(j->ctx, LC_ERR_INVALID, "prior arrays must have M entries");
+    std::vector<float> p(4 * j->M);
+    for (int i = 0; i < j->M; ++i) {
+      p[i] = cfg->prior_cx_mean[i];
+      p[j->M + i] = cfg->prior_cx_sigma[i];
+      p[2 * j->M + i] = cfg->prior_cy_mean[i];
+      p[3 * j->M + i] = cfg->prior_cy_sigma[i];
+    }
+    int rc = h2d(j, j->prior, p.data(), p.size() * sizeof(float));
+    if (rc) return rc;
+    j->n_prior = j->M;
+  }
+  j->cfg.prior_cx_mean = j->cfg.prior_cx_sigma = j->cfg.prior_cy_mean = j->cfg.prior_cy_sigma = nullptr;
+  if (W) {
+    int rc = h2d(j, j->W, W, (size_t)j->J * j->N * j->N * sizeof(float));
+    if (rc) return rc;
+    j->have_W = true;
+  } else {
+    j->have_W = false;
+  }
+  return LC_OK;
+}
+
+int lc_joint_propagate_noise(lc_joint *j, float *W_out) {
+  if (!j) return LC_ERR_INVALID;
+  const int N = j->N, L = j->L, n = j->n, ss = j->ss, E = j->E, c = (N - 1) / 2;
+  const size_t NN = (size_t)N * N, nn = (size_t)n * n;
+  // V = sum_e adj[x -> conv_same(x, s_e^2)](up(1/sigma_e^2)), accumulated in Fourier space (host, one-time)
+  std::vector<cd> acc((size_t)L * L, cd(0, 0)), r((size_t)L * L), s2((size_t)L * L);
+  for (int e = 0; e < E; ++e) {
+    std::fill(r.begin(), r.end(), cd(0, 0));
+    std::fill(s2.begin(), s2.end(), cd(0, 0));
+    for (int u = 0; u < N; ++u)
+      for (int v = 0; v < N; ++v) {
+        const float sg = j->h_sigma2[(size_t)e * nn + (size_t)(u / ss) * n + v / ss];
+        const double w = (std::isfinite(sg) && sg > 0.f) ? 1.0 / sg : 0.0;
+        r[(size_t)(u + c) * L + (v + c)] = w;
+        const double p = j->h_psf[(size_t)e * NN + (size_t)u * N + v];
+        s2[(size_t)u * L + v] = p * p;
+      }
+    fft2d(r, L, c, N, false);
+    fft2d(s2, L, 0, N, false);
+    for (size_t i = 0; i < acc.size(); ++i) acc[i] += r[i] * std::conj(s2[i]);
+  }
+  fft2d(acc, L, 0, L, true);
+  std::vector<float> V(NN);
+  const double sc = 1.0 / ((double)L * L);
+  for (int u = 0; u < N; ++u)
+    for (int v = 0; v < N; ++v) V[(size_t)u * N + v] = (float)std::max(acc[(size_t)u * L + v].real() * sc, 0.0);
+  int rc = h2d(j, j->V, V.data(), NN * sizeof(float));
+  if (rc) return rc;
+  hipLaunchKernelGGL(starlet_noise_w_kernel, dim3(1, j->J + 1), dim3(256), 0, j->ctx->stream, N, j->J + 1, j->V, j->atoms,
+                     j->W, j->qscr);
+  LC_HIP(j->ctx, hipGetLastError());
+  j->have_W = true;
+  if (W_out) return d2h(j, W_out, j->W, (size_t)(j->J + 1) * NN * sizeof(float));
+  return LC_OK;
+}
+
+int lc_joint_step_local(lc_joint *j) {
+  if (!j) return LC_ERR_INVALID;
+  int need = launch_epochs(j, 0, 0, false, nullptr);
+  if (need < 0) return need;
+  return launch_reduce(j, need);
+}
+int lc_joint_shared_buffer_dev(lc_joint *j, void **dev_ptr, int *count) {
+  if (!j || !dev_ptr || !count) return LC_ERR_INVALID;
+  *dev_ptr = j->shared;
+  *count = j->shared_count;
+  return LC_OK;
+}
+int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
+  if (!j) return LC_ERR_INVALID;
+  int rc = ensure_hist(j, j->iters_done + 2);
+  if (rc) return rc;
+  rc = launch_update(j, 1, j->iters_done, cfg, true, false);
+  if (rc) return rc;
+  j->iters_done += 1;
+  return LC_OK;
+}
+
+int lc_joint_loss_grad(lc_joint *j, float *loss, float *const grads[LC_P_COUNT]) {
+  if (!j) return LC_ERR_INVALID;
+  const bool want_h = grads && grads[LC_P_H];
+  int need = launch_epochs(j, 0, 0, want_h, nullptr);
+  if (need < 0) return need;
+  int rc = launch_reduce(j, need);
+  if (rc) return rc;
+  rc = launch_update(j, 0, 0, nullptr, false, true);
+  if (rc) return rc;
+  if (loss && (rc = d2h(j, loss, j->out_loss, sizeof(float)))) return rc;
+  if (grads)
+    for (int k = 0; k < LC_P_COUNT; ++k)
+      if (grads[k] && k != LC_P_ALPHA && (rc = d2h(j, grads[k], j->gout[k], (size_t)j->psize[k] * sizeof(float)))) return rc;
+  LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+  return LC_OK;
+}
+
+int lc_joint_model(lc_joint *j, float *model, float *chi2_per_epoch) {
+  if (!j) return LC_ERR_INVALID;
+  int rc = launch_epochs(j, 1, 0, false, j->model);
+  if (rc < 0) return rc;
+  if (model && (rc = d2h(j, model, j->model, (size_t)j->E * j->n * j->n * sizeof(float)))) return rc;
+  if (chi2_per_epoch && (rc = d2h(j, chi2_per_epoch, j->chi2_e, (size_t)j->E * sizeof(float)))) return rc;
+  LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+  return LC_OK;
+}
+
+int lc_joint_deconvolved(lc_joint *j, int epoch, float *scene, float *background) {
+  if (!j || epoch < 0 || epoch >= j->E) return LC_ERR_INVALID;
+  const size_t NN = (size_t)j->N * j->N;
+  hipLaunchKernelGGL(joint_scene_kernel, dim3(64), dim3(256), 0, j->ctx->stream, j->N, j->ss, j->M, epoch, j->par[LC_P_A],
+                     j->par[LC_P_CX], j->par[LC_P_CY], j->par[LC_P_DX], j->par[LC_P_DY], j->par[LC_P_ALPHA],
+                     j->par[LC_P_H], j->scene2, j->scene2 + NN);
+  LC_HIP(j->ctx, hipGetLastError());
+  int rc;
+  if (scene && (rc = d2h(j, scene, j->scene2, NN * sizeof(float)))) return rc;
+  if (background && (rc = d2h(j, background, j->scene2 + NN, NN * sizeof(float)))) return rc;
+  return LC_OK;
+}
+
+int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg) {
+  if (!j || n_iter <= 0) return LC_ERR_INVALID;
+  int rc = ensure_hist(j, j->iters_done + n_iter + 2);
+  if (rc) return rc;
+  for (int it = 0; it < n_iter; ++it) {
+    if ((rc = lc_joint_step_local(j))) return rc;
+    if ((rc = lc_joint_step_update(j, cfg))) return rc;
+  }
+  return LC_OK;
+}
+int lc_joint_iterations_done(lc_joint *j) { return j ? j->iters_done : LC_ERR_INVALID; }
+
+int lc_joint_get_loss_history(lc_joint *j, float *history, int count) {
+  if (!j || !history || count < j->iters_done + 1) return LC_ERR_INVALID;
+  int rc = ensure_hist(j, j->iters_done + 2);
+  if (rc) return rc;
+  int need = launch_epochs(j, 0, 0, false, nullptr);  // loss of the final parameters -> hist[T]
+  if (need < 0) return need;
+  if ((rc = launch_reduce(j, need))) return rc;
+  if ((rc = launch_update(j, 0, j->iters_done, nullptr, true, false))) return rc;
+  return d2h(j, history, j->hist, (size_t)(j->iters_done + 1) * sizeof(float));
+}
+
+int lc_joint_fisher_flux_sigma(lc_joint *j, float *sigma_a) {
+  if (!j || !sigma_a) return LC_ERR_INVALID;
+  for (int i = 0; i < j->M; ++i) {
+    int rc = launch_epochs(j, 2, i, false, nullptr);
+    if (rc < 0) return rc;
+  }
+  return d2h(j, sigma_a, j->fisher, (size_t)j->E * j->M * sizeof(float));
+}
+
+}  // extern "C"

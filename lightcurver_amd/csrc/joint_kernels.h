@@ -1,0 +1,608 @@
+// Joint multi-epoch forward model (STARRED "Deconv") device code, gfx950.
+//
+// Replaces Deconv.model / Loss / autodiff gradient as called from
+// lightcurver/processes/star_photometry.py:66-137 and roi_modelling.py:213-334 (reference):
+//   f_e = D_ss[ s_e (*) ( T_e[h] + sum_i a_{e,i} G(R_e c_i + d_e) ) ] + mean_e
+// Kernel 1 (one workgroup per epoch): scene build, zero-padded FFT convolution with the epoch's
+//   narrow PSF (spectrum precomputed), down-sampling, residuals, chi2, adjoint convolution, and
+//   the analytic gradients w.r.t. a, c, dx, dy, mean plus T_e^T of the scene gradient (h slab).
+// Kernel 2: deterministic reduction over epochs into the shared block [dh | dc_x | dc_y | ...].
+// Kernel 3 (one workgroup): starlet l1 / positivity / flux terms, loss, fused AdaBelief update.
+#pragma once
+#include "fft_device.h"
+#include "starlet_device.h"
+
+namespace lc {
+
+constexpr int kMaxSources = 8;
+
+struct JointArgs {
+  int E, M, mode, isrc;       // mode 0 = forward + backward, 1 = forward only, 2 = Fisher diagonal of source isrc
+  int h_active, need_hgrad;   // h present in the scene; produce T^T slabs
+  const float *data, *wgt;    // [E][n][n], wgt = 1 / sigma^2 (0 where invalid)
+  const float2 *St;           // [E][L/2+1][L] PSF spectrum / L^2, transposed
+  const float2 *twid;         // [L/2]
+  const float *a, *cx, *cy, *dx, *dy, *alpha, *h, *mean;
+  float *tabs;                // [E][4][M][N] gx, dgx, gy, dgy scratch
+  float *GS;                  // [E][N*N] scene-gradient scratch
+  float *HG;                  // [E][N*N] T_e^T (scene gradient)
+  float *chi2_e, *g_a, *g_cx_e, *g_cy_e, *g_dx, *g_dy, *g_mean;
+  float *model_out;           // [E][n][n] or null
+  float *fisher_out;          // [E][M]
+};
+
+__device__ __forceinline__ void sample_coords(int u, int v, float c0, float ca, float sa, float sdx, float sdy,
+                                              float &Xs, float &Ys) {
+  const float qx = ((float)v - c0) - sdx;
+  const float qy = ((float)u - c0) - sdy;
+  Xs = c0 + (ca * qx + sa * qy);
+  Ys = c0 + (ca * qy - sa * qx);
+}
+
+template <int N>
+__device__ __forceinline__ float bilinear_h(const float *h, float Xs, float Ys, float &dHx, float &dHy) {
+  const float x0f = floorf(Xs), y0f = floorf(Ys);
+  const float fx = Xs - x0f, fy = Ys - y0f;
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const int xa = min(max(x0, 0), N - 1), xb = min(max(x0 + 1, 0), N - 1);
+  const int ya = min(max(y0, 0), N - 1), yb = min(max(y0 + 1, 0), N - 1);
+  const float h00 = h[ya * N + xa], h01 = h[ya * N + xb], h10 = h[yb * N + xa], h11 = h[yb * N + xb];
+  const float top = h00 + fx * (h01 - h00), bot = h10 + fx * (h11 - h10);
+  dHx = (1.f - fy) * (h01 - h00) + fy * (h11 - h10);
+  dHy = bot - top;
+  return top + fy * (bot - top);
+}
+
+template <int N_, int SS_, int L_>
+struct JointCfg {
+  static constexpr int N = N_, SS = SS_, L = L_, n = N / SS;
+  static constexpr int NTHR = 256, NW = 4;
+  static constexpr int KH = L / 2 + 1;           // stored spectrum columns
+  static constexpr int OFF_SPEC = 0;             // float2 units
+  static constexpr int SZ_SPEC = N * KH;
+  static constexpr int OFF_WS = OFF_SPEC + SZ_SPEC;
+  static constexpr int SZ_WS = NW * 2 * L;
+  static constexpr int OFF_TW = OFF_WS + SZ_WS;
+  static constexpr int SZ_TW = L / 2;
+  static constexpr int OFF_RED = OFF_TW + SZ_TW;  // float2 units; reduction scratch as floats
+  static constexpr int SZ_RED = NW * (4 + 3 * kMaxSources) / 2 + 8;
+  static constexpr int LDS_BYTES = (OFF_RED + SZ_RED) * 8;
+  static constexpr int CREF = (N - 1) / 2;
+  static_assert(N % 2 == 0, "row pairs");
+  static_assert(L >= 2 * N - 1 - CREF, "FFT length too short for an alias-free 'same' window");
+  static_assert(LDS_BYTES <= 163840, "LDS");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
+  constexpr int N = C::N, SS = C::SS, L = C::L, n = C::n, KH = C::KH, CREF = C::CREF;
+  extern __shared__ __align__(16) float2 lds2[];
+  float2 *SPEC = lds2 + C::OFF_SPEC;
+  float2 *TW = lds2 + C::OFF_TW;
+  float *RED = (float *)(lds2 + C::OFF_RED);
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float2 *wsA = lds2 + C::OFF_WS + wid * 2 * L, *wsB = wsA + L;
+  const int M = A.M;
+  const float c0 = (N - 1) * 0.5f;
+  const float al = A.alpha[e] * 0.017453292519943295f;
+  const float ca = cosf(al), sa = sinf(al);
+  const float dxe = A.dx[e], dye = A.dy[e];
+  const float sdx = SS * dxe, sdy = SS * dye;
+  const float meane = A.mean[e];
+  float *tab = A.tabs + (size_t)e * 4 * M * N;
+
+  for (int k = tid; k < L / 2; k += C::NTHR) TW[k] = A.twid[k];
+  // separable Gaussian factors of every point source (full grid, as the oracle evaluates them)
+  {
+    const float inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm = 0.3989422804014327f / kSigmaG;
+    for (int idx = tid; idx < M * N; idx += C::NTHR) {
+      const int i = idx / N, p = idx % N;
+      const float X = c0 + SS * (ca * A.cx[i] - sa * A.cy[i] + dxe);
+      const float Y = c0 + SS * (sa * A.cx[i] + ca * A.cy[i] + dye);
+      const float tx = (float)p - X, ty = (float)p - Y;
+      const float gx = nrm * expf(-0.5f * tx * tx * inv_s2), gy = nrm * expf(-0.5f * ty * ty * inv_s2);
+      tab[(0 * M + i) * N + p] = gx;
+      tab[(1 * M + i) * N + p] = gx * tx * inv_s2;
+      tab[(2 * M + i) * N + p] = gy;
+      tab[(3 * M + i) * N + p] = gy * ty * inv_s2;
+    }
+  }
+  __syncthreads();
+  float amp[kMaxSources];
+#pragma unroll
+  for (int i = 0; i < kMaxSources; ++i) amp[i] = (i < M) ? ((A.mode == 2) ? ((i == A.isrc) ? 1.f : 0.f) : A.a[e * M + i]) : 0.f;
+  const bool use_h = A.h_active && A.mode != 2;
+
+  // ---- phase A: scene rows, two real rows per complex FFT ---------------------------------------
+  for (int rp = wid; rp < N / 2; rp += C::NW) {
+    const int u0 = 2 * rp;
+    for (int v = lane; v < L; v += 64) {
+      float2 z = make_float2(0.f, 0.f);
+      if (v < N) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int i = 0; i < M; ++i) {
+          const float gx = tab[(0 * M + i) * N + v];
+          s0 = fmaf(amp[i] * tab[(2 * M + i) * N + u0], gx, s0);
+          s1 = fmaf(amp[i] * tab[(2 * M + i) * N + u0 + 1], gx, s1);
+        }
+        if (use_h) {
+          float Xs, Ys, t0, t1;
+          sample_coords(u0, v, c0, ca, sa, sdx, sdy, Xs, Ys);
+          s0 += bilinear_h<N>(A.h, Xs, Ys, t0, t1);
+          sample_coords(u0 + 1, v, c0, ca, sa, sdx, sdy, Xs, Ys);
+          s1 += bilinear_h<N>(A.h, Xs, Ys, t0, t1);
+        }
+        z = make_float2(s0, s1);
+      }
+      wsA[v] = z;
+    }
+    float2 *Z = wave_fft<L, false>(wsA, wsB, TW, lane);
+    for (int k = lane; k < KH; k += 64) {
+      const float2 zk = Z[k], zc = Z[(L - k) & (L - 1)];
+      SPEC[u0 * KH + k] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+      SPEC[(u0 + 1) * KH + k] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+    }
+    wave_lds_sync();
+  }
+  __syncthreads();
+  // ---- phase B: columns: FFT, multiply by the PSF spectrum, inverse FFT, keep the 'same' window ----
+  const float2 *Ste = A.St + (size_t)e * KH * L;
+  for (int k = wid; k < KH; k += C::NW) {
+    for (int r = lane; r < L; r += 64) wsA[r] = (r < N) ? SPEC[r * KH + k] : make_float2(0.f, 0.f);
+    float2 *Z = wave_fft<L, false>(wsA, wsB, TW, lane);
+    float2 *O = (Z == wsA) ? wsB : wsA;
+    for (int r = lane; r < L; r += 64) Z[r] = cmul(Z[r], Ste[(size_t)k * L + r]);
+    float2 *Y = wave_fft<L, true>(Z, O, TW, lane);
+    for (int r = lane; r < N; r += 64) SPEC[r * KH + k] = Y[r + CREF];
+    wave_lds_sync();
+  }
+  __syncthreads();
+  // ---- phase C: inverse rows -> model, residuals; forward rows of the up-sampled weighted residual ----
+  float acc_chi = 0.f, acc_mean = 0.f, acc_fis = 0.f;
+  const float *de = A.data + (size_t)e * n * n, *we = A.wgt + (size_t)e * n * n;
+  for (int rp = wid; rp < N / 2; rp += C::NW) {
+    const int u0 = 2 * rp;
+    for (int k = lane; k < L; k += 64) {
+      float2 z;
+      if (k <= L / 2) {
+        const float2 x1 = SPEC[u0 * KH + k], x2 = SPEC[(u0 + 1) * KH + k];
+        z = make_float2(x1.x - x2.y, x1.y + x2.x);
+      } else {
+        const float2 x1 = SPEC[u0 * KH + (L - k)], x2 = SPEC[(u0 + 1) * KH + (L - k)];
+        z = make_float2(x1.x + x2.y, x2.x - x1.y);
+      }
+      wsA[k] = z;
+    }
+    float2 *Y = wave_fft<L, true>(wsA, wsB, TW, lane);
+    float2 *O = (Y == wsA) ? wsB : wsA;
+    // model, residual; O receives the adjoint input rows (offset by CREF), zero elsewhere
+    for (int v = lane; v < L; v += 64) O[v] = make_float2(0.f, 0.f);
+    wave_lds_sync();
+    if (SS == 2) {
+      const int I = rp;
+      for (int jd = lane; jd < n; jd += 64) {
+        const float2 y0 = Y[2 * jd + CREF], y1 = Y[2 * jd + 1 + CREF];
+        const float conv = (y0.x + y1.x) + (y0.y + y1.y);
+        const float model = conv + meane;
+        const float w = we[I * n + jd];
+        if (A.mode == 2) {
+          acc_fis = fmaf(w * conv, conv, acc_fis);
+        } else {
+          const float res = model - de[I * n + jd];
+          const float rw = w * res;
+          acc_chi = fmaf(rw, res, acc_chi);
+          acc_mean += rw;
+          if (A.model_out) A.model_out[(size_t)e * n * n + I * n + jd] = model;
+          O[2 * jd + CREF] = make_float2(rw, rw);
+          O[2 * jd + 1 + CREF] = make_float2(rw, rw);
+        }
+      }
+    } else {
+      for (int v = lane; v < n; v += 64) {
+        const float2 y = Y[v + CREF];
+        const float w0 = we[u0 * n + v], w1 = we[(u0 + 1) * n + v];
+        if (A.mode == 2) {
+          acc_fis = fmaf(w0 * y.x, y.x, acc_fis);
+          acc_fis = fmaf(w1 * y.y, y.y, acc_fis);
+        } else {
+          const float m0 = y.x + meane, m1 = y.y + meane;
+          const float r0 = m0 - de[u0 * n + v], r1 = m1 - de[(u0 + 1) * n + v];
+          const float rw0 = w0 * r0, rw1 = w1 * r1;
+          acc_chi = fmaf(rw0, r0, acc_chi);
+          acc_chi = fmaf(rw1, r1, acc_chi);
+          acc_mean += rw0 + rw1;
+          if (A.model_out) {
+            A.model_out[(size_t)e * n * n + u0 * n + v] = m0;
+            A.model_out[(size_t)e * n * n + (u0 + 1) * n + v] = m1;
+          }
+          O[v + CREF] = make_float2(rw0, rw1);
+        }
+      }
+    }
+    if (A.mode == 0) {
+      float2 *Z = wave_fft<L, false>(O, Y, TW, lane);
+      for (int k = lane; k < KH; k += 64) {
+        const float2 zk = Z[k], zc = Z[(L - k) & (L - 1)];
+        SPEC[u0 * KH + k] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+        SPEC[(u0 + 1) * KH + k] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+      }
+    }
+    wave_lds_sync();
+  }
+  if (A.mode != 0) {
+    const float v0 = wave_sum((A.mode == 2) ? acc_fis : acc_chi);
+    if (lane == 0) RED[wid] = v0;
+    __syncthreads();
+    if (tid == 0) {
+      const float s = (RED[0] + RED[1]) + (RED[2] + RED[3]);
+      if (A.mode == 2) A.fisher_out[e * M + A.isrc] = 1.0f / sqrtf(s);
+      else A.chi2_e[e] = s;
+    }
+    return;
+  }
+  __syncthreads();
+  // ---- phase B': adjoint columns (rows sit at offset CREF), multiply by conj(spectrum) ------------
+  for (int k = wid; k < KH; k += C::NW) {
+    for (int r = lane; r < L; r += 64) {
+      const int rr = r - CREF;
+      wsA[r] = (rr >= 0 && rr < N) ? SPEC[rr * KH + k] : make_float2(0.f, 0.f);
+    }
+    float2 *Z = wave_fft<L, false>(wsA, wsB, TW, lane);
+    float2 *O = (Z == wsA) ? wsB : wsA;
+    for (int r = lane; r < L; r += 64) Z[r] = cmul_conj(Z[r], Ste[(size_t)k * L + r]);
+    float2 *Y = wave_fft<L, true>(Z, O, TW, lane);
+    for (int r = lane; r < N; r += 64) SPEC[r * KH + k] = Y[r];
+    wave_lds_sync();
+  }
+  __syncthreads();
+  // ---- phase C': adjoint inverse rows -> scene gradient rows; parameter gradients ------------------
+  float pa[kMaxSources], pX[kMaxSources], pY[kMaxSources];
+#pragma unroll
+  for (int i = 0; i < kMaxSources; ++i) pa[i] = pX[i] = pY[i] = 0.f;
+  float acc_dx = 0.f, acc_dy = 0.f;
+  float *GSe = A.GS + (size_t)e * N * N;
+  for (int rp = wid; rp < N / 2; rp += C::NW) {
+    const int u0 = 2 * rp;
+    for (int k = lane; k < L; k += 64) {
+      float2 z;
+      if (k <= L / 2) {
+        const float2 x1 = SPEC[u0 * KH + k], x2 = SPEC[(u0 + 1) * KH + k];
+        z = make_float2(x1.x - x2.y, x1.y + x2.x);
+      } else {
+        const float2 x1 = SPEC[u0 * KH + (L - k)], x2 = SPEC[(u0 + 1) * KH + (L - k)];
+        z = make_float2(x1.x + x2.y, x2.x - x1.y);
+      }
+      wsA[k] = z;
+    }
+    float2 *Y = wave_fft<L, true>(wsA, wsB, TW, lane);
+    for (int v = lane; v < N; v += 64) {
+      const float2 g = Y[v];
+#pragma unroll
+      for (int i = 0; i < kMaxSources; ++i) {
+        if (i < M) {
+          const float gx = tab[(0 * M + i) * N + v], dgx = tab[(1 * M + i) * N + v];
+          const float gy0 = tab[(2 * M + i) * N + u0], gy1 = tab[(2 * M + i) * N + u0 + 1];
+          const float dgy0 = tab[(3 * M + i) * N + u0], dgy1 = tab[(3 * M + i) * N + u0 + 1];
+          const float gg = g.x * gy0 + g.y * gy1;
+          pa[i] = fmaf(gg, gx, pa[i]);
+          pX[i] = fmaf(gg, dgx, pX[i]);
+          pY[i] = fmaf(g.x * dgy0 + g.y * dgy1, gx, pY[i]);
+        }
+      }
+      if (use_h) {
+        float Xs, Ys, hx, hy;
+        sample_coords(u0, v, c0, ca, sa, sdx, sdy, Xs, Ys);
+        bilinear_h<N>(A.h, Xs, Ys, hx, hy);
+        acc_dx = fmaf(g.x, SS * (sa * hy - ca * hx), acc_dx);
+        acc_dy = fmaf(g.x, -SS * (sa * hx + ca * hy), acc_dy);
+        sample_coords(u0 + 1, v, c0, ca, sa, sdx, sdy, Xs, Ys);
+        bilinear_h<N>(A.h, Xs, Ys, hx, hy);
+        acc_dx = fmaf(g.y, SS * (sa * hy - ca * hx), acc_dx);
+        acc_dy = fmaf(g.y, -SS * (sa * hx + ca * hy), acc_dy);
+        if (A.need_hgrad) {
+          GSe[u0 * N + v] = g.x;
+          GSe[(u0 + 1) * N + v] = g.y;
+        }
+      }
+    }
+    wave_lds_sync();
+  }
+  // reductions: lanes by shuffles, the four waves in fixed order
+  {
+    constexpr int NQ = 4 + 3 * kMaxSources;
+    float vals[NQ];
+    vals[0] = acc_chi;
+    vals[1] = acc_mean;
+    vals[2] = acc_dx;
+    vals[3] = acc_dy;
+#pragma unroll
+    for (int i = 0; i < kMaxSources; ++i) {
+      vals[4 + 3 * i] = pa[i];
+      vals[5 + 3 * i] = pX[i];
+      vals[6 + 3 * i] = pY[i];
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float s = wave_sum(vals[q]);
+      if (lane == 0) RED[wid * NQ + q] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float t[NQ];
+      for (int q = 0; q < NQ; ++q) t[q] = (RED[q] + RED[NQ + q]) + (RED[2 * NQ + q] + RED[3 * NQ + q]);
+      A.chi2_e[e] = t[0];
+      A.g_mean[e] = t[1];
+      float gdx = t[2], gdy = t[3];
+      for (int i = 0; i < M; ++i) {
+        const float ai = A.a[e * M + i];
+        const float gX = ai * t[5 + 3 * i], gY = ai * t[6 + 3 * i];
+        A.g_a[e * M + i] = t[4 + 3 * i];
+        gdx += SS * gX;
+        gdy += SS * gY;
+        A.g_cx_e[e * M + i] = SS * (ca * gX + sa * gY);
+        A.g_cy_e[e * M + i] = SS * (ca * gY - sa * gX);
+      }
+      A.g_dx[e] = gdx;
+      A.g_dy[e] = gdy;
+    }
+  }
+  // ---- phase D: T_e^T of the scene gradient by an exact, ordered gather -----------------------------
+  if (use_h && A.need_hgrad) {
+    __syncthreads();  // GS of this epoch complete and visible inside the workgroup
+    float *HGe = A.HG + (size_t)e * N * N;
+    const float asa = fabsf(sa);
+    const int band = (int)ceilf(fmaxf(fabsf(sdx), fabsf(sdy)) + N * asa) + 3;
+    const int mext = (int)ceilf(asa * (band + 2)) + 2;
+    for (int k = tid; k < N * N; k += C::NTHR) {
+      const int ky = k / N, kx = k % N;
+      const float rx = (float)kx - c0, ry = (float)ky - c0;
+      const float px = c0 + (ca * rx - sa * ry) + sdx, py = c0 + (sa * rx + ca * ry) + sdy;
+      int vlo = (int)floorf(px) - 1, vhi = vlo + 3, ulo = (int)floorf(py) - 1, uhi = ulo + 3;
+      if (kx == 0) { vlo = min(vlo, 0); ulo -= mext; uhi += mext; }
+      if (kx == N - 1) { vhi = max(vhi, N - 1); ulo -= mext; uhi += mext; }
+      if (ky == 0) { ulo = min(ulo, 0); vlo -= mext; vhi += mext; }
+      if (ky == N - 1) { uhi = max(uhi, N - 1); vlo -= mext; vhi += mext; }
+      if (kx == 0) vlo = 0;
+      if (kx == N - 1) vhi = N - 1;
+      if (ky == 0) ulo = 0;
+      if (ky == N - 1) uhi = N - 1;
+      vlo = max(vlo, 0);
+      vhi = min(vhi, N - 1);
+      ulo = max(ulo, 0);
+      uhi = min(uhi, N - 1);
+      float acc = 0.f;
+      for (int u = ulo; u <= uhi; ++u) {
+        for (int v = vlo; v <= vhi; ++v) {
+          float Xs, Ys;
+          sample_coords(u, v, c0, ca, sa, sdx, sdy, Xs, Ys);
+          const float x0f = floorf(Xs), y0f = floorf(Ys);
+          const float fx = Xs - x0f, fy = Ys - y0f;
+          const int x0 = (int)x0f, y0 = (int)y0f;
+          const int xa = min(max(x0, 0), N - 1), xb = min(max(x0 + 1, 0), N - 1);
+          const int ya = min(max(y0, 0), N - 1), yb = min(max(y0 + 1, 0), N - 1);
+          const float wx = ((xa == kx) ? (1.f - fx) : 0.f) + ((xb == kx) ? fx : 0.f);
+          const float wy = ((ya == ky) ? (1.f - fy) : 0.f) + ((yb == ky) ? fy : 0.f);
+          acc = fmaf(wx * wy, GSe[u * N + v], acc);
+        }
+      }
+      HGe[k] = acc;
+    }
+  }
+}
+
+// ---- kernel 2: ordered reduction over the epochs of this rank -------------------------------------
+// shared = [ dL/dh (N*N) | dL/dc_x (M) | dL/dc_y (M) | sum_e a (M) | sum_e a^2 (M) | chi2 | n_epochs ]
+__global__ void joint_reduce_kernel(int E, int M, int NN, int need_h, const float *HG, const float *g_cx_e,
+                                    const float *g_cy_e, const float *chi2_e, const float *a, float *shared) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < NN) {
+    float acc = 0.f;
+    if (need_h)
+      for (int e = 0; e < E; ++e) acc += HG[(size_t)e * NN + k];
+    shared[k] = acc;
+  } else if (k < NN + 4 * M) {
+    const int q = (k - NN) / M, i = (k - NN) % M;
+    double acc = 0.0;
+    for (int e = 0; e < E; ++e) {
+      const float ai = a[e * M + i];
+      acc += (q == 0) ? (double)g_cx_e[e * M + i] : (q == 1) ? (double)g_cy_e[e * M + i] : (q == 2) ? (double)ai : (double)ai * ai;
+    }
+    shared[k] = (float)acc;
+  } else if (k == NN + 4 * M) {
+    double acc = 0.0;
+    for (int e = 0; e < E; ++e) acc += chi2_e[e];
+    shared[k] = (float)acc;
+  } else if (k == NN + 4 * M + 1) {
+    shared[k] = (float)E;
+  }
+}
+
+// ---- kernel 3: regularisers, loss, AdaBelief -------------------------------------------------------
+struct JointUpdArgs {
+  int E, M, mode, t, hist_stride;  // mode 1 = update, 0 = gradients only
+  int free_mask[LC_P_COUNT];
+  const float *shared;             // reduced (and, multi-GPU, all-reduced) block
+  float *h, *mh, *sh;              // [N*N]
+  const float *W, *norms;          // [J][N*N] or null; [J]
+  float *qscr;                     // [J][N*N]
+  float *par[LC_P_COUNT], *pm[LC_P_COUNT], *ps[LC_P_COUNT];  // device parameter blocks and moments (P_H unused here)
+  const float *g_a, *g_dx, *g_dy, *g_mean;                    // per-epoch gradients of kernel 1
+  float *gout[LC_P_COUNT];         // gradient outputs (mode 0), nullable
+  float *hist, *out_loss;
+  float lam_sc, lam_hf, lam_pos, lam_pos_ps, lam_pts, lam_fu;
+  int n_prior;
+  const float *prior_cx_mean, *prior_cx_sigma, *prior_cy_mean, *prior_cy_sigma;
+  lc_adabelief_cfg ab;
+};
+
+__device__ __forceinline__ float adabelief_step(float &p, float &m, float &s, float g, float lr, float bc1, float bc2,
+                                                const lc_adabelief_cfg &ab) {
+  const float mn = ab.b1 * m + (1.f - ab.b1) * g;
+  const float dg = g - mn;
+  const float sn = ab.b2 * s + (1.f - ab.b2) * dg * dg + ab.eps_root;
+  m = mn;
+  s = sn;
+  p -= lr * (mn * bc1) / (sqrtf(sn * bc2) + ab.eps);
+  return p;
+}
+
+template <int N, int PX>
+__global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A) {
+  constexpr int NTHR = N * N / PX, NWV = (NTHR + 63) / 64, J = ilog2(N);
+  extern __shared__ __align__(16) float lds[];
+  __shared__ float red[NWV * 2 + 16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int pu = tid / (N / PX), pv = (tid % (N / PX)) * PX;
+  const size_t pix = (size_t)pu * N + pv;
+  const int E = A.E, M = A.M, NN = N * N;
+  const float Etot = A.shared[NN + 4 * M + 1];
+  const bool h_free = A.free_mask[LC_P_H] != 0;
+
+  float hp[PX], g[PX];
+#pragma unroll
+  for (int q = 0; q < PX / 4; ++q) {
+    const float4 v = *(const float4 *)(A.h + pix + 4 * q);
+    const float4 gs = *(const float4 *)(A.shared + pix + 4 * q);
+    hp[4 * q] = v.x; hp[4 * q + 1] = v.y; hp[4 * q + 2] = v.z; hp[4 * q + 3] = v.w;
+    g[4 * q] = gs.x; g[4 * q + 1] = gs.y; g[4 * q + 2] = gs.z; g[4 * q + 3] = gs.w;
+  }
+  float l1 = 0.f, pos = 0.f;
+  if (A.lam_sc != 0.f || A.lam_hf != 0.f) {
+    float z[PX];
+    starlet_l1_grad<N, PX>(hp, A.W, A.norms, A.qscr, A.lam_sc, A.lam_hf, lds, tid, l1, z);
+#pragma unroll
+    for (int p = 0; p < PX; ++p) g[p] += z[p];
+  }
+  if (A.lam_pos != 0.f) {
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      pos += (hp[p] < 0.f) ? -A.lam_pos * hp[p] : 0.f;
+      g[p] += (hp[p] < 0.f) ? -A.lam_pos : 0.f;
+    }
+  }
+  {
+    const float s1 = wave_sum(l1), s2 = wave_sum(pos);
+    if (lane == 0) {
+      red[wid * 2] = s1;
+      red[wid * 2 + 1] = s2;
+    }
+  }
+  __syncthreads();
+  // scalars: learning rate, bias corrections, flux statistics, loss
+  float *sc = red + NWV * 2;  // [0] lr [1] bc1 [2] bc2
+  if (tid == 0) {
+    const double t1 = (double)(A.t + 1);
+    double lr = A.ab.init_learning_rate;
+    if (A.ab.schedule_learning_rate) lr *= pow((double)A.ab.decay_rate, (double)A.t / (double)A.ab.transition_steps);
+    sc[0] = (float)lr;
+    sc[1] = (float)(1.0 / (1.0 - pow((double)A.ab.b1, t1)));
+    sc[2] = (float)(1.0 / (1.0 - pow((double)A.ab.b2, t1)));
+    float tl1 = 0.f, tpos = 0.f;
+    for (int w = 0; w < NWV; ++w) {
+      tl1 += red[w * 2];
+      tpos += red[w * 2 + 1];
+    }
+    double loss = 0.5 * (double)A.shared[NN + 4 * M] + tl1 + tpos;
+    // flux uniformity: lam * sum_i std_e(a_{e,i}) over ALL epochs of the fit
+    if (A.lam_fu != 0.f && Etot > 1.f)
+      for (int i = 0; i < M; ++i) {
+        const double mean = A.shared[NN + 2 * M + i] / Etot;
+        const double var = fmax((double)A.shared[NN + 3 * M + i] / Etot - mean * mean, 0.0);
+        loss += A.lam_fu * sqrt(var);
+      }
+    if (A.n_prior > 0)
+      for (int i = 0; i < M; ++i) {
+        const double zx = (A.par[LC_P_CX][i] - A.prior_cx_mean[i]) / A.prior_cx_sigma[i];
+        const double zy = (A.par[LC_P_CY][i] - A.prior_cy_mean[i]) / A.prior_cy_sigma[i];
+        loss += 0.5 * (zx * zx + zy * zy);
+      }
+    sc[3] = (float)loss;  // positivity of the fluxes is added by the a-loop below through sc[4..]
+  }
+  __syncthreads();
+  const float lr = sc[0], bc1 = sc[1], bc2 = sc[2];
+  // ---- h ----
+  if (A.mode == 0 && A.gout[LC_P_H]) {
+#pragma unroll
+    for (int p = 0; p < PX; ++p) A.gout[LC_P_H][pix + p] = g[p];
+  }
+  if (A.mode == 1 && h_free) {
+#pragma unroll
+    for (int q = 0; q < PX / 4; ++q) {
+      float4 m = *(float4 *)(A.mh + pix + 4 * q), s = *(float4 *)(A.sh + pix + 4 * q);
+      float *mm = &m.x, *ss_ = &s.x;
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) adabelief_step(hp[4 * q + e4], mm[e4], ss_[e4], g[4 * q + e4], lr, bc1, bc2, A.ab);
+      *(float4 *)(A.h + pix + 4 * q) = make_float4(hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]);
+      *(float4 *)(A.mh + pix + 4 * q) = m;
+      *(float4 *)(A.sh + pix + 4 * q) = s;
+    }
+  }
+  // ---- per-epoch parameters: a (E*M), dx, dy, mean (E) ----
+  float pos_ps = 0.f;
+  for (int idx = tid; idx < E * M; idx += NTHR) {
+    const int i = idx % M;
+    float av = A.par[LC_P_A][idx];
+    float ga = A.g_a[idx];
+    if (A.lam_pos_ps != 0.f && av < 0.f) {
+      pos_ps += -A.lam_pos_ps * av;
+      ga -= A.lam_pos_ps;
+    }
+    if (A.lam_fu != 0.f && Etot > 1.f) {
+      const float mean = A.shared[NN + 2 * M + i] / Etot;
+      const float var = fmaxf(A.shared[NN + 3 * M + i] / Etot - mean * mean, 0.f);
+      const float sd = sqrtf(var);
+      if (sd > 0.f) ga += A.lam_fu * (av - mean) / (Etot * sd);
+    }
+    if (A.mode == 0) {
+      if (A.gout[LC_P_A]) A.gout[LC_P_A][idx] = ga;
+    } else if (A.free_mask[LC_P_A]) {
+      adabelief_step(av, A.pm[LC_P_A][idx], A.ps[LC_P_A][idx], ga, lr, bc1, bc2, A.ab);
+      A.par[LC_P_A][idx] = av;
+    }
+  }
+  for (int idx = tid; idx < 3 * E; idx += NTHR) {
+    const int which = (idx / E == 0) ? LC_P_DX : (idx / E == 1) ? LC_P_DY : LC_P_MEAN;
+    const int e = idx % E;
+    const float gv = (which == LC_P_DX) ? A.g_dx[e] : (which == LC_P_DY) ? A.g_dy[e] : A.g_mean[e];
+    if (A.mode == 0) {
+      if (A.gout[which]) A.gout[which][e] = gv;
+    } else if (A.free_mask[which]) {
+      float pv_ = A.par[which][e];
+      adabelief_step(pv_, A.pm[which][e], A.ps[which][e], gv, lr, bc1, bc2, A.ab);
+      A.par[which][e] = pv_;
+    }
+  }
+  // ---- shared point-source positions ----
+  if (tid < 2 * M) {
+    const int which = (tid < M) ? LC_P_CX : LC_P_CY, i = tid % M;
+    float gv = A.shared[NN + (which == LC_P_CX ? 0 : M) + i];
+    float cv = A.par[which][i];
+    if (A.n_prior > 0) {
+      const float mu = (which == LC_P_CX) ? A.prior_cx_mean[i] : A.prior_cy_mean[i];
+      const float sg = (which == LC_P_CX) ? A.prior_cx_sigma[i] : A.prior_cy_sigma[i];
+      gv += (cv - mu) / (sg * sg);
+    }
+    if (A.mode == 0) {
+      if (A.gout[which]) A.gout[which][i] = gv;
+    } else if (A.free_mask[which]) {
+      adabelief_step(cv, A.pm[which][i], A.ps[which][i], gv, lr, bc1, bc2, A.ab);
+      A.par[which][i] = cv;
+    }
+  }
+  // ---- loss (positivity of fluxes reduced here) ----
+  {
+    const float s = wave_sum(pos_ps);
+    __syncthreads();
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    if (tid == 0) {
+      float tp = 0.f;
+      for (int w = 0; w < NWV; ++w) tp += red[w];
+      const float loss = sc[3] + tp;
+      if (A.hist) A.hist[A.t] = loss;
+      if (A.out_loss) *A.out_loss = loss;
+    }
+  }
+}
+
+}  // namespace lc

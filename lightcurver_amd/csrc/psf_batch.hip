@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "lbfgs_host.h"
+#include "noise_kernels.h"
 #include "psf_kernels.h"
 
 using namespace lc;
@@ -203,58 +204,6 @@ __global__ void psf_noise_v_kernel(int S, int n, int ss, const float *wgt, const
   }
 }
 
-// W_j = sqrt( sum_{term} c_term * (k_term (x) k_term) (*) V ), 'same' with zero lag at (N-1)//2.
-// atoms: [J+1][3][N] 1-D factors; coefficients {+1, -2, +1}.  One block per (frame, scale).
-__global__ void psf_noise_w_kernel(int N, int J, const float *V, const float *atoms, float *W, float *tmp) {
-  const int f = blockIdx.x, j = blockIdx.y;
-  const int c = (N - 1) / 2;
-  const float *Vf = V + (size_t)f * N * N;
-  float *t = tmp + ((size_t)f * J + j) * N * N;
-  float *Wf = W + ((size_t)f * J + j) * N * N;
-  const float coef[3] = {1.f, -2.f, 1.f};
-  for (int i = threadIdx.x; i < N * N; i += blockDim.x) Wf[i] = 0.f;
-  for (int term = 0; term < 3; ++term) {
-    const float *k = atoms + ((size_t)j * 3 + term) * N;
-    __syncthreads();
-    for (int i = threadIdx.x; i < N * N; i += blockDim.x) {  // rows
-      const int u = i / N, v = i % N;
-      double acc = 0;
-      for (int vp = 0; vp < N; ++vp) {
-        const int kk = v - vp + c;
-        if (kk >= 0 && kk < N) acc += (double)Vf[u * N + vp] * k[kk];
-      }
-      t[i] = (float)acc;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < N * N; i += blockDim.x) {  // columns
-      const int u = i / N, v = i % N;
-      double acc = 0;
-      for (int upp = 0; upp < N; ++upp) {
-        const int kk = u - upp + c;
-        if (kk >= 0 && kk < N) acc += (double)t[upp * N + v] * k[kk];
-      }
-      Wf[i] += coef[term] * (float)acc;
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < N * N; i += blockDim.x) Wf[i] = sqrtf(fmaxf(Wf[i], 0.f));
-}
-
-// 1-D starlet cascade of a dirac at the zero-lag index with edge replication: p_j = A_j delta_c.
-void starlet_atoms_1d(int N, int J, std::vector<std::vector<double>> &p) {
-  const double b3[5] = {1. / 16, 4. / 16, 6. / 16, 4. / 16, 1. / 16};
-  p.assign(J + 1, std::vector<double>(N, 0.0));
-  p[0][(N - 1) / 2] = 1.0;
-  for (int j = 0; j < J; ++j) {
-    const int d = 1 << j;
-    for (int i = 0; i < N; ++i) {
-      double acc = 0;
-      for (int t = -2; t <= 2; ++t) acc += b3[t + 2] * p[j][std::min(std::max(i + t * d, 0), N - 1)];
-      p[j + 1][i] = acc;
-    }
-  }
-}
-
 typedef void (*psf_kernel_fn)(PsfArgs);
 struct PsfVariant {
   int n, ss;
@@ -420,23 +369,8 @@ int lc_psf_batch_create(lc_ctx *ctx, int F, int S_max, int n, int ss, const floa
   }
   // starlet scale norms and the separable factors of psi_j^2
   {
-    std::vector<std::vector<double>> p;
-    starlet_atoms_1d(b->N, b->J, p);
-    std::vector<float> norms(b->J + 1), atoms((size_t)(b->J + 1) * 3 * b->N, 0.f);
-    for (int j = 0; j <= b->J; ++j) {
-      // 2-D atom: psi_j = p_j (x) p_j - p_{j+1} (x) p_{j+1} (detail), coarse: p_J (x) p_J
-      double s_pp = 0, s_qq = 0, s_pq = 0;
-      for (int i = 0; i < b->N; ++i) {
-        const double pj = p[j][i], qj = (j < b->J) ? p[j + 1][i] : 0.0;
-        s_pp += pj * pj;
-        s_qq += qj * qj;
-        s_pq += pj * qj;
-        atoms[((size_t)j * 3 + 0) * b->N + i] = (float)(pj * pj);
-        atoms[((size_t)j * 3 + 1) * b->N + i] = (float)(pj * qj);
-        atoms[((size_t)j * 3 + 2) * b->N + i] = (float)(qj * qj);
-      }
-      norms[j] = (float)std::sqrt(std::max(s_pp * s_pp - 2.0 * s_pq * s_pq + s_qq * s_qq, 0.0));
-    }
+    std::vector<float> norms, atoms;
+    starlet_noise_tables(b->N, b->J, norms, atoms);
     TRY(h2d(b, b->norms, norms.data(), norms.size() * sizeof(float)));
     TRY(h2d(b, b->atoms, atoms.data(), atoms.size() * sizeof(float)));
   }
@@ -505,7 +439,7 @@ int lc_psf_batch_propagate_noise(lc_psf_batch *b) {
   hipLaunchKernelGGL(psf_noise_v_kernel, dim3(b->F), dim3(256), 0, b->ctx->stream, b->S, b->n, b->ss, b->wgt,
                      b->stars, b->V);
   // qscratch doubles as the row-pass temporary ([F][J][N*N])
-  hipLaunchKernelGGL(psf_noise_w_kernel, dim3(b->F, b->J), dim3(256), 0, b->ctx->stream, b->N, b->J, b->V, b->atoms,
+  hipLaunchKernelGGL(starlet_noise_w_kernel, dim3(b->F, b->J), dim3(256), 0, b->ctx->stream, b->N, b->J, b->V, b->atoms,
                      b->W, b->qscratch);
   LC_HIP(b->ctx, hipGetLastError());
   b->have_W = true;

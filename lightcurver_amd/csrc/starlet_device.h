@@ -1,0 +1,386 @@
+// Starlet l1 regulariser of an N x N image held PX-pixels-per-thread by one workgroup:
+//   value  lam_hf * sum W_0 |w_0| + lam_sc * sum_{1<=j<J} W_j |w_j|   (coarse scale unpenalised)
+//   and its sub-gradient through the exact adjoint of the edge-replicating a-trous transform.
+// Used by the PSF fit (on the pixel grid B) and by the joint fit (on the background h).
+// Restates STARRED's Loss(regularization_terms='l1_starlet') as frozen in DESIGN.md "SPEC"
+// (reference call sites: lightcurver/processes/star_photometry.py:95-111, roi_modelling.py:313-321).
+#pragma once
+#include <utility>
+
+#include "lc_common.h"
+
+namespace lc {
+
+#ifndef LC_LAUNDER
+#define LC_LAUNDER(x) asm volatile("" : "+v"(x))
+#endif
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// starred's first-generation starlet uses the B3 spline [1,4,6,4,1]/16.
+__device__ __forceinline__ float b3tap(int t) {  // t in [-2, 2]
+  return (t == 0) ? 0.375f : ((t == 1 || t == -1) ? 0.25f : 0.0625f);
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// Sum over the LPR (4, 8 or 16) consecutive lanes that own one image line, result in every lane.
+// xor-1 / xor-2 butterflies as quad permutes, then the half-row and row mirrors (DPP, no LDS).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  const int r = __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xF, 0xF, false);
+  return v + __builtin_bit_cast(float, r);
+}
+template <int LPR>
+__device__ __forceinline__ float line_sum(float v) {
+  v = dpp_add<0xB1>(v);  // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);  // quad_perm [2,3,0,1]
+  if constexpr (LPR >= 8) v = dpp_add<0x141>(v);   // row_half_mirror
+  if constexpr (LPR >= 16) v = dpp_add<0x140>(v);  // row_mirror
+  return v;
+}
+
+// Zero-filling DPP lane shifts inside one image line (LPR consecutive lanes, LPR | 16).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov0(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int K, int LPR>
+__device__ __forceinline__ float line_from_lower(float v, int lil) {  // value of lane - K of the same line, else 0
+  if constexpr (K >= LPR) {
+    return 0.f;
+  } else {
+    float r = dpp_mov0<0x110 + K>(v);  // row_shr:K
+    if constexpr (LPR < 16) r = (lil >= K) ? r : 0.f;
+    return r;
+  }
+}
+template <int K, int LPR>
+__device__ __forceinline__ float line_from_upper(float v, int lil) {  // value of lane + K of the same line, else 0
+  if constexpr (K >= LPR) {
+    return 0.f;
+  } else {
+    float r = dpp_mov0<0x100 + K>(v);  // row_shl:K
+    if constexpr (LPR < 16) r = (lil + K < LPR) ? r : 0.f;
+    return r;
+  }
+}
+
+// Adjoint of one edge-replicating 5-tap a-trous pass (dilation D) along a line of N samples:
+//   out[x] = sum_t b3[t] * sum_{x'': clamp(x'' + t D) = x} g[x'']
+// The calling thread holds samples x0 .. x0+PX-1 of the line in own[]; the LPR = N / PX threads of the
+// line are consecutive lanes (lil = lane index inside the line).  Interior samples gather g[x -/+ D],
+// g[x -/+ 2D] with zero outside the line: pure DPP lane shifts, no LDS.  The two end samples also collect
+// every sample that clamps onto them: masked partial sums reduced over the line's lanes by DPP.
+template <int N, int PX, int LPR, int D>
+__device__ __forceinline__ void adjoint_line_dpp(const float own[PX], int x0, int lil, float out[PX]) {
+  if constexpr (D < PX) {
+    float w[3 * PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      w[p] = line_from_lower<1, LPR>(own[p], lil);
+      w[PX + p] = own[p];
+      w[2 * PX + p] = line_from_upper<1, LPR>(own[p], lil);
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      float acc = 0.375f * own[p];
+      acc = fmaf(0.25f, w[PX + p - D] + w[PX + p + D], acc);
+      acc = fmaf(0.0625f, w[PX + p - 2 * D] + w[PX + p + 2 * D], acc);
+      out[p] = acc;
+    }
+  } else {
+    constexpr int K1 = D / PX, K2 = 2 * D / PX;
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      float acc = 0.375f * own[p];
+      acc = fmaf(0.25f, line_from_lower<K1, LPR>(own[p], lil) + line_from_upper<K1, LPR>(own[p], lil), acc);
+      acc = fmaf(0.0625f, line_from_lower<K2, LPR>(own[p], lil) + line_from_upper<K2, LPR>(own[p], lil), acc);
+      out[p] = acc;
+    }
+  }
+  float s1 = 0.f, s2 = 0.f, e1 = 0.f, e2 = 0.f;  // head sums x <= D, x <= 2D; tail sums x >= N-1-D, x >= N-1-2D
+#pragma unroll
+  for (int p = 0; p < PX; ++p) {
+    const int x = x0 + p;
+    s1 += (x <= D) ? own[p] : 0.f;
+    s2 += (x <= 2 * D) ? own[p] : 0.f;
+    e1 += (x >= N - 1 - D) ? own[p] : 0.f;
+    e2 += (x >= N - 1 - 2 * D) ? own[p] : 0.f;
+  }
+  s1 = line_sum<LPR>(s1);
+  s2 = line_sum<LPR>(s2);
+  e1 = line_sum<LPR>(e1);
+  e2 = line_sum<LPR>(e2);
+  if (x0 == 0) out[0] = 0.375f * own[0] + 0.25f * s1 + 0.0625f * s2;
+  if (x0 + PX == N) out[PX - 1] = 0.375f * own[PX - 1] + 0.25f * e1 + 0.0625f * e2;
+}
+
+// Same operator for line layouts DPP cannot serve (LPR not in {4, 8, 16}): gathers from LDS, serial edge sums.
+template <int N, int PX>
+__device__ __forceinline__ void adjoint_line_lds(const float *in, int base, int stride, int x0, int d, float out[PX]) {
+  float own[PX];
+#pragma unroll
+  for (int p = 0; p < PX; ++p) own[p] = in[base + (x0 + p) * stride];
+  float s1 = 0.f, s2 = 0.f, e1 = 0.f, e2 = 0.f;
+  if (x0 == 0) {
+    const int m1 = min(d, N - 1), m2 = min(2 * d, N - 1);
+    for (int x = 0; x <= m2; ++x) {
+      const float gv = in[base + x * stride];
+      if (x <= m1) s1 += gv;
+      s2 += gv;
+    }
+  }
+  if (x0 + PX == N) {
+    const int m1 = max(N - 1 - d, 0), m2 = max(N - 1 - 2 * d, 0);
+    for (int x = m2; x <= N - 1; ++x) {
+      const float gv = in[base + x * stride];
+      if (x >= m1) e1 += gv;
+      e2 += gv;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PX; ++p) {
+    const int x = x0 + p;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = -2; t <= 2; ++t) {
+      const int xx = x - t * d;
+      const int cx = min(max(xx, 0), N - 1);
+      const float gv = (t == 0) ? own[p] : in[base + cx * stride];
+      acc = fmaf(b3tap(t), (xx >= 0 && xx <= N - 1) ? gv : 0.f, acc);
+    }
+    if (x == 0) acc = 0.375f * own[p] + 0.25f * s1 + 0.0625f * s2;
+    if (x == N - 1) acc = 0.375f * own[p] + 0.25f * e1 + 0.0625f * e2;
+    out[p] = acc;
+  }
+}
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F &&f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+
+
+// LDS needed by starlet_l1_grad (floats): two ping-pong images at the 16-byte aligned row stride.
+template <int N>
+struct StarletLds {
+  static constexpr int TS = N + 1, TSS = N + 4;
+  static constexpr int FLOATS = 2 * N * TSS;
+};
+
+// img[PX]: the calling thread's pixels (row pu = tid / (N/PX), columns pv = (tid % (N/PX)) * PX ..).
+// Wf: [J][N*N] weights or null (then norms[j] is used); qscr: [J][N*N] thread-private scratch, only
+// touched when the sub-gradients do not fit in registers.  All N*N/PX threads of the block must call.
+// On return l1 holds this thread's share of the value and z[PX] the sub-gradient at its pixels.
+template <int N, int PX>
+__device__ __forceinline__ void starlet_l1_grad(const float img[PX], const float *Wf, const float *norms, float *qscr,
+                                                float lam_sc, float lam_hf, float *lds, int tid, float &l1,
+                                                float z[PX]) {
+  constexpr int J = ilog2(N);
+  constexpr int TS = StarletLds<N>::TS;
+  float *bufA = lds, *bufB = lds + N * TS;
+  const int pu = tid / (N / PX);
+  const int pv = (tid % (N / PX)) * PX;
+  l1 = 0.f;
+#pragma unroll
+  for (int p = 0; p < PX; ++p) z[p] = 0.f;
+  const int pu_ = pu, pv_ = pv;
+  constexpr bool QREG = (J * PX <= 32);  // sub-gradients stay in registers when they fit
+  constexpr int TSS = StarletLds<N>::TSS;  // 16-byte aligned rows for the forward sweep
+  float *fA = lds, *fB = lds + N * TSS;
+  float qreg[QREG ? J : 1][PX];
+  float c[PX];
+#pragma unroll
+  for (int q = 0; q < PX / 4; ++q) {
+    c[4 * q] = img[4 * q];
+    c[4 * q + 1] = img[4 * q + 1];
+    c[4 * q + 2] = img[4 * q + 2];
+    c[4 * q + 3] = img[4 * q + 3];
+    *(float4 *)&fA[pu * TSS + pv + 4 * q] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int d = 1 << j;
+    int pu = pu_, pv = pv_;
+    LC_LAUNDER(pu);
+    LC_LAUNDER(pv);
+    // weights of this scale: issued before the row pass so the latency hides behind it
+    float wj[PX];
+    if (Wf) {
+      const float4 *wp = (const float4 *)(Wf + (size_t)j * N * N + (size_t)pu * N + pv);
+#pragma unroll
+      for (int q = 0; q < PX / 4; ++q) {
+        const float4 w4 = wp[q];
+        wj[4 * q] = w4.x;
+        wj[4 * q + 1] = w4.y;
+        wj[4 * q + 2] = w4.z;
+        wj[4 * q + 3] = w4.w;
+      }
+    } else {
+      const float nv = norms[j];
+#pragma unroll
+      for (int p = 0; p < PX; ++p) wj[p] = nv;
+    }
+    // row pass: r = Row_j c (edge replicating), own samples from registers, neighbours by 128-bit reads
+    float r[PX];
+    const float *row = fA + pu * TSS;
+    if (d < 4) {
+      float w[PX + 8];
+      const float4 Lc = ld4(row + max(pv - 4, 0));
+      const float4 Rc = ld4(row + min(pv + PX, N - 4));
+      const bool hl = pv > 0, hr = pv + PX < N;
+      w[0] = hl ? Lc.x : c[0];
+      w[1] = hl ? Lc.y : c[0];
+      w[2] = hl ? Lc.z : c[0];
+      w[3] = hl ? Lc.w : c[0];
+#pragma unroll
+      for (int p = 0; p < PX; ++p) w[4 + p] = c[p];
+      w[PX + 4] = hr ? Rc.x : c[PX - 1];
+      w[PX + 5] = hr ? Rc.y : c[PX - 1];
+      w[PX + 6] = hr ? Rc.z : c[PX - 1];
+      w[PX + 7] = hr ? Rc.w : c[PX - 1];
+#pragma unroll
+      for (int p = 0; p < PX; ++p) {
+        float acc = 0.375f * w[4 + p];
+        acc = fmaf(0.25f, w[4 + p - d] + w[4 + p + d], acc);
+        acc = fmaf(0.0625f, w[4 + p - 2 * d] + w[4 + p + 2 * d], acc);
+        r[p] = acc;
+      }
+    } else {
+      const float e0 = row[0], eN = row[N - 1];
+#pragma unroll
+      for (int q = 0; q < PX / 4; ++q) {
+        float a4[4] = {0.375f * c[4 * q], 0.375f * c[4 * q + 1], 0.375f * c[4 * q + 2], 0.375f * c[4 * q + 3]};
+#pragma unroll
+        for (int t = -2; t <= 2; ++t) {
+          if (t == 0) continue;
+          const int idx = pv + 4 * q + t * d;
+          const float4 v4 = ld4(row + min(max(idx, 0), N - 4));
+          const float bt = b3tap(t);
+          const bool lo = idx < 0, hi = idx > N - 4;
+          a4[0] = fmaf(bt, lo ? e0 : (hi ? eN : v4.x), a4[0]);
+          a4[1] = fmaf(bt, lo ? e0 : (hi ? eN : v4.y), a4[1]);
+          a4[2] = fmaf(bt, lo ? e0 : (hi ? eN : v4.z), a4[2]);
+          a4[3] = fmaf(bt, lo ? e0 : (hi ? eN : v4.w), a4[3]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[4 * q + e] = a4[e];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < PX / 4; ++q)
+      *(float4 *)&fB[pu * TSS + pv + 4 * q] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+    __syncthreads();
+    // column pass: c_{j+1} = Col_j r; detail coefficients, l1 value and sub-gradient
+    const float lam = (j == 0) ? lam_hf : lam_sc;
+    float q[PX];
+#pragma unroll
+    for (int qq = 0; qq < PX / 4; ++qq) {
+      float a4[4] = {0.375f * r[4 * qq], 0.375f * r[4 * qq + 1], 0.375f * r[4 * qq + 2], 0.375f * r[4 * qq + 3]};
+#pragma unroll
+      for (int t = -2; t <= 2; ++t) {
+        if (t == 0) continue;
+        const int uu = min(max(pu + t * d, 0), N - 1);
+        const float4 v4 = ld4(fB + uu * TSS + pv + 4 * qq);
+        const float bt = b3tap(t);
+        a4[0] = fmaf(bt, v4.x, a4[0]);
+        a4[1] = fmaf(bt, v4.y, a4[1]);
+        a4[2] = fmaf(bt, v4.z, a4[2]);
+        a4[3] = fmaf(bt, v4.w, a4[3]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int p = 4 * qq + e;
+        const float w = c[p] - a4[e];
+        const float lw = lam * wj[p];
+        l1 = fmaf(lw, fabsf(w), l1);
+        q[p] = (w > 0.f) ? lw : ((w < 0.f) ? -lw : 0.f);
+        c[p] = a4[e];
+      }
+    }
+    if constexpr (QREG) {
+#pragma unroll
+      for (int p = 0; p < PX; ++p) qreg[j][p] = q[p];
+    } else {
+      float4 *qp = (float4 *)(qscr + (size_t)j * N * N + (size_t)pu * N + pv);
+#pragma unroll
+      for (int qq = 0; qq < PX / 4; ++qq) qp[qq] = make_float4(q[4 * qq], q[4 * qq + 1], q[4 * qq + 2], q[4 * qq + 3]);
+    }
+    if (j + 1 < J) {
+#pragma unroll
+      for (int qq = 0; qq < PX / 4; ++qq)
+        *(float4 *)&fA[pu * TSS + pv + 4 * qq] = make_float4(c[4 * qq], c[4 * qq + 1], c[4 * qq + 2], c[4 * qq + 3]);
+    }
+    __syncthreads();
+  }
+  // backward: z_J = 0; z_j = q_j + H_j^T (z_{j+1} - q_j), H_j^T = Row^T Col^T (edge-replicating adjoint).
+  // Col^T runs with a column-major thread mapping and Row^T with the row-major one, so that each
+  // line (column resp. row) is owned by LPR consecutive lanes and both passes are lane shifts.
+  constexpr int LPR = N / PX;
+  constexpr bool FAST = (LPR == 4 || LPR == 8 || LPR == 16);
+  const int cu0_ = (tid % LPR) * PX;  // column-major mapping: first owned row ...
+  const int cv_ = tid / LPR;          // ... of this column
+  const int lil_ = tid % LPR;
+  static_for(std::make_integer_sequence<int, J>{}, [&](auto jc) {
+    constexpr int j = J - 1 - decltype(jc)::value;
+    constexpr int d = 1 << j;
+    int pu = pu_, pv = pv_, cu0 = cu0_, cv = cv_, lil = lil_;
+    LC_LAUNDER(pu);
+    LC_LAUNDER(pv);
+    LC_LAUNDER(cu0);
+    LC_LAUNDER(cv);
+    LC_LAUNDER(lil);
+    float q[PX];
+    if constexpr (QREG) {
+#pragma unroll
+      for (int p = 0; p < PX; ++p) q[p] = qreg[j][p];
+    } else {
+      const float4 *qp = (const float4 *)(qscr + (size_t)j * N * N + (size_t)pu * N + pv);
+#pragma unroll
+      for (int qq = 0; qq < PX / 4; ++qq) {
+        const float4 v4 = qp[qq];
+        q[4 * qq] = v4.x;
+        q[4 * qq + 1] = v4.y;
+        q[4 * qq + 2] = v4.z;
+        q[4 * qq + 3] = v4.w;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) bufA[pu * TS + pv + p] = z[p] - q[p];
+    __syncthreads();
+    float ct[PX];
+    if constexpr (FAST) {
+      float own[PX];
+#pragma unroll
+      for (int p = 0; p < PX; ++p) own[p] = bufA[(cu0 + p) * TS + cv];
+      adjoint_line_dpp<N, PX, LPR, d>(own, cu0, lil, ct);  // Col^T: line = column cv
+    } else {
+      adjoint_line_lds<N, PX>(bufA, cv, TS, cu0, d, ct);
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) bufB[(cu0 + p) * TS + cv] = ct[p];
+    __syncthreads();
+    float rt[PX];
+    if constexpr (FAST) {
+      float own[PX];
+#pragma unroll
+      for (int p = 0; p < PX; ++p) own[p] = bufB[pu * TS + pv + p];
+      adjoint_line_dpp<N, PX, LPR, d>(own, pv, lil, rt);  // Row^T: line = row pu
+    } else {
+      adjoint_line_lds<N, PX>(bufB, pu * TS, 1, pv, d, rt);
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) z[p] = q[p] + rt[p];
+  });
+}
+
+}  // namespace lc

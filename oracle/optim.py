@@ -35,7 +35,7 @@ def adabelief(loss_fn, params, free, lr0, n_iter, schedule=True, decay_rate=0.99
             p[k] = p[k].detach().requires_grad_(True)
         L = loss_fn(p)
         grads = torch.autograd.grad(L, [p[k] for k in free])
-        losses.append(float(L))
+        losses.append(float(L.detach()))
         lr = learning_rate(t, lr0, schedule, decay_rate, transition_steps)
         with torch.no_grad():
             for k, g in zip(free, grads):

@@ -1,0 +1,123 @@
+"""GPU parity of the joint (Deconv) forward model, loss, gradients, noise propagation, Fisher
+diagonal and AdaBelief trajectories against the float64 oracle, through the C ABI.
+
+Tolerances: fp32 device (FFT convolution) vs fp64 oracle: 3e-5 on models/losses, 1e-4 on
+gradients relative to their largest element."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om, optim as oo
+from lightcurver_amd.synthetic import make_roi_dataset
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(ds, rng, jitter=True, with_h=True):
+    t = ds['truth']
+    E = ds['data'].shape[0]
+    p = {k: np.array(v, dtype=np.float64) for k, v in t.items()}
+    if jitter:
+        p['a'] = p['a'] * rng.uniform(0.9, 1.1, p['a'].shape)
+        p['c_x'] = p['c_x'] + rng.normal(0, 0.1, p['c_x'].shape)
+        p['c_y'] = p['c_y'] + rng.normal(0, 0.1, p['c_y'].shape)
+        p['dx'] = p['dx'] + rng.normal(0, 0.05, E)
+        p['dy'] = p['dy'] + rng.normal(0, 0.05, E)
+        p['mean'] = rng.normal(0, 1e-3, E)
+        # additive noise: an exactly flat region has starlet coefficients at +-0 whose l1 sub-gradient
+        # sign is rounding noise in both the fp32 and the fp64 implementation
+        p['h'] = p['h'] * rng.uniform(0.8, 1.2, p['h'].shape) + 2e-3 * rng.standard_normal(p['h'].shape)
+    if not with_h:
+        p['h'] = np.zeros_like(p['h'])
+    return p
+
+
+def _setup(ctx, E, M, n, ss, seed, alpha_sigma=0.0, with_h=True):
+    from lightcurver_amd.joint import JointFit
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=seed, alpha_sigma=alpha_sigma)
+    rng = np.random.default_rng(seed + 7)
+    p = _params(ds, rng, with_h=with_h)
+    j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
+    j.set_params(**p)
+    po = {k: om.T(v) for k, v in p.items()}
+    data, sig2, psf = om.T(ds['data']), om.T(ds['noisemap']) ** 2, om.T(ds['psf'])
+    return ds, j, po, data, sig2, psf
+
+
+@pytest.mark.parametrize('E,M,n,ss,alpha', [(3, 1, 16, 1, 0.0), (4, 2, 16, 2, 0.0), (3, 2, 16, 2, 2.0),
+                                            (3, 3, 24, 2, 0.5), (2, 2, 32, 2, 0.3)])
+def test_model_loss_and_gradients(ctx, E, M, n, ss, alpha):
+    ds, j, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 100 + n + M, alpha_sigma=alpha)
+    N = n * ss
+    W = om.propagate_noise_deconv(sig2, psf, ss)
+    lam = dict(lam_scales=1.5, lam_hf=0.8, lam_pos=20.0, lam_pos_ps=5.0, lam_fu=0.7)
+    prior = [('c_x', po['c_x'] + 0.05, np.full(M, 0.5)), ('c_y', po['c_y'] - 0.02, np.full(M, 0.7))]
+    j.set_loss(W=W.numpy(), lam_scales=1.5, lam_hf=0.8, lam_positivity=20.0, lam_positivity_ps=5.0,
+               lam_flux_uniformity=0.7,
+               prior=dict(c_x_mean=prior[0][1].numpy(), c_x_sigma=prior[0][2], c_y_mean=prior[1][1].numpy(),
+                          c_y_sigma=prior[1][2]))
+    j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean'])
+    model, chi2_e = j.model()
+    mo = om.deconv_model(po, psf, ss, n)
+    assert H.rel_err(model, mo.numpy()) < 3e-5
+    assert H.rel_err(chi2_e, (((data - mo) ** 2) / sig2).sum((-1, -2)).numpy()) < 3e-5
+    fn = lambda q: om.deconv_loss(q, data, sig2, psf, ss, W=W, prior=prior, **lam)
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean']
+    L, g = oo.value_and_grad(fn, po, free)
+    loss, grads = j.loss_grad(free)
+    assert abs(loss - L) / abs(L) < 3e-5
+    for k in free:
+        assert H.rel_err(grads[k], g[k].numpy()) < 1e-4, k
+    sc, bg = j.deconvolved(1)
+    so, bo = om.deconv_deconvolved(po, 1, N, ss)
+    assert H.rel_err(sc, so.numpy()) < 1e-5 and H.rel_err(bg, bo.numpy()) < 1e-5
+
+
+def test_no_background_path(ctx):
+    """h == 0 and fixed (star photometry default, star_photometry.py:74-87): scene has point sources only."""
+    ds, j, po, data, sig2, psf = _setup(ctx, 5, 1, 16, 2, 5, with_h=False)
+    j.set_loss(lam_scales=3.0, lam_hf=3.0)
+    j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy'])
+    fn = lambda q: om.deconv_loss(q, data, sig2, psf, 2, lam_scales=3.0, lam_hf=3.0)
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy']
+    L, g = oo.value_and_grad(fn, po, free)
+    loss, grads = j.loss_grad(free)
+    assert abs(loss - L) / abs(L) < 3e-5
+    for k in free:
+        assert H.rel_err(grads[k], g[k].numpy()) < 1e-4, k
+
+
+def test_noise_propagation_and_fisher(ctx):
+    ds, j, po, data, sig2, psf = _setup(ctx, 4, 2, 16, 2, 11)
+    W = j.propagate_noise()
+    Wo = om.propagate_noise_deconv(sig2, psf, 2).numpy()
+    assert W.shape == Wo.shape
+    assert H.rel_err(W, Wo) < 3e-5
+    s = j.fisher_flux_sigma()
+    so = om.fisher_flux_sigma(po, sig2, psf, 2).numpy()
+    assert H.rel_err(s, so) < 3e-5
+
+
+@pytest.mark.parametrize('n,ss,with_h', [(16, 2, True), (32, 2, True), (16, 1, False)])
+def test_adabelief_trajectory(ctx, n, ss, with_h):
+    E, M, T = 4, 2, 20
+    ds, j, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 40 + n, with_h=with_h)
+    W = om.propagate_noise_deconv(sig2, psf, ss)
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'mean'] + (['h'] if with_h else [])
+    j.set_loss(W=W.numpy(), lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0)
+    j.set_free(free)
+    j.run_adabelief(T, init_learning_rate=1e-3, schedule_learning_rate=True)
+    hist = j.loss_history()
+    fn = lambda q: om.deconv_loss(q, data, sig2, psf, ss, W=W, lam_scales=1.0, lam_hf=1.0, lam_pos=10.0)
+    pf, lh, l0 = oo.adabelief(fn, po, free, 1e-3, T, schedule=True)
+    ref = np.array([l0] + lh)
+    assert hist.shape == (T + 1,)
+    assert np.abs(hist - ref).max() / np.abs(ref).max() < 2e-4
+    got = j.get_params()
+    assert H.rel_err(got['a'], pf['a'].numpy()) < 2e-4
+    assert np.abs(got['c_x'] - pf['c_x'].numpy()).max() < 5e-4
+    assert np.abs(got['dx'] - pf['dx'].numpy()).max() < 5e-4
+    if with_h:
+        dh = np.abs(got['h'] - pf['h'].numpy())
+        assert dh.max() < 0.05 * T * 1e-3 and np.median(dh) < 1e-5
