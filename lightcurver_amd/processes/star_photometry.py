@@ -1,0 +1,83 @@
+"""PSF photometry of one star over all its epochs = one joint forward-model fit, restated from the
+reference's lightcurver/processes/star_photometry.py:23-151 on top of the GPU STARRED mirror.  Same
+signature, same in-place rescaling of the inputs (callers plot the rescaled arrays, :47-49), same keys
+in the returned dictionary (tests/test_starred_calls/test_starred_calls.py:21-64)."""
+import numpy as np
+
+from ..starred.deconvolution.deconvolution import setup_model
+from ..starred.deconvolution.loss import Loss
+from ..starred.deconvolution.parameters import ParametersDeconv
+from ..starred.optim.optimization import Optimizer
+from ..starred.utils.noise_utils import propagate_noise
+from ..utilities.starred_utilities import get_flux_uncertainties
+
+
+def _border_level(stack):
+    """Sky estimate: mean over the four borders of the per-epoch median of the outermost row / column."""
+    edges = [stack[:, :1, :], stack[:, :, :1], stack[:, -1:, :], stack[:, :, -1:]]
+    with np.errstate(all='ignore'):
+        level = np.nanmean([np.nanmedian(e, axis=(1, 2)) for e in edges])
+    return float(np.nan_to_num(level, nan=0.0))
+
+
+def do_one_star_forward_modelling(data, noisemap, psf, subsampling_factor, n_iter=2000,
+                                  uniform_background_per_epoch=False, starlet_global_background=True):
+    """data, noisemap: (E, n, n) (rescaled IN PLACE by nanmax(data)); psf: (E, N, N) narrow PSFs.
+
+    Returns dict: scale, kwargs_final, fluxes, fluxes_uncertainties, chi2, chi2_per_frame, loss_curve,
+    residuals, deconvolved_image, starlet_background.
+    """
+    scale = np.nanmax(data)
+    data /= scale
+    noisemap /= scale
+    variance = noisemap ** 2
+    n_epochs = len(data)
+
+    # rough aperture-like flux guess: stamp sum minus the border sky level
+    flux_guess = np.nansum(data, axis=(1, 2)) - data[0].size * _border_level(data)
+    model, k_init, k_up, k_down, _ = setup_model(data, variance, psf, np.array([0.]), np.array([0.]),
+                                                 subsampling_factor, list(flux_guess))
+
+    # what stays fixed: rotation always; background grid and per-epoch constant unless asked for
+    fixed = {'kwargs_analytic': {'alpha': k_init['kwargs_analytic']['alpha']},
+             'kwargs_background': {}, 'kwargs_sersic': {}}
+    if not starlet_global_background:
+        fixed['kwargs_background']['h'] = k_init['kwargs_background']['h']
+    if not uniform_background_per_epoch:
+        fixed['kwargs_background']['mean'] = np.zeros(n_epochs)
+    pars = ParametersDeconv(kwargs_init=k_init, kwargs_fixed=fixed, kwargs_up=k_up, kwargs_down=k_down)
+
+    loss_options = dict(data=data, deconv_class=model, param_class=pars, sigma_2=variance,
+                        regularization_terms='l1_starlet', regularization_strength_scales=3.0,
+                        regularization_strength_hf=3.0, regularization_strength_flux_uniformity=0.)
+    if starlet_global_background:
+        loss_options['W'] = propagate_noise(model, noisemap, k_init, wavelet_type_list=['starlet'], method='SLIT',
+                                            num_samples=200, seed=1, likelihood_type='chi2', verbose=False,
+                                            upsampling_factor=subsampling_factor)[0]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        loss = Loss(**loss_options)
+    optim = Optimizer(loss, pars, method='adabelief')
+    optim.minimize(max_iterations=n_iter, min_iterations=None, init_learning_rate=1e-3, schedule_learning_rate=True,
+                   restart_from_init=True, stop_at_loss_increase=False, progress_bar=True,
+                   return_param_history=True)
+    k_final = pars.best_fit_values(as_kwargs=True)
+
+    residuals = data - np.array(model.model(k_final))
+    chi2_per_frame = np.nansum(residuals ** 2 / variance, axis=(1, 2)) / model.image_size ** 2
+    sigma_a = get_flux_uncertainties(kwargs=k_final, kwargs_down=k_down, kwargs_up=k_up, data=data,
+                                     noisemap=noisemap, model=model)
+    scene, background = model.getDeconvolved(k_final, 0)
+    return {
+        'scale': scale,
+        'kwargs_final': k_final,
+        'fluxes': scale * np.array(k_final['kwargs_analytic']['a']),
+        'fluxes_uncertainties': scale * sigma_a,
+        'chi2': float(np.nanmean(chi2_per_frame)),
+        'chi2_per_frame': np.array(chi2_per_frame),
+        'loss_curve': optim.loss_history,
+        'residuals': scale * residuals,
+        'deconvolved_image': scale * scene,
+        'starlet_background': scale * background,
+    }

@@ -1,0 +1,114 @@
+"""The drop-in boundary: the reference's own structural test of its STARRED calls
+(tests/test_starred_calls/test_starred_calls.py:20-64) restated on the same (seeded) fixture, plus the
+ParametersDeconv / Loss / Optimizer behaviours the pipeline relies on."""
+from copy import deepcopy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fixture(seed=0):
+    rng = np.random.default_rng(seed)
+    x, y = np.meshgrid(np.arange(-8, 8), np.arange(-8, 8))
+    gauss = np.exp(-0.1 * (x ** 2 + y ** 2))
+    data = 0.1 * rng.random((5, 16, 16)) + np.repeat(gauss[None, :, :], repeats=5, axis=0)
+    noisemap = 0.1 * np.ones((5, 16, 16))
+    psf = np.repeat(gauss[None, :, :], repeats=5, axis=0)
+    return data, noisemap, psf
+
+
+@pytest.mark.parametrize('starlet_bg', [True, False])
+def test_do_one_star_forward_modelling_contract(starlet_bg):
+    from lightcurver_amd.processes.star_photometry import do_one_star_forward_modelling
+    data, noisemap, psf = _fixture()
+    d0 = data.copy()
+    n_iter = 50
+    result = do_one_star_forward_modelling(data, noisemap, psf, 1, n_iter, starlet_global_background=starlet_bg)
+    assert isinstance(result, dict)
+    for key in ('scale', 'kwargs_final', 'fluxes', 'fluxes_uncertainties', 'chi2', 'chi2_per_frame', 'loss_curve',
+                'residuals'):
+        assert key in result
+    assert isinstance(result['scale'], float) and result['scale'] > 0
+    assert isinstance(result['kwargs_final'], dict)
+    assert isinstance(result['fluxes'], np.ndarray) and isinstance(result['fluxes_uncertainties'], np.ndarray)
+    assert result['fluxes'].ndim == 1 and result['fluxes_uncertainties'].ndim == 1
+    assert result['fluxes'].size == result['fluxes_uncertainties'].size == data.shape[0]
+    assert isinstance(result['chi2'], float) and result['chi2'] >= 0
+    assert isinstance(result['chi2_per_frame'], np.ndarray) and result['chi2_per_frame'].ndim == 1
+    assert len(result['chi2_per_frame']) == data.shape[0]
+    assert len(result['loss_curve']) == n_iter  # no early stop
+    assert result['residuals'].shape == data.shape
+    # in-place rescaling by nanmax, as callers of the reference rely on (star_photometry.py:47-49)
+    assert np.allclose(data * result['scale'], d0)
+    assert np.all(np.isfinite(result['fluxes'])) and np.all(result['fluxes_uncertainties'] > 0)
+    assert result['deconvolved_image'].shape == (16, 16) and result['starlet_background'].shape == (16, 16)
+    lc = np.array(result['loss_curve'])
+    assert np.all(np.isfinite(lc)) and lc[-1] < lc[0]
+
+
+def test_kwargs_manipulations_and_two_stage_fit():
+    """deepcopy / del / in-place *= 0 on kwargs, L-BFGS-B stage then AdaBelief stage (roi_modelling.py:259-334)."""
+    from lightcurver_amd.starred.deconvolution.deconvolution import setup_model
+    from lightcurver_amd.starred.deconvolution.loss import Loss, Prior
+    from lightcurver_amd.starred.deconvolution.parameters import ParametersDeconv
+    from lightcurver_amd.starred.optim.optimization import Optimizer
+    from lightcurver_amd.starred.utils.noise_utils import propagate_noise
+    from lightcurver_amd.synthetic import make_roi_dataset
+    ds = make_roi_dataset(E=6, M=2, n=16, ss=2, seed=3)
+    data, noise, s = ds['data'].astype(np.float64), ds['noisemap'].astype(np.float64), ds['psf']
+    t = ds['truth']
+    E, M = 6, 2
+    a0 = np.tile(t['a'].reshape(E, M).mean(0) * 0.8, E)
+    model, k_init, k_up, k_down, k_fixed = setup_model(data, noise ** 2, s, t['c_x'] + 0.2, t['c_y'] - 0.2, 2, list(a0))
+    k_init['kwargs_analytic']['alpha'] = t['alpha']
+    k_fixed = deepcopy(k_init)
+    del k_fixed['kwargs_analytic']['dx']
+    del k_fixed['kwargs_analytic']['dy']
+    del k_fixed['kwargs_analytic']['a']
+    pars = ParametersDeconv(kwargs_init=k_init, kwargs_fixed=k_fixed, kwargs_up=k_up, kwargs_down=k_down)
+    prior = Prior(prior_analytic=[['c_x', t['c_x'] + 0.2, np.array(M * [2.0])], ['c_y', t['c_y'] - 0.2, np.array(M * [2.0])]])
+    with pytest.warns(UserWarning, match='lambda is not normalized'):
+        loss = Loss(data, model, pars, noise ** 2, prior=prior, regularization_strength_flux_uniformity=1.0)
+    optim = Optimizer(loss, pars, method='l-bfgs-b')
+    best_fit, logL, extra, runtime = optim.minimize(maxiter=40)
+    k1 = deepcopy(pars.best_fit_values(as_kwargs=True))
+    assert len(extra['loss_history']) >= 1 and extra['loss_history'][-1] <= extra['loss_history'][0]
+    # (with h fixed to zero in this stage the fluxes absorb the background, so no truth comparison here)
+    assert np.all(np.isfinite(np.array(k1['kwargs_analytic']['a'])))
+    k_fixed = deepcopy(k1)
+    for grp, name in (('kwargs_background', 'h'), ('kwargs_background', 'mean'), ('kwargs_analytic', 'a'),
+                      ('kwargs_analytic', 'c_x'), ('kwargs_analytic', 'c_y'), ('kwargs_analytic', 'dx'),
+                      ('kwargs_analytic', 'dy')):
+        del k_fixed[grp][name]
+    W = propagate_noise(model, noise, k_init, wavelet_type_list=['starlet'], method='SLIT', num_samples=500, seed=1,
+                        likelihood_type='chi2', verbose=False, upsampling_factor=2)[0]
+    assert W.shape == (6, 32, 32)
+    pars = ParametersDeconv(kwargs_init=k1, kwargs_fixed=k_fixed, kwargs_up=k_up, kwargs_down=k_down)
+    loss = Loss(data, model, pars, noise ** 2, regularization_terms='l1_starlet', regularization_strength_scales=1.0,
+                regularization_strength_hf=1.0, regularization_strength_positivity=100.0, W=W, prior=prior)
+    optim = Optimizer(loss, pars, method='adabelief')
+    best_fit, logL, extra, runtime = optim.minimize(max_iterations=120, init_learning_rate=1e-4,
+                                                    schedule_learning_rate=False, restart_from_init=False,
+                                                    stop_at_loss_increase=False, progress_bar=True,
+                                                    return_param_history=True)
+    assert len(optim.loss_history) == 120
+    k_final = deepcopy(pars.best_fit_values(as_kwargs=True))
+    # diagnostics of roi_modelling.py:99-110: zero the background / the fluxes in place and re-model
+    only_ps = deepcopy(k_final)
+    only_ps['kwargs_background']['h'] *= 0.0
+    no_ps = deepcopy(k_final)
+    no_ps['kwargs_analytic']['a'] *= 0.0
+    m_full, m_ps, m_bg = model.model(k_final), model.model(only_ps), model.model(no_ps)
+    assert m_full.shape == data.shape
+    assert np.allclose(m_ps + m_bg - np.array(k_final['kwargs_background']['mean'])[:, None, None], m_full, atol=2e-5)
+    chi2 = np.nansum((data - m_full) ** 2 / noise ** 2, axis=(1, 2)) / model.image_size ** 2
+    assert np.all(chi2 < 3.0)
+    hi, bg = model.getDeconvolved(k_final, 0)
+    assert hi.shape == (32, 32) and bg.shape == (32, 32)
+    from lightcurver_amd.utilities.starred_utilities import get_flux_uncertainties
+    sig = get_flux_uncertainties(kwargs=k_final, kwargs_up=k_up, kwargs_down=k_down, data=data, noisemap=noise, model=model)
+    assert sig.shape == (E * M,) and np.all(sig > 0)
+    # de-interleave per source as roi_modelling.py:462 does
+    assert sig[0::M].shape == (E,)
