@@ -158,6 +158,9 @@ int lc_joint_fisher_flux_sigma(lc_joint *j, float *sigma_a);
 int lc_joint_step_local(lc_joint *j);                      /* forward/backward of local epochs */
 int lc_joint_shared_buffer_dev(lc_joint *j, void **dev_ptr, int *count);
 int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg); /* regularise + AdaBelief */
+/* host-staged access to the shared block (round-1 collective path: D2H, all-reduce, H2D) */
+int lc_joint_shared_get(lc_joint *j, float *host, int count);
+int lc_joint_shared_set(lc_joint *j, const float *host, int count);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,8 @@ SIGNATURES = {
     'lc_joint_step_local': (C.c_int, [vp]),
     'lc_joint_shared_buffer_dev': (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int)]),
     'lc_joint_step_update': (C.c_int, [vp, C.POINTER(AdabeliefCfg)]),
+    'lc_joint_shared_get': (C.c_int, [vp, fp, C.c_int]),
+    'lc_joint_shared_set': (C.c_int, [vp, fp, C.c_int]),
 }
 
 _lib = None

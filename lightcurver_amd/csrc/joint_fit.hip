@@ -1,9 +1,11 @@
 // Joint multi-epoch forward-model object behind the C ABI (include/lcmi.h, "joint" section).
 #include <cmath>
 #include <complex>
+#include <thread>
 #include <cstring>
 
 #include "joint_kernels.h"
+#include "noise_host.h"
 #include "noise_kernels.h"
 
 using namespace lc;
@@ -19,7 +21,7 @@ struct lc_joint {
   float *chi2_e = nullptr, *g_a = nullptr, *g_cx_e = nullptr, *g_cy_e = nullptr, *g_dx = nullptr, *g_dy = nullptr,
         *g_mean = nullptr;
   float *model = nullptr, *fisher = nullptr, *shared = nullptr, *W = nullptr, *norms = nullptr, *atoms = nullptr,
-        *qscr = nullptr, *V = nullptr, *out_loss = nullptr, *hist = nullptr, *scene2 = nullptr;
+        *qscr = nullptr, *out_loss = nullptr, *hist = nullptr, *scene2 = nullptr;
   float *prior = nullptr;  // [4][M]
   int shared_count = 0, hist_cap = 0, iters_done = 0, n_prior = 0;
   int free_mask[LC_P_COUNT] = {};
@@ -47,51 +49,6 @@ int d2h(lc_joint *j, void *dst, const void *src, size_t bytes) {
   LC_HIP(j->ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, j->ctx->stream));
   LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
   return LC_OK;
-}
-
-// ---- small host FFT (double) for the one-time PSF spectra and noise propagation -------------------
-typedef std::complex<double> cd;
-void fft1d(cd *x, int L, bool inv) {
-  for (int i = 1, j = 0; i < L; ++i) {
-    int bit = L >> 1;
-    for (; j & bit; bit >>= 1) j ^= bit;
-    j ^= bit;
-    if (i < j) std::swap(x[i], x[j]);
-  }
-  for (int len = 2; len <= L; len <<= 1) {
-    const double ang = 2.0 * M_PI / len * (inv ? 1.0 : -1.0);
-    const cd wl(std::cos(ang), std::sin(ang));
-    for (int i = 0; i < L; i += len) {
-      cd w(1.0, 0.0);
-      for (int k = 0; k < len / 2; ++k) {
-        const cd u = x[i + k], v = x[i + k + len / 2] * w;
-        x[i + k] = u + v;
-        x[i + k + len / 2] = u - v;
-        w *= wl;
-      }
-    }
-  }
-}
-// 2-D FFT of an L x L array whose non-zero rows are [r0, r0 + nr)
-void fft2d(std::vector<cd> &a, int L, int r0, int nr, bool inv) {
-  if (!inv) {
-    for (int r = r0; r < r0 + nr; ++r) fft1d(&a[(size_t)r * L], L, false);
-  }
-  std::vector<cd> col(L);
-  for (int c = 0; c < L; ++c) {
-    for (int r = 0; r < L; ++r) col[r] = a[(size_t)r * L + c];
-    fft1d(col.data(), L, inv);
-    for (int r = 0; r < L; ++r) a[(size_t)r * L + c] = col[r];
-  }
-  if (inv)
-    for (int r = 0; r < L; ++r) fft1d(&a[(size_t)r * L], L, true);
-}
-
-int fft_length(int N) {
-  const int c = (N - 1) / 2;
-  int L = 1;
-  while (L < 2 * N - 1 - c) L <<= 1;
-  return L;
 }
 
 typedef void (*epoch_fn)(JointArgs);
@@ -334,7 +291,6 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   TRY(dmalloc(j, &j->norms, j->J + 1));
   TRY(dmalloc(j, &j->atoms, (size_t)(j->J + 1) * 3 * N));
   TRY(dmalloc(j, &j->qscr, (size_t)(j->J + 1) * NN));
-  TRY(dmalloc(j, &j->V, NN));
   TRY(dmalloc(j, &j->out_loss, 4));
   TRY(dmalloc(j, &j->scene2, 2 * NN));
   TRY(dmalloc(j, &j->prior, 4 * std::max(M, 1)));
@@ -373,7 +329,7 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
       std::fill(a.begin(), a.end(), cd(0, 0));
       for (int r = 0; r < N; ++r)
         for (int c = 0; c < N; ++c) a[(size_t)r * L + c] = psf[(size_t)e * NN + (size_t)r * N + c];
-      fft2d(a, L, 0, N, false);
+      host_fft2d(a, L, 0, N, false);
       for (int k = 0; k < KH; ++k)
         for (int r = 0; r < L; ++r) st[(size_t)k * L + r] = make_float2((float)(a[(size_t)r * L + k].real() * sc), (float)(a[(size_t)r * L + k].imag() * sc));
       TRY(h2d(j, j->St + (size_t)e * KH * L, st.data(), st.size() * sizeof(float2)));
@@ -455,37 +411,45 @@ int lc_joint_set_loss(lc_joint *j, const lc_joint_loss_cfg *cfg, const float *W)
 
 int lc_joint_propagate_noise(lc_joint *j, float *W_out) {
   if (!j) return LC_ERR_INVALID;
-  const int N = j->N, L = j->L, n = j->n, ss = j->ss, E = j->E, c = (N - 1) / 2;
+  const int N = j->N, n = j->n, ss = j->ss, E = j->E, c = (N - 1) / 2;
   const size_t NN = (size_t)N * N, nn = (size_t)n * n;
-  // V = sum_e adj[x -> conv_same(x, s_e^2)](up(1/sigma_e^2)), accumulated in Fourier space (host, one-time)
-  std::vector<cd> acc((size_t)L * L, cd(0, 0)), r((size_t)L * L), s2((size_t)L * L);
-  for (int e = 0; e < E; ++e) {
-    std::fill(r.begin(), r.end(), cd(0, 0));
-    std::fill(s2.begin(), s2.end(), cd(0, 0));
-    for (int u = 0; u < N; ++u)
-      for (int v = 0; v < N; ++v) {
-        const float sg = j->h_sigma2[(size_t)e * nn + (size_t)(u / ss) * n + v / ss];
-        const double w = (std::isfinite(sg) && sg > 0.f) ? 1.0 / sg : 0.0;
-        r[(size_t)(u + c) * L + (v + c)] = w;
-        const double p = j->h_psf[(size_t)e * NN + (size_t)u * N + v];
-        s2[(size_t)u * L + v] = p * p;
-      }
-    fft2d(r, L, c, N, false);
-    fft2d(s2, L, 0, N, false);
-    for (size_t i = 0; i < acc.size(); ++i) acc[i] += r[i] * std::conj(s2[i]);
+  // contributor = epoch; response of dL/dh to a unit of whitened noise in data pixel p* = (n/2, n/2):
+  //   r_e[u'][v'] = sum_{(u,v) in block(p*)} s_e[u - u' + c][v - v' + c]      (adjoint of D_ss . conv_same(., s_e))
+  std::vector<float> w((size_t)E * nn);
+  for (size_t i = 0; i < w.size(); ++i) {
+    const float sg = j->h_sigma2[i];
+    w[i] = (std::isfinite(sg) && sg > 0.f) ? 1.0f / sg : 0.f;
   }
-  fft2d(acc, L, 0, L, true);
-  std::vector<float> V(NN);
-  const double sc = 1.0 / ((double)L * L);
-  for (int u = 0; u < N; ++u)
-    for (int v = 0; v < N; ++v) V[(size_t)u * N + v] = (float)std::max(acc[(size_t)u * L + v].real() * sc, 0.0);
-  int rc = h2d(j, j->V, V.data(), NN * sizeof(float));
+  const int T = noise_threads(E);
+  std::vector<NoiseAccumulator> accs(T, NoiseAccumulator(N, ss));
+  std::vector<std::thread> pool;
+  for (int t = 0; t < T; ++t)
+    pool.emplace_back([&, t]() {
+      std::vector<double> r(NN);
+      const int b0 = ss * (n / 2);
+      for (int e = t; e < E; e += T) {
+        const float *s = &j->h_psf[(size_t)e * NN];
+        for (int up = 0; up < N; ++up)
+          for (int vp = 0; vp < N; ++vp) {
+            double acc = 0;
+            for (int du = 0; du < ss; ++du)
+              for (int dv = 0; dv < ss; ++dv) {
+                const int a = b0 + du - up + c, b = b0 + dv - vp + c;
+                if (a >= 0 && a < N && b >= 0 && b < N) acc += s[(size_t)a * N + b];
+              }
+            r[(size_t)up * N + vp] = acc;
+          }
+        accs[t].add(r, &w[(size_t)e * nn]);
+      }
+    });
+  for (auto &th : pool) th.join();
+  for (int t = 1; t < T; ++t) accs[0].merge(accs[t]);
+  std::vector<float> W((size_t)(j->J + 1) * NN);
+  accs[0].finalize(W.data());
+  int rc = h2d(j, j->W, W.data(), W.size() * sizeof(float));
   if (rc) return rc;
-  hipLaunchKernelGGL(starlet_noise_w_kernel, dim3(1, j->J + 1), dim3(256), 0, j->ctx->stream, N, j->J + 1, j->V, j->atoms,
-                     j->W, j->qscr);
-  LC_HIP(j->ctx, hipGetLastError());
   j->have_W = true;
-  if (W_out) return d2h(j, W_out, j->W, (size_t)(j->J + 1) * NN * sizeof(float));
+  if (W_out) std::memcpy(W_out, W.data(), W.size() * sizeof(float));
   return LC_OK;
 }
 
@@ -500,6 +464,14 @@ int lc_joint_shared_buffer_dev(lc_joint *j, void **dev_ptr, int *count) {
   *dev_ptr = j->shared;
   *count = j->shared_count;
   return LC_OK;
+}
+int lc_joint_shared_get(lc_joint *j, float *host, int count) {
+  if (!j || !host || count != j->shared_count) return LC_ERR_INVALID;
+  return d2h(j, host, j->shared, (size_t)count * sizeof(float));
+}
+int lc_joint_shared_set(lc_joint *j, const float *host, int count) {
+  if (!j || !host || count != j->shared_count) return LC_ERR_INVALID;
+  return h2d(j, j->shared, host, (size_t)count * sizeof(float));
 }
 int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   if (!j) return LC_ERR_INVALID;

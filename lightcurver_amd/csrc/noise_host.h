@@ -1,0 +1,141 @@
+// One-time noise propagation into starlet space (host, double precision, threaded):
+//   W_j(x)^2 = sum_k ( up0(w_k) (*) kappa_{k,j}^2 )(x),   kappa_{k,j} = starlet scale j of the response r_k of the
+//   gradient image to a unit of whitened noise in the central data pixel of contributor k (epoch / star).
+// Restates starred.utils.noise_utils.propagate_noise(method='SLIT', likelihood_type='chi2') as frozen in
+// DESIGN.md "SPEC" (reference call sites: lightcurver/processes/star_photometry.py:108-110,
+// roi_modelling.py:299-301, and the propagate_noise call inside build_psf, psf_modelling.py:164-171).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <thread>
+#include <vector>
+
+namespace lc {
+
+typedef std::complex<double> cd;
+
+inline void host_fft1d(cd *x, int L, bool inv) {
+  for (int i = 1, j = 0; i < L; ++i) {
+    int bit = L >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(x[i], x[j]);
+  }
+  for (int len = 2; len <= L; len <<= 1) {
+    const double ang = 2.0 * M_PI / len * (inv ? 1.0 : -1.0);
+    const cd wl(std::cos(ang), std::sin(ang));
+    for (int i = 0; i < L; i += len) {
+      cd w(1.0, 0.0);
+      for (int k = 0; k < len / 2; ++k) {
+        const cd u = x[i + k], v = x[i + k + len / 2] * w;
+        x[i + k] = u + v;
+        x[i + k + len / 2] = u - v;
+        w *= wl;
+      }
+    }
+  }
+}
+// 2-D FFT (unnormalised) of an L x L array whose non-zero rows are [r0, r0 + nr)
+inline void host_fft2d(std::vector<cd> &a, int L, int r0, int nr, bool inv) {
+  if (!inv)
+    for (int r = r0; r < r0 + nr; ++r) host_fft1d(&a[(size_t)r * L], L, false);
+  std::vector<cd> col(L);
+  for (int c = 0; c < L; ++c) {
+    for (int r = 0; r < L; ++r) col[r] = a[(size_t)r * L + c];
+    host_fft1d(col.data(), L, inv);
+    for (int r = 0; r < L; ++r) a[(size_t)r * L + c] = col[r];
+  }
+  if (inv)
+    for (int r = 0; r < L; ++r) host_fft1d(&a[(size_t)r * L], L, true);
+}
+inline int host_fft_length(int N) {  // smallest power of two that keeps the 'same' window alias free
+  const int c = (N - 1) / 2;
+  int L = 1;
+  while (L < 2 * N - 1 - c) L <<= 1;
+  return L;
+}
+
+// 2-D first-generation starlet, edge replicating: out[j] (j < J) detail scales, out[J] coarse.
+inline void host_starlet(const std::vector<double> &img, int N, int J, std::vector<std::vector<double>> &out) {
+  const double b3[5] = {1. / 16, 4. / 16, 6. / 16, 4. / 16, 1. / 16};
+  out.assign(J + 1, std::vector<double>((size_t)N * N));
+  std::vector<double> c = img, r((size_t)N * N), cn((size_t)N * N);
+  for (int j = 0; j < J; ++j) {
+    const int d = 1 << j;
+    for (int u = 0; u < N; ++u)
+      for (int v = 0; v < N; ++v) {
+        double acc = 0;
+        for (int t = -2; t <= 2; ++t) acc += b3[t + 2] * c[(size_t)u * N + std::min(std::max(v + t * d, 0), N - 1)];
+        r[(size_t)u * N + v] = acc;
+      }
+    for (int u = 0; u < N; ++u)
+      for (int v = 0; v < N; ++v) {
+        double acc = 0;
+        for (int t = -2; t <= 2; ++t) acc += b3[t + 2] * r[(size_t)std::min(std::max(u + t * d, 0), N - 1) * N + v];
+        cn[(size_t)u * N + v] = acc;
+      }
+    for (size_t i = 0; i < c.size(); ++i) out[j][i] = c[i] - cn[i];
+    c = cn;
+  }
+  out[J] = c;
+}
+
+struct NoiseAccumulator {
+  int N, n, ss, J, L, c, shift;
+  std::vector<std::vector<cd>> acc;  // [J+1][L*L], Fourier space
+  NoiseAccumulator(int N_, int ss_) : N(N_), n(N_ / ss_), ss(ss_) {
+    J = 0;
+    for (int m = N; m > 1; m >>= 1) ++J;
+    L = host_fft_length(N);
+    c = (N - 1) / 2;
+    shift = ss * (n / 2) - c;
+    acc.assign(J + 1, std::vector<cd>((size_t)L * L, cd(0, 0)));
+  }
+  // r: N*N impulse response, w: n*n inverse variances of this contributor
+  void add(const std::vector<double> &r, const float *w) {
+    std::vector<std::vector<double>> kap;
+    host_starlet(r, N, J, kap);
+    std::vector<cd> A((size_t)L * L, cd(0, 0)), B((size_t)L * L);
+    for (int i = 0; i < n; ++i)
+      for (int jx = 0; jx < n; ++jx) {
+        const float wv = w[(size_t)i * n + jx];
+        A[(size_t)(ss * i) * L + ss * jx] = (std::isfinite(wv) && wv > 0.f) ? (double)wv : 0.0;
+      }
+    host_fft2d(A, L, 0, N, false);
+    for (int j = 0; j <= J; ++j) {
+      std::fill(B.begin(), B.end(), cd(0, 0));
+      for (int u = 0; u < N; ++u)
+        for (int v = 0; v < N; ++v) {
+          const int su = u + shift, sv = v + shift;
+          if (su < 0 || su >= N || sv < 0 || sv >= N) continue;
+          const double k = kap[j][(size_t)su * N + sv];
+          B[(size_t)u * L + v] = k * k;
+        }
+      host_fft2d(B, L, 0, N, false);
+      for (size_t i = 0; i < A.size(); ++i) acc[j][i] += A[i] * B[i];
+    }
+  }
+  void merge(const NoiseAccumulator &o) {
+    for (int j = 0; j <= J; ++j)
+      for (size_t i = 0; i < acc[j].size(); ++i) acc[j][i] += o.acc[j][i];
+  }
+  // W: [(J+1)][N*N]
+  void finalize(float *W) {
+    const double sc = 1.0 / ((double)L * L);
+    for (int j = 0; j <= J; ++j) {
+      host_fft2d(acc[j], L, 0, L, true);
+      for (int u = 0; u < N; ++u)
+        for (int v = 0; v < N; ++v)
+          W[((size_t)j * N + u) * N + v] = (float)std::sqrt(std::max(acc[j][(size_t)(u + c) * L + (v + c)].real() * sc, 0.0));
+    }
+  }
+};
+
+inline int noise_threads(int work_items) {
+  int t = (int)std::thread::hardware_concurrency();
+  if (t <= 0) t = 4;
+  return std::max(1, std::min({t, 16, work_items}));
+}
+
+}  // namespace lc

@@ -1,9 +1,6 @@
-// Noise propagation into starlet space, shared by the PSF fit and the joint fit:
-//   W_j = sqrt( conv_same(V, psi_j^2) ),   psi_j = 2-D starlet atom of scale j (dirac at the zero-lag index)
-// psi_j = p_j (x) p_j - p_{j+1} (x) p_{j+1} with p_j the 1-D cascade of the dirac, so
-// psi_j^2 = p_j^2 (x) p_j^2 - 2 (p_j p_{j+1}) (x) (p_j p_{j+1}) + p_{j+1}^2 (x) p_{j+1}^2: three separable kernels.
-// Restates starred.utils.noise_utils.propagate_noise(method='SLIT') as frozen in DESIGN.md "SPEC"
-// (reference call sites: lightcurver/processes/star_photometry.py:108-110, roi_modelling.py:299-301).
+// Starlet scale norms: the l1 weights STARRED falls back to when no noise-propagated weight map is given
+// ("lambda is not normalized", docs/example_starred_notebooks/example_roi_modelling.ipynb:302).
+// psi_j = p_j (x) p_j - p_{j+1} (x) p_{j+1} with p_j the 1-D cascade of a dirac at the zero-lag index.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -12,43 +9,6 @@
 #include "lc_common.h"
 
 namespace lc {
-
-// W_j = sqrt( sum_{term} c_term * (k_term (x) k_term) (*) V ), 'same' with zero lag at (N-1)//2.
-// atoms: [J+1][3][N] 1-D factors; coefficients {+1, -2, +1}.  One block per (frame, scale).
-static __global__ void starlet_noise_w_kernel(int N, int J, const float *V, const float *atoms, float *W, float *tmp) {
-  const int f = blockIdx.x, j = blockIdx.y;
-  const int c = (N - 1) / 2;
-  const float *Vf = V + (size_t)f * N * N;
-  float *t = tmp + ((size_t)f * J + j) * N * N;
-  float *Wf = W + ((size_t)f * J + j) * N * N;
-  const float coef[3] = {1.f, -2.f, 1.f};
-  for (int i = threadIdx.x; i < N * N; i += blockDim.x) Wf[i] = 0.f;
-  for (int term = 0; term < 3; ++term) {
-    const float *k = atoms + ((size_t)j * 3 + term) * N;
-    __syncthreads();
-    for (int i = threadIdx.x; i < N * N; i += blockDim.x) {  // rows
-      const int u = i / N, v = i % N;
-      double acc = 0;
-      for (int vp = 0; vp < N; ++vp) {
-        const int kk = v - vp + c;
-        if (kk >= 0 && kk < N) acc += (double)Vf[u * N + vp] * k[kk];
-      }
-      t[i] = (float)acc;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < N * N; i += blockDim.x) {  // columns
-      const int u = i / N, v = i % N;
-      double acc = 0;
-      for (int upp = 0; upp < N; ++upp) {
-        const int kk = u - upp + c;
-        if (kk >= 0 && kk < N) acc += (double)t[upp * N + v] * k[kk];
-      }
-      Wf[i] += coef[term] * (float)acc;
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < N * N; i += blockDim.x) Wf[i] = sqrtf(fmaxf(Wf[i], 0.f));
-}
 
 // 1-D starlet cascade of a dirac at the zero-lag index with edge replication: p_j = A_j delta_c.
 static inline void starlet_atoms_1d(int N, int J, std::vector<std::vector<double>> &p) {

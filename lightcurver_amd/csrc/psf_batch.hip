@@ -3,6 +3,9 @@
 #include <cstring>
 
 #include "lbfgs_host.h"
+#include <thread>
+
+#include "noise_host.h"
 #include "noise_kernels.h"
 #include "psf_kernels.h"
 
@@ -18,8 +21,6 @@ struct lc_psf_batch {
   float *o_loss = nullptr, *o_chi2 = nullptr, *o_gstars = nullptr, *o_ggrid = nullptr, *o_gT = nullptr,
         *o_model = nullptr, *o_gmoffat = nullptr;
   float *narrow = nullptr, *full = nullptr, *resid = nullptr, *redchi2 = nullptr;
-  float *atoms = nullptr;  // [J+1][3][N] separable factors of psi_j^2 (noise propagation)
-  float *V = nullptr;      // [F][N*N]
   bool have_W = false;
   float lam_sc = 0.f, lam_hf = 0.f;
   int hist_stride = 0, iters_done = 0;
@@ -171,39 +172,6 @@ __global__ void psf_residual_kernel(int S, int n, const float *data, const float
   if (threadIdx.x == 0) redchi2[f] = (float)(C / (K > 0 ? K : 1.0));
 }
 
-// ---- noise propagation of the chi2 gradient w.r.t. B into starlet space ---------------------------
-// V[u'][v'] = sum_s a_s^2 sum_{u,v} up(w_s)[u][v] phi_y^2(u - u') phi_x^2(v - v')
-__global__ void psf_noise_v_kernel(int S, int n, int ss, const float *wgt, const float *stars, float *V) {
-  const int N = n * ss, f = blockIdx.x;
-  const double c_off = (N % 2 == 0) ? 0.5 : 0.0;
-  const double is2 = 1.0 / ((double)kSigmaG * kSigmaG), nrm = 1.0 / (sqrt(2.0 * M_PI) * kSigmaG);
-  for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
-    const int up = i / N, vp = i % N;
-    double acc = 0;
-    for (int s = 0; s < S; ++s) {
-      const float *st = stars + ((size_t)f * S + s) * 4;
-      const double a = st[0], dx = ss * (double)st[1] + c_off, dy = ss * (double)st[2] + c_off;
-      const int ox = (int)nearbyint(dx), oy = (int)nearbyint(dy);
-      double r = 0;
-      for (int tu = oy - kRg; tu <= oy + kRg; ++tu) {
-        const int u = up + tu;
-        if (u < 0 || u >= N) continue;
-        const double py = nrm * exp(-0.5 * (tu - dy) * (tu - dy) * is2);
-        double rr = 0;
-        for (int tv = ox - kRg; tv <= ox + kRg; ++tv) {
-          const int v = vp + tv;
-          if (v < 0 || v >= N) continue;
-          const double px = nrm * exp(-0.5 * (tv - dx) * (tv - dx) * is2);
-          rr += px * px * wgt[((size_t)f * S + s) * n * n + (size_t)(u / ss) * n + v / ss];
-        }
-        r += py * py * rr;
-      }
-      acc += a * a * r;
-    }
-    V[(size_t)f * N * N + i] = (float)acc;
-  }
-}
-
 typedef void (*psf_kernel_fn)(PsfArgs);
 struct PsfVariant {
   int n, ss;
@@ -353,8 +321,6 @@ int lc_psf_batch_create(lc_ctx *ctx, int F, int S_max, int n, int ss, const floa
   TRY(dmalloc(b, &b->full, F * NN));
   TRY(dmalloc(b, &b->resid, F * S_max * nn));
   TRY(dmalloc(b, &b->redchi2, F));
-  TRY(dmalloc(b, &b->atoms, (size_t)(b->J + 1) * 3 * b->N));
-  TRY(dmalloc(b, &b->V, F * NN));
   TRY(ensure_hist(b, 64));
   // sanitise inputs: non-finite data or weight -> weight 0 (NaN handling of psf_modelling.py:136-140)
   {
@@ -372,7 +338,6 @@ int lc_psf_batch_create(lc_ctx *ctx, int F, int S_max, int n, int ss, const floa
     std::vector<float> norms, atoms;
     starlet_noise_tables(b->N, b->J, norms, atoms);
     TRY(h2d(b, b->norms, norms.data(), norms.size() * sizeof(float)));
-    TRY(h2d(b, b->atoms, atoms.data(), atoms.size() * sizeof(float)));
   }
 #undef TRY
   *out = b;
@@ -436,12 +401,52 @@ int lc_psf_batch_set_regularization(lc_psf_batch *b, const float *W, float lam_s
 }
 int lc_psf_batch_propagate_noise(lc_psf_batch *b) {
   if (!b) return LC_ERR_INVALID;
-  hipLaunchKernelGGL(psf_noise_v_kernel, dim3(b->F), dim3(256), 0, b->ctx->stream, b->S, b->n, b->ss, b->wgt,
-                     b->stars, b->V);
-  // qscratch doubles as the row-pass temporary ([F][J][N*N])
-  hipLaunchKernelGGL(starlet_noise_w_kernel, dim3(b->F, b->J), dim3(256), 0, b->ctx->stream, b->N, b->J, b->V, b->atoms,
-                     b->W, b->qscratch);
-  LC_HIP(b->ctx, hipGetLastError());
+  const int F = b->F, S = b->S, N = b->N, n = b->n, ss = b->ss, J = b->J;
+  const size_t NN = (size_t)N * N, nn = (size_t)n * n;
+  std::vector<float> st((size_t)F * S * 4), w((size_t)F * S * nn);
+  int rc;
+  if ((rc = d2h(b, st.data(), b->stars, st.size() * sizeof(float)))) return rc;
+  if ((rc = d2h(b, w.data(), b->wgt, w.size() * sizeof(float)))) return rc;
+  std::vector<float> Wall((size_t)F * J * NN);
+  // contributor = star of the frame; response of dL/dB to a unit of whitened noise in data pixel p*:
+  //   r_i[u'][v'] = a_i * sum_{(u,v) in block(p*)} phi_y(u - u') phi_x(v - v'),  phi = sampled Gaussian of the star
+  const int T = noise_threads(F);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < T; ++t)
+    pool.emplace_back([&, t]() {
+      std::vector<double> r(NN), py(2 * kRg + 1 + 2), px(2 * kRg + 1 + 2);
+      std::vector<float> Wf((size_t)(J + 1) * NN);
+      const double c_off = (N % 2 == 0) ? 0.5 : 0.0, is2 = 1.0 / ((double)kSigmaG * kSigmaG),
+                   nrm = 1.0 / (std::sqrt(2.0 * M_PI) * kSigmaG);
+      const int b0 = ss * (n / 2);
+      for (int f = t; f < F; f += T) {
+        NoiseAccumulator acc(N, ss);
+        for (int s = 0; s < S; ++s) {
+          const float *sp = &st[((size_t)f * S + s) * 4];
+          const double a = sp[0], dx = ss * (double)sp[1] + c_off, dy = ss * (double)sp[2] + c_off;
+          const int ox = (int)std::nearbyint(dx), oy = (int)std::nearbyint(dy);
+          std::fill(r.begin(), r.end(), 0.0);
+          if (a != 0.0)
+            for (int du = 0; du < ss; ++du)
+              for (int tu = oy - kRg; tu <= oy + kRg; ++tu) {
+                const int up = b0 + du - tu;
+                if (up < 0 || up >= N) continue;
+                const double gy = nrm * std::exp(-0.5 * (tu - dy) * (tu - dy) * is2);
+                for (int dv = 0; dv < ss; ++dv)
+                  for (int tv = ox - kRg; tv <= ox + kRg; ++tv) {
+                    const int vp = b0 + dv - tv;
+                    if (vp < 0 || vp >= N) continue;
+                    r[(size_t)up * N + vp] += a * gy * nrm * std::exp(-0.5 * (tv - dx) * (tv - dx) * is2);
+                  }
+              }
+          acc.add(r, &w[((size_t)f * S + s) * nn]);
+        }
+        acc.finalize(Wf.data());
+        std::memcpy(&Wall[(size_t)f * J * NN], Wf.data(), (size_t)J * NN * sizeof(float));
+      }
+    });
+  for (auto &th : pool) th.join();
+  if ((rc = h2d(b, b->W, Wall.data(), Wall.size() * sizeof(float)))) return rc;
   b->have_W = true;
   return LC_OK;
 }

@@ -1,0 +1,75 @@
+"""Epoch sharding of the joint fit over the GPUs of one node (one process per GPU).
+
+Per-epoch parameters (a, dx, dy, mean) and their optimiser state live only on the rank that owns the
+epoch; the shared parameters (h, c_x, c_y) are replicated.  Each iteration every rank runs the
+forward/backward of its epochs, the shared block
+    [ dL/dh (N^2) | dL/dc_x (M) | dL/dc_y (M) | sum_e a (M) | sum_e a^2 (M) | chi2 | n_epochs ]
+is sum-all-reduced, and every rank applies the identical regularisation + AdaBelief update, so the
+replicas stay in lock step.  The reference has no counterpart: it keeps all epochs in
+one JAX array on one device (lightcurver/processes/roi_modelling.py:154-160,213).
+
+Round 1 stages the block through the host (works with the gloo and the nccl backend alike); the PSF
+fit needs no collective at all (frames shard, see bench.py).
+"""
+import numpy as np
+
+
+def shard_epochs(n_epochs, world_size, rank):
+    """Contiguous block of epochs owned by ``rank``: returns (start, stop)."""
+    if not 0 <= rank < world_size:
+        raise ValueError('rank out of range')
+    base, rem = divmod(int(n_epochs), int(world_size))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def shard_kwargs(flat, n_epochs, n_sources, world_size, rank):
+    """Slice the per-epoch blocks of a flat parameter dict (a is epoch-major) for one rank."""
+    lo, hi = shard_epochs(n_epochs, world_size, rank)
+    out = dict(flat)
+    out['a'] = np.asarray(flat['a']).reshape(n_epochs, n_sources)[lo:hi].reshape(-1)
+    for k in ('dx', 'dy', 'alpha', 'mean'):
+        out[k] = np.asarray(flat[k])[lo:hi]
+    return out
+
+
+class ShardedJointOptimizer:
+    """Drives ``n_iter`` AdaBelief iterations of a sharded joint fit.
+
+    ``local_fit`` is the rank's device object (``lightcurver_amd.joint.JointFit`` over the local epochs) or
+    anything with the same four methods: step_local(), shared_get() -> float array, shared_set(array),
+    step_update(**adabelief_cfg).
+    """
+
+    def __init__(self, local_fit, group=None):
+        self.fit = local_fit
+        self.group = group
+
+    def all_reduce(self, buf):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return buf
+        t = torch.from_numpy(np.ascontiguousarray(buf))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.numpy()
+
+    def run(self, n_iter, **adabelief_cfg):
+        for _ in range(int(n_iter)):
+            self.fit.step_local()
+            self.fit.shared_set(self.all_reduce(self.fit.shared_get()))
+            self.fit.step_update(**adabelief_cfg)
+
+
+def gather_epoch_blocks(local_flat, n_sources, group=None):
+    """All-gather the per-epoch parameters so that every rank holds the full kwargs again."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return dict(local_flat)
+    world = dist.get_world_size(group)
+    out = dict(local_flat)
+    for k in ('a', 'dx', 'dy', 'alpha', 'mean'):
+        parts = [None] * world
+        dist.all_gather_object(parts, np.asarray(local_flat[k]), group=group)
+        out[k] = np.concatenate(parts)
+    return out

@@ -127,6 +127,16 @@ class JointFit:
         self._chk(self._l.lc_joint_shared_buffer_dev(self.h, C.byref(p), C.byref(n)), 'shared_buffer_dev')
         return p.value, n.value
 
+    def shared_get(self):
+        _, n = self.shared_buffer()
+        buf = np.empty(n, np.float32)
+        self._chk(self._l.lc_joint_shared_get(self.h, ptr(buf), n), 'shared_get')
+        return buf
+
+    def shared_set(self, buf):
+        buf = f32(buf)
+        self._chk(self._l.lc_joint_shared_set(self.h, ptr(buf), buf.size), 'shared_set')
+
     def step_update(self, **cfg):
         c = _lib.adabelief_cfg(**cfg)
         self._chk(self._l.lc_joint_step_update(self.h, C.byref(c)), 'step_update')

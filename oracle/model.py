@@ -226,26 +226,48 @@ def deconv_loss(p, data, sigma2, psf, ss, W=None, lam_scales=0.0, lam_hf=0.0, la
     return (total, terms) if parts else total
 
 
-def propagate_noise_deconv(sigma2, psf, ss):
-    """propagate_noise(model, noisemap, ..., method='SLIT', likelihood_type='chi2')[0].
+def _shift_zero(img, sh):
+    """out[..., t] = img[..., t + sh] along the last two axes, zero filled."""
+    out = torch.zeros_like(img)
+    N = img.shape[-1]
+    lo, hi = max(0, -sh), min(N, N - sh)
+    if hi > lo:
+        out[..., lo:hi, lo:hi] = img[..., lo + sh:hi + sh, lo + sh:hi + sh]
+    return out
 
-    Standard deviation, per starlet scale, of the chi2-gradient noise in the h plane:
-      V   = sum_e  adj[x -> conv_same(x, s_e^2)] ( up(1 / sigma_e^2) )
-      W_j = sqrt( conv_same(V, psi_j^2) ),  psi_j = starlet atom of scale j (dirac at the zero-lag index).
-    Returns (J + 1, N, N).
+
+def noise_levels_from_impulse(r, w, ss):
+    """Standard deviation of the chi2-gradient noise in every starlet scale.
+
+    r: (K, N, N) response of the gradient image to a unit of (Sigma^-1 noise) in the central data pixel
+    p* = (n//2, n//2) of contributor k (an epoch, or a star of a frame); w: (K, n, n) its inverse variances.
+    With kappa_{k,j} = starlet(r_k)[j] and shift invariance, the coefficient at x responds to data pixel p
+    with kappa_{k,j}(x - ss p + ss p*), hence
+        W_j(x)^2 = sum_k sum_p w_k[p] kappa_{k,j}(x - ss p + ss p*)^2 = sum_k ( up0(w_k) (*) kappa_{k,j}^2 )(x)
+    (up0 = zero-insertion up-sampling).  Returns (J + 1, N, N).
     """
+    K, N, _ = r.shape
+    n = N // ss
+    J = n_scales(N)
+    kap = starlet(r, J)  # (J + 1, K, N, N)
+    kern = _shift_zero(kap, ss * (n // 2) - cref(N)) ** 2
+    up0 = torch.zeros(K, N, N, dtype=r.dtype)
+    up0[:, ::ss, ::ss] = w
+    lev = conv_same(up0[None].expand(J + 1, K, N, N), kern).sum(dim=1)
+    return torch.sqrt(torch.clamp(lev, min=0.0))
+
+
+def propagate_noise_deconv(sigma2, psf, ss):
+    """propagate_noise(model, noisemap, ..., method='SLIT', likelihood_type='chi2')[0]:
+    noise level of d(chi2/2)/dh per starlet scale, epochs added in quadrature (see
+    noise_levels_from_impulse).  Returns (J + 1, N, N)."""
     E, n, _ = sigma2.shape
     N = ss * n
-    J = n_scales(N)
     x = torch.zeros(E, N, N, dtype=psf.dtype, requires_grad=True)
-    up = upsample_rep(1.0 / sigma2, ss)
-    (V,) = torch.autograd.grad((conv_same(x, psf ** 2) * up).sum(), x)
-    V = V.sum(dim=0)
-    d = torch.zeros(N, N, dtype=psf.dtype)
-    d[cref(N), cref(N)] = 1.0
-    psi = starlet(d, J)
-    lev = conv_same(V[None].expand(J + 1, N, N), psi ** 2)
-    return torch.sqrt(torch.clamp(lev, min=0.0))
+    y = blocksum(conv_same(x, psf), ss)[:, n // 2, n // 2].sum()
+    (r,) = torch.autograd.grad(y, x)
+    w = torch.where(torch.isfinite(sigma2) & (sigma2 > 0), 1.0 / sigma2, torch.zeros_like(sigma2))
+    return noise_levels_from_impulse(r, w, ss)
 
 
 def fisher_flux_sigma(p, sigma2, psf, ss):
@@ -328,22 +350,18 @@ def psf_outputs(p, ss, n):
 
 
 def propagate_noise_psf(p, sigma2, mask, ss):
-    """Noise level of the chi2 gradient w.r.t. the pixel grid B, per starlet scale (J + 1, N, N)."""
+    """Noise level of d(chi2/2)/dB per starlet scale (J + 1, N, N): the stars of the frame add in
+    quadrature, each through the impulse response of its own shifted Gaussian (times its amplitude)."""
     S, n, _ = sigma2.shape
     N = ss * n
-    J = n_scales(N)
     c0 = (N - 1) / 2.0
     X = (c0 + ss * p['x0'])[:, None]
     Y = (c0 + ss * p['y0'])[:, None]
     G = gaussian_stack(N, X, Y, torch.ones(S, 1, dtype=sigma2.dtype))
-    x = torch.zeros(N, N, dtype=sigma2.dtype, requires_grad=True)
-    up = upsample_rep(mask / sigma2, ss) * (p['a'] ** 2)[:, None, None]
-    (V,) = torch.autograd.grad((conv_same(G ** 2, x[None].expand(S, N, N)) * up).sum(), x)
-    d = torch.zeros(N, N, dtype=sigma2.dtype)
-    d[cref(N), cref(N)] = 1.0
-    psi = starlet(d, J)
-    lev = conv_same(V[None].expand(J + 1, N, N), psi ** 2)
-    return torch.sqrt(torch.clamp(lev, min=0.0))
+    x = torch.zeros(S, N, N, dtype=sigma2.dtype, requires_grad=True)
+    y = (p['a'][:, None, None] * blocksum(conv_same(G, x), ss))[:, n // 2, n // 2].sum()
+    (r,) = torch.autograd.grad(y, x)
+    return noise_levels_from_impulse(r, mask / sigma2, ss)
 
 
 def reduced_chi2(data, model, sigma2, mask):

@@ -1,0 +1,182 @@
+"""Host-side logic that needs no GPU: kwargs bookkeeping of the STARRED mirror, priors, initial guesses,
+epoch sharding, and the sharded-optimiser protocol on two gloo ranks with the oracle as the local model."""
+import os
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om, optim as oo
+
+
+def _kwargs(E=3, M=2, N=8):
+    return {'kwargs_analytic': {'a': np.arange(E * M, dtype=float), 'c_x': np.array([1., 2.]), 'c_y': np.array([3., 4.]),
+                                'dx': np.zeros(E), 'dy': np.ones(E), 'alpha': np.zeros(E)},
+            'kwargs_background': {'h': np.zeros(N * N), 'mean': np.zeros(E)}, 'kwargs_sersic': {}}
+
+
+def test_parameters_free_fixed_and_roundtrip():
+    from lightcurver_amd.starred.deconvolution.parameters import ParametersDeconv
+    k = _kwargs()
+    fixed = deepcopy(k)
+    del fixed['kwargs_analytic']['dx']
+    del fixed['kwargs_analytic']['a']
+    p = ParametersDeconv(k, fixed, deepcopy(k), deepcopy(k))
+    assert p.free == ['a', 'dx'] and p.num_parameters == 9
+    x = p.current_values()
+    assert np.array_equal(x, np.concatenate([np.arange(6.), np.zeros(3)]))
+    kw = p.args2kwargs(x + 1)
+    assert np.allclose(kw['kwargs_analytic']['a'], np.arange(6.) + 1) and np.allclose(kw['kwargs_analytic']['dy'], 1)
+    # the kwargs support the in-place manipulations the reference performs (roi_modelling.py:99-103)
+    kw['kwargs_background']['h'] *= 0.0
+    kw['kwargs_analytic']['a'] *= 0.0
+    assert kw['kwargs_analytic']['a'].sum() == 0
+    best = p.best_fit_values(as_kwargs=True)
+    assert set(best) == {'kwargs_analytic', 'kwargs_background', 'kwargs_sersic'}
+    with pytest.raises(NotImplementedError):
+        f2 = deepcopy(k)
+        del f2['kwargs_analytic']['alpha']
+        ParametersDeconv(k, f2)
+
+
+def test_prior_arrays():
+    from lightcurver_amd.starred.deconvolution.loss import Prior
+    pr = Prior(prior_analytic=[['c_x', np.array([1., 2.]), np.array([0.5, 0.5])]])
+    arr = pr.as_arrays(2, [1., 2.], [3., 4.])
+    assert np.allclose(arr['c_x_sigma'], 0.5) and np.all(arr['c_y_sigma'] > 1e12) and np.allclose(arr['c_y_mean'], [3, 4])
+    with pytest.raises(NotImplementedError):
+        Prior(prior_analytic=[['dx', 0., 1.]])
+
+
+def test_initial_positions():
+    from lightcurver_amd.starred.procedures.psf_routines import _initial_positions
+    n = 16
+    yy, xx = np.mgrid[0:n, 0:n]
+    img = np.exp(-0.5 * ((xx - 9.0) ** 2 + (yy - 6.0) ** 2) / 2.0)[None]
+    m = np.ones_like(img)
+    assert _initial_positions(img, m, 'center') == (0.0, 0.0) or np.allclose(_initial_positions(img, m, 'center'), 0)
+    x0, y0 = _initial_positions(img, m, 'barycenter')
+    assert abs(x0[0] - 1.5) < 0.05 and abs(y0[0] + 1.5) < 0.05
+    x0, y0 = _initial_positions(img, m, 'max')
+    assert x0[0] == 1.5 and y0[0] == -1.5
+
+
+def test_epoch_sharding_covers_everything_once():
+    from lightcurver_amd.distributed import shard_epochs, shard_kwargs
+    for E in (1, 7, 200, 1000):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_epochs(E, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == E
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    flat = dict(a=np.arange(12.), c_x=np.zeros(2), c_y=np.zeros(2), dx=np.arange(6.), dy=np.arange(6.), alpha=np.zeros(6),
+                h=np.zeros(4), mean=np.zeros(6))
+    s = shard_kwargs(flat, 6, 2, 2, 1)
+    assert np.array_equal(s['a'], np.arange(6., 12.)) and np.array_equal(s['dx'], [3., 4., 5.])
+
+
+# ---- the sharded optimiser protocol, two gloo ranks, oracle as the local model -------------------------
+class OracleLocalFit:
+    """Same four methods as lightcurver_amd.joint.JointFit (step_local / shared_get / shared_set /
+    step_update) with the float64 oracle doing the arithmetic of the local epochs."""
+
+    def __init__(self, data, sig2, psf, ss, params, lam):
+        self.data, self.sig2, self.psf, self.ss, self.lam = data, sig2, psf, ss, lam
+        self.p = {k: v.clone() for k, v in params.items()}
+        self.E, self.n = data.shape[0], data.shape[-1]
+        self.M = self.p['c_x'].numel()
+        self.N = ss * self.n
+        self.free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean']
+        self.m = {k: torch.zeros_like(self.p[k]) for k in self.free}
+        self.s = {k: torch.zeros_like(self.p[k]) for k in self.free}
+        self.t = 0
+        self.losses = []
+
+    def step_local(self):
+        fn = lambda q: 0.5 * (((self.data - om.deconv_model(q, self.psf, self.ss, self.n)) ** 2) / self.sig2).sum()
+        L, g = oo.value_and_grad(fn, self.p, self.free)
+        self.g = g
+        a2 = self.p['a'].reshape(self.E, self.M)
+        self.shared = torch.cat([g['h'], g['c_x'], g['c_y'], a2.sum(0), (a2 ** 2).sum(0),
+                                 torch.tensor([2 * L, float(self.E)], dtype=om.DT)])
+
+    def shared_get(self):
+        return self.shared.numpy().copy()
+
+    def shared_set(self, buf):
+        self.shared = torch.as_tensor(buf, dtype=om.DT)
+
+    def step_update(self, init_learning_rate=1e-3, **_):
+        NN, M = self.N * self.N, self.M
+        sh = self.shared
+        Etot = float(sh[NN + 4 * M + 1])
+        g = dict(self.g)
+        g['h'], g['c_x'], g['c_y'] = sh[:NN].clone(), sh[NN:NN + M], sh[NN + M:NN + 2 * M]
+        h = self.p['h'].detach().requires_grad_(True)
+        W = om.default_W(self.N, om.n_scales(self.N))
+        reg = om.l1_starlet(h.reshape(self.N, self.N), W, self.lam['sc'], self.lam['hf'], om.n_scales(self.N)) \
+            + self.lam['pos'] * torch.clamp(-h, min=0).sum()
+        (gr,) = torch.autograd.grad(reg, h)
+        g['h'] = g['h'] + gr
+        mean = sh[NN + 2 * M:NN + 3 * M] / Etot
+        var = torch.clamp(sh[NN + 3 * M:NN + 4 * M] / Etot - mean ** 2, min=0)
+        sd = torch.sqrt(var)
+        a2 = self.p['a'].reshape(self.E, M)
+        g['a'] = g['a'] + (self.lam['fu'] * (a2 - mean) / (Etot * sd)).reshape(-1)
+        self.losses.append(0.5 * float(sh[NN + 4 * M]) + float(reg) + self.lam['fu'] * float(sd.sum()))
+        b1, b2, eps, er, t = 0.9, 0.999, 1e-16, 1e-16, self.t
+        for k in self.free:
+            self.m[k] = b1 * self.m[k] + (1 - b1) * g[k]
+            self.s[k] = b2 * self.s[k] + (1 - b2) * (g[k] - self.m[k]) ** 2 + er
+            self.p[k] = self.p[k].detach() - init_learning_rate * (self.m[k] / (1 - b1 ** (t + 1))) / (
+                torch.sqrt(self.s[k] / (1 - b2 ** (t + 1))) + eps)
+        self.t += 1
+
+
+def _problem():
+    from lightcurver_amd.synthetic import make_roi_dataset
+    ds = make_roi_dataset(E=4, M=2, n=8, ss=2, seed=17)
+    rng = np.random.default_rng(3)
+    p = {k: om.T(v) for k, v in ds['truth'].items()}
+    p['a'] = p['a'] * om.T(rng.uniform(0.9, 1.1, p['a'].shape))
+    p['h'] = p['h'] + om.T(1e-3 * rng.standard_normal(p['h'].shape))
+    return ds, p, om.T(ds['data']), om.T(ds['noisemap']) ** 2, om.T(ds['psf'])
+
+
+def _rank_main(rank, world, port, ret):
+    import torch.distributed as dist
+    from lightcurver_amd.distributed import ShardedJointOptimizer, gather_epoch_blocks, shard_epochs, shard_kwargs
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    ds, p, data, sig2, psf = _problem()
+    lo, hi = shard_epochs(4, world, rank)
+    flat = {k: v.numpy() for k, v in p.items()}
+    loc = {k: om.T(v) for k, v in shard_kwargs(flat, 4, 2, world, rank).items()}
+    fit = OracleLocalFit(data[lo:hi], sig2[lo:hi], psf[lo:hi], 2, loc, dict(sc=1.0, hf=1.0, pos=5.0, fu=0.4))
+    ShardedJointOptimizer(fit).run(5, init_learning_rate=1e-3)
+    full = gather_epoch_blocks({k: v.numpy() for k, v in fit.p.items()}, 2)
+    if rank == 0:
+        ret['params'] = full
+        ret['losses'] = fit.losses
+    dist.destroy_process_group()
+
+
+def test_sharded_optimiser_equals_single_rank_gloo():
+    import torch.multiprocessing as mp
+    ds, p, data, sig2, psf = _problem()
+    W = om.default_W(16, 4)
+    fn = lambda q: om.deconv_loss(q, data, sig2, psf, 2, W=W, lam_scales=1.0, lam_hf=1.0, lam_pos=5.0, lam_fu=0.4)
+    pf, lh, l0 = oo.adabelief(fn, p, ['a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean'], 1e-3, 5, schedule=False)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_rank_main, args=(2, port, ret), nprocs=2, join=True)
+    got = ret['params']
+    assert np.allclose(ret['losses'], [l0] + lh[:-1], rtol=1e-9)
+    for k in ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean'):
+        assert np.allclose(got[k], pf[k].numpy(), rtol=1e-7, atol=1e-9), k
+    dh = np.abs(got['h'] - pf['h'].numpy())
+    assert np.median(dh) < 1e-10 and dh.max() < 2.5e-3  # a sign flip of a ~0 gradient moves one pixel by <= 2 lr
