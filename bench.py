@@ -32,12 +32,15 @@ def algorithmic_bytes_per_cutout_iteration(n, ss, S):
     return 8 * n * n + (24 + 4 * J) * N * N / S
 
 
-def cpu_baseline(ds, ss, n_frames=2, n_iter=40):
+def cpu_baseline(ds, ss, n_frames=3, n_iter=100, threads=8):
     """The float64 oracle (kind 'port') timed on the host cores on a bounded sample of the same
-    workload: n_frames frames x S stamps x n_iter AdaBelief iterations of the pixel-grid stage."""
+    workload: n_frames frames x S stamps x n_iter AdaBelief iterations of the pixel-grid stage.
+    torch is limited to `threads` intra-op threads (more only oversubscribes these small FFTs)."""
     import torch
     from oracle import model as om, optim as oo
     from tests import helpers as H
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
     S = ds['data'].shape[1]
     t_total = 0.0
     for f in range(n_frames):
@@ -48,7 +51,7 @@ def cpu_baseline(ds, ss, n_frames=2, n_iter=40):
         t0 = time.perf_counter()
         oo.adabelief(fn, p, ['B', 'a', 'x0', 'y0'], 1e-4, n_iter, schedule=True)
         t_total += time.perf_counter() - t0
-    return dict(value=n_frames * S * n_iter / t_total, unit='cutouts/sec', cores=torch.get_num_threads(),
+    return dict(value=n_frames * S * n_iter / t_total, unit='cutouts/sec', cores=threads,
                 kind='port',
                 sample=f'{n_frames} frames x {S} stamps x {n_iter} AdaBelief iterations of the same C2 data, '
                        'torch float64 oracle')
@@ -135,6 +138,13 @@ def main():
         achieved = F * S * ITERS_PER_STEP * bytes_per / launch_s / 1e9
         N = n * ss
         flops_per = 70.0 * N * N  # separable passes: 35 N^2 MAC per stamp-iteration
+        traffic = None
+        prof = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+        if os.path.exists(prof) and args.config == 'C2':
+            try:
+                traffic = json.load(open(prof)).get('psf_fit_kernel', {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
         out = {
             'metric': 'cutouts/sec (PSF-fit + joint forward-model iter), 32x32 & 64x64 stamps',
             'value': value, 'unit': 'cutouts/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -148,7 +158,8 @@ def main():
                        'setup_seconds_untimed': setup_s, 'loss_finite': finite,
                        'median_reduced_chi2': float(np.median(res['chi2']))},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_source': 'profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch)' if traffic else None,
                          'kernel': 'psf_fit_kernel', 'kernel_ms_per_launch': launch_s * 1e3,
                          'algorithmic_bytes_per_cutout_iteration': bytes_per,
                          'note': 'state is kept on-chip across iterations, so algorithmic bytes/s may exceed '

@@ -191,7 +191,7 @@ __device__ __forceinline__ void starlet_l1_grad(const float img[PX], const float
 #pragma unroll
   for (int p = 0; p < PX; ++p) z[p] = 0.f;
   const int pu_ = pu, pv_ = pv;
-  constexpr bool QREG = (J * PX <= 32);  // sub-gradients stay in registers when they fit
+  constexpr bool QREG = (J * PX <= 64);  // sub-gradients stay in registers when they fit
   constexpr int TSS = StarletLds<N>::TSS;  // 16-byte aligned rows for the forward sweep
   float *fA = lds, *fB = lds + N * TSS;
   float qreg[QREG ? J : 1][PX];
