@@ -188,6 +188,7 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   A.M = j->M;
   A.mode = mode;
   A.t = t;
+  A.ss = j->ss;
   for (int k = 0; k < LC_P_COUNT; ++k) {
     A.free_mask[k] = j->free_mask[k];
     A.par[k] = j->par[k];
@@ -381,7 +382,6 @@ int lc_joint_set_free(lc_joint *j, const int32_t *free_mask) {
 }
 int lc_joint_set_loss(lc_joint *j, const lc_joint_loss_cfg *cfg, const float *W) {
   if (!j || !cfg) return LC_ERR_INVALID;
-  if (cfg->lam_pts_source != 0.f) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "regularization_strength_pts_source is not built yet");
   j->cfg = *cfg;
   j->n_prior = 0;
   if (cfg->n_prior > 0) {

@@ -419,7 +419,7 @@ __global__ void joint_reduce_kernel(int E, int M, int NN, int need_h, const floa
 
 // ---- kernel 3: regularisers, loss, AdaBelief -------------------------------------------------------
 struct JointUpdArgs {
-  int E, M, mode, t, hist_stride;  // mode 1 = update, 0 = gradients only
+  int E, M, mode, t, hist_stride, ss;  // mode 1 = update, 0 = gradients only
   int free_mask[LC_P_COUNT];
   const float *shared;             // reduced (and, multi-GPU, all-reduced) block
   float *h, *mh, *sh;              // [N*N]
@@ -480,6 +480,58 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
       g[p] += (hp[p] < 0.f) ? -A.lam_pos : 0.f;
     }
   }
+  // ---- regularization_strength_pts_source: lam * sum W_0 |starlet_0(Pbar)|, Pbar = sum_i mean_e(a_i) G(c_i)
+  //      (the point-source channel at the target resolution in the reference frame, DESIGN.md SPEC) ----
+  __shared__ float pts_red[NWV * 3 * kMaxSources + 3 * kMaxSources];
+  if (A.lam_pts != 0.f) {
+    const float c0 = (N - 1) * 0.5f, inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm2 = 0.15915494309189535f * inv_s2;
+    float pb[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) pb[p] = 0.f;
+    for (int i = 0; i < M; ++i) {
+      const float abar = A.shared[NN + 2 * M + i] / Etot;
+      const float X = c0 + A.ss * A.par[LC_P_CX][i], Y = c0 + A.ss * A.par[LC_P_CY][i];
+      const float ty = (float)pu - Y;
+#pragma unroll
+      for (int p = 0; p < PX; ++p) {
+        const float tx = (float)(pv + p) - X;
+        pb[p] = fmaf(abar * nrm2, expf(-0.5f * (tx * tx + ty * ty) * inv_s2), pb[p]);
+      }
+    }
+    float zp[PX], l1p = 0.f;
+    __syncthreads();  // the background starlet above is done with the LDS buffers
+    starlet_l1_grad<N, PX, 1>(pb, A.W, A.norms, A.qscr, 0.f, A.lam_pts, lds, tid, l1p, zp);
+    pos += l1p;  // joins the loss through the same reduction
+    for (int i = 0; i < M; ++i) {
+      const float X = c0 + A.ss * A.par[LC_P_CX][i], Y = c0 + A.ss * A.par[LC_P_CY][i];
+      const float ty = (float)pu - Y;
+      float sa = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+      for (int p = 0; p < PX; ++p) {
+        const float tx = (float)(pv + p) - X;
+        const float gq = zp[p] * nrm2 * expf(-0.5f * (tx * tx + ty * ty) * inv_s2);
+        sa += gq;
+        sx = fmaf(gq, tx * inv_s2, sx);
+        sy = fmaf(gq, ty * inv_s2, sy);
+      }
+      sa = wave_sum(sa);
+      sx = wave_sum(sx);
+      sy = wave_sum(sy);
+      if (lane == 0) {
+        pts_red[(wid * kMaxSources + i) * 3 + 0] = sa;
+        pts_red[(wid * kMaxSources + i) * 3 + 1] = sx;
+        pts_red[(wid * kMaxSources + i) * 3 + 2] = sy;
+      }
+    }
+    __syncthreads();
+    if (tid < 3 * M) {
+      const int i = tid / 3, q = tid % 3;
+      float acc = 0.f;
+      for (int w = 0; w < NWV; ++w) acc += pts_red[(w * kMaxSources + i) * 3 + q];
+      pts_red[NWV * 3 * kMaxSources + i * 3 + q] = acc;  // d/d abar_i, d/dX_i / abar_i, d/dY_i / abar_i
+    }
+  }
+  const float *ptsg = pts_red + NWV * 3 * kMaxSources;
   {
     const float s1 = wave_sum(l1), s2 = wave_sum(pos);
     if (lane == 0) {
@@ -553,6 +605,7 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
       const float sd = sqrtf(var);
       if (sd > 0.f) ga += A.lam_fu * (av - mean) / (Etot * sd);
     }
+    if (A.lam_pts != 0.f) ga += ptsg[i * 3] / Etot;
     if (A.mode == 0) {
       if (A.gout[LC_P_A]) A.gout[LC_P_A][idx] = ga;
     } else if (A.free_mask[LC_P_A]) {
@@ -577,6 +630,7 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
     const int which = (tid < M) ? LC_P_CX : LC_P_CY, i = tid % M;
     float gv = A.shared[NN + (which == LC_P_CX ? 0 : M) + i];
     float cv = A.par[which][i];
+    if (A.lam_pts != 0.f) gv += (A.shared[NN + 2 * M + i] / Etot) * A.ss * ptsg[i * 3 + (which == LC_P_CX ? 1 : 2)];
     if (A.n_prior > 0) {
       const float mu = (which == LC_P_CX) ? A.prior_cx_mean[i] : A.prior_cy_mean[i];
       const float sg = (which == LC_P_CX) ? A.prior_cx_sigma[i] : A.prior_cy_sigma[i];

@@ -143,6 +143,25 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
   }
   __syncthreads();
 
+  // Pixel state of this thread.  With <= 8 pixels per thread it stays in registers for the whole launch
+  // (B, both AdaBelief moments and the Moffat): HBM then sees it once per launch instead of per iteration.
+  constexpr bool STATE_REGS = (PX <= 8);
+  float Bp[PX], Mp[PX], Sp_[PX], Tp[PX];
+  {
+    const size_t g0pix = (size_t)f * N * N + (size_t)(tid0 / (N / PX)) * N + (tid0 % (N / PX)) * PX;
+#pragma unroll
+    for (int q = 0; q < PX / 4; ++q) {
+      if (STATE_REGS) {
+        const float4 b = ((const float4 *)(A.B + g0pix))[q], t = ((const float4 *)(A.Tm + g0pix))[q];
+        const float4 m = ((const float4 *)(A.mB + g0pix))[q], sv = ((const float4 *)(A.sB + g0pix))[q];
+        Bp[4 * q] = b.x; Bp[4 * q + 1] = b.y; Bp[4 * q + 2] = b.z; Bp[4 * q + 3] = b.w;
+        Tp[4 * q] = t.x; Tp[4 * q + 1] = t.y; Tp[4 * q + 2] = t.z; Tp[4 * q + 3] = t.w;
+        Mp[4 * q] = m.x; Mp[4 * q + 1] = m.y; Mp[4 * q + 2] = m.z; Mp[4 * q + 3] = m.w;
+        Sp_[4 * q] = sv.x; Sp_[4 * q + 1] = sv.y; Sp_[4 * q + 2] = sv.z; Sp_[4 * q + 3] = sv.w;
+      }
+    }
+  }
+
   for (int it = 0; it < A.n_iter; ++it) {
     const int tglob = A.t0 + it;
     int tid = tid0;
@@ -163,7 +182,10 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     LC_STAMP(0);
     // ---- P1: T = Moffat + B into LDS -----------------------------------------------------
     float gB[PX];
-    {
+    if (STATE_REGS) {
+#pragma unroll
+      for (int p = 0; p < PX; ++p) T[pu * TS + pv + p] = Bp[p] + Tp[p];
+    } else {
       const float4 *bp = (const float4 *)(A.B + gpix);
       const float4 *tp = (const float4 *)(A.Tm + gpix);
 #pragma unroll
@@ -174,9 +196,9 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         T[pu * TS + pv + 4 * q + 2] = b.z + t.z;
         T[pu * TS + pv + 4 * q + 3] = b.w + t.w;
       }
-#pragma unroll
-      for (int p = 0; p < PX; ++p) gB[p] = 0.f;
     }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) gB[p] = 0.f;
     if (tid < S * 5) SGR[tid] = 0.f;
 
     // ---- tap tables of every star of the frame (once per iteration) ----------------------------
@@ -195,6 +217,24 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     for (int g0 = 0; g0 < S; g0 += SG) {
       __syncthreads();  // T and taps visible; previous group's P5 (reads V) done before P2 rewrites R
       LC_STAMP(1 + 5 * (g0 / SG));
+      // data / weights of this group's column-pass pixels: issued now, consumed in P3, so the L2/HBM
+      // latency hides behind the row pass
+      constexpr int NIT3 = (SG * C::IPS_PAD + NTHR - 1) / NTHR;
+      float dpre[NIT3][LC], wpre[NIT3][LC];
+#pragma unroll
+      for (int i3 = 0; i3 < NIT3; ++i3) {
+        const int item0 = wid * 64 + i3 * NTHR, item = item0 + lane;
+        const int sl = item0 / C::IPS_PAD, within = item % C::IPS_PAD, s = g0 + sl;
+        const bool ok = (item0 < SG * C::IPS_PAD) && (s < S) && (within < C::IPS);
+        const int jd = within % n, a0 = (within / n) * LC;
+#pragma unroll
+        for (int j = 0; j < LC; ++j) {
+          const size_t pix = ok ? ((size_t)s * n * n + (size_t)(a0 + j) * n + jd) : 0;
+          const float dv = dataf[pix], wv = wgtf[pix];
+          dpre[i3][j] = ok ? dv : 0.f;
+          wpre[i3][j] = ok ? wv : 0.f;
+        }
+      }
       // ---- P2: row pass (x taps) fused with the column down-sampling ----------------------
       {
         constexpr int WL = SS * (LR - 1) + NT;
@@ -240,7 +280,10 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       {
         constexpr int WL = SS * (LC - 1) + NT;
         constexpr int NSTRIP = n / LC;
-        for (int item0 = wid * 64; item0 < SG * C::IPS_PAD; item0 += NTHR) {
+#pragma unroll
+        for (int i3 = 0; i3 < NIT3; ++i3) {
+          const int item0 = wid * 64 + i3 * NTHR;
+          if (item0 >= SG * C::IPS_PAD) break;
           const int item = item0 + lane;
           const int sl = item0 / C::IPS_PAD;  // wave-uniform
           const int within = item % C::IPS_PAD;
@@ -282,7 +325,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
               }
               const int id = a0 + j;
               const size_t pix = (size_t)s * n * n + (size_t)id * n + jd;
-              const float d = dataf[pix], w = wgtf[pix];
+              const float d = dpre[i3][j], w = wpre[i3][j];
               const float model = fmaf(amp, fv, sky);
               const float res = model - d;
               const float rw = w * res;
@@ -401,14 +444,19 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     for (int p = 0; p < PX; ++p) z[p] = 0.f;
     if (A.lam_sc != 0.f || A.lam_hf != 0.f) {
       float bpix[PX];
-      const float4 *bp = (const float4 *)(A.B + gpix);
+      if (STATE_REGS) {
 #pragma unroll
-      for (int q = 0; q < PX / 4; ++q) {
-        const float4 b = bp[q];
-        bpix[4 * q] = b.x;
-        bpix[4 * q + 1] = b.y;
-        bpix[4 * q + 2] = b.z;
-        bpix[4 * q + 3] = b.w;
+        for (int p = 0; p < PX; ++p) bpix[p] = Bp[p];
+      } else {
+        const float4 *bp = (const float4 *)(A.B + gpix);
+#pragma unroll
+        for (int q = 0; q < PX / 4; ++q) {
+          const float4 b = bp[q];
+          bpix[4 * q] = b.x;
+          bpix[4 * q + 1] = b.y;
+          bpix[4 * q + 2] = b.z;
+          bpix[4 * q + 3] = b.w;
+        }
       }
       starlet_l1_grad<N, PX>(bpix, A.W ? A.W + (size_t)f * J * N * N : nullptr, A.norms,
                              A.qscratch + (size_t)f * J * N * N, A.lam_sc, A.lam_hf, lds, tid, l1, z);
@@ -442,11 +490,23 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     if (A.mode == 1) {
       const float lr = SCAL[0], bc1 = SCAL[1], bc2 = SCAL[2];
       const float b1 = A.ab.b1, b2 = A.ab.b2, eps = A.ab.eps, eps_root = A.ab.eps_root;
+      if (STATE_REGS) {
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+          const float g = gB[p] + z[p];
+          const float mn = b1 * Mp[p] + (1.f - b1) * g;
+          const float dg = g - mn;
+          const float sn = b2 * Sp_[p] + (1.f - b2) * dg * dg + eps_root;
+          Mp[p] = mn;
+          Sp_[p] = sn;
+          Bp[p] -= lr * (mn * bc1) / (sqrtf(sn * bc2) + eps);
+        }
+      }
       float4 *bp = (float4 *)(A.B + gpix);
       float4 *mp = (float4 *)(A.mB + gpix);
       float4 *sp = (float4 *)(A.sB + gpix);
 #pragma unroll
-      for (int q = 0; q < PX / 4; ++q) {
+      for (int q = 0; q < (STATE_REGS ? 0 : PX / 4); ++q) {
         float4 b = bp[q], m = mp[q], s = sp[q];
         float *bb = &b.x, *mm = &m.x, *ss_ = &s.x;
 #pragma unroll
@@ -478,6 +538,15 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     LC_STAMP(43);
   }  // iterations
 
+  if (A.mode == 1 && STATE_REGS) {
+    const size_t g0pix = (size_t)f * N * N + (size_t)(tid0 / (N / PX)) * N + (tid0 % (N / PX)) * PX;
+#pragma unroll
+    for (int q = 0; q < PX / 4; ++q) {
+      ((float4 *)(A.B + g0pix))[q] = make_float4(Bp[4 * q], Bp[4 * q + 1], Bp[4 * q + 2], Bp[4 * q + 3]);
+      ((float4 *)(A.mB + g0pix))[q] = make_float4(Mp[4 * q], Mp[4 * q + 1], Mp[4 * q + 2], Mp[4 * q + 3]);
+      ((float4 *)(A.sB + g0pix))[q] = make_float4(Sp_[4 * q], Sp_[4 * q + 1], Sp_[4 * q + 2], Sp_[4 * q + 3]);
+    }
+  }
   if (A.mode == 1 && tid0 < S * 4) {
     A.stars[(size_t)f * S * 4 + tid0] = SP[tid0];
     A.stars_m[(size_t)f * S * 4 + tid0] = SM[tid0];

@@ -15,7 +15,7 @@ namespace lc {
 #define LC_LAUNDER(x) asm volatile("" : "+v"(x))
 #endif
 
-__device__ inline float wave_sum(float v) {
+__device__ inline float wave_sum_shfl(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
@@ -43,6 +43,18 @@ __device__ __forceinline__ float line_sum(float v) {
   if constexpr (LPR >= 8) v = dpp_add<0x141>(v);   // row_half_mirror
   if constexpr (LPR >= 16) v = dpp_add<0x140>(v);  // row_mirror
   return v;
+}
+
+// Sum over the 64 lanes of the wave (valid in every lane): DPP butterflies inside each row of 16 lanes,
+// then the four row totals through scalar broadcasts.  All lanes must be active.
+__device__ __forceinline__ float wave_sum(float v) {
+  v = line_sum<16>(v);
+  const int iv = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 // Zero-filling DPP lane shifts inside one image line (LPR consecutive lanes, LPR | 16).
@@ -178,11 +190,11 @@ struct StarletLds {
 // Wf: [J][N*N] weights or null (then norms[j] is used); qscr: [J][N*N] thread-private scratch, only
 // touched when the sub-gradients do not fit in registers.  All N*N/PX threads of the block must call.
 // On return l1 holds this thread's share of the value and z[PX] the sub-gradient at its pixels.
-template <int N, int PX>
+template <int N, int PX, int JUSE = ilog2(N)>
 __device__ __forceinline__ void starlet_l1_grad(const float img[PX], const float *Wf, const float *norms, float *qscr,
                                                 float lam_sc, float lam_hf, float *lds, int tid, float &l1,
                                                 float z[PX]) {
-  constexpr int J = ilog2(N);
+  constexpr int J = JUSE;  // detail scales entering the penalty (the PSF / background terms use all of them)
   constexpr int TS = StarletLds<N>::TS;
   float *bufA = lds, *bufB = lds + N * TS;
   const int pu = tid / (N / PX);

@@ -1,0 +1,145 @@
+"""Joint modelling of the ROI cutouts: the arithmetic core of the reference's
+lightcurver/processes/roi_modelling.py:198-335 (two-stage fit) and :450-474 (fluxes, uncertainties,
+per-frame chi2), restated on the GPU STARRED mirror and taking arrays instead of the HDF5 / WCS /
+config plumbing (which stays with the caller: SURVEY.md section 2 rows 6, 16, 17 are out of scope).
+
+Stage 1 (roi_modelling.py:259-282): only the per-epoch translations and fluxes are free, L-BFGS-B,
+flux-scatter regularisation.  Stage 2 (:284-335): background (optional), per-epoch constants, fluxes,
+astrometry and translations, AdaBelief with the starlet-regularised background.
+"""
+import warnings
+from copy import deepcopy
+
+import numpy as np
+
+from ..starred.deconvolution.deconvolution import setup_model
+from ..starred.deconvolution.loss import Loss, Prior
+from ..starred.deconvolution.parameters import ParametersDeconv
+from ..starred.optim.optimization import Optimizer
+from ..starred.utils.noise_utils import propagate_noise
+from ..utilities.starred_utilities import get_flux_uncertainties
+
+DEFAULT_REGULARIZATION = {  # code fall-backs of the reference (roi_modelling.py:273,308-312)
+    'regularization_scatter_fluxes_pre_optim': 10.0,
+    'regularization_strength_scales': 1.0,
+    'regularization_strength_hf': 1.0,
+    'regularization_strength_positivity': 100.0,
+    'regularization_strength_pts_source': 0.01,
+    'regularization_scatter_fluxes_main_optim': 10.0,
+}
+
+
+def initial_point_source_fluxes(data, xs, ys, radius):
+    """Aperture sums on the median stack (roi_modelling.py:198-204 uses photutils' exact circular
+    apertures; this is the pixel-centre version, good enough for a starting point)."""
+    stack = np.nanmedian(data, axis=0)
+    n = stack.shape[0]
+    yy, xx = np.mgrid[0:n, 0:n]
+    return [float(np.nansum(stack[(xx - x) ** 2 + (yy - y) ** 2 <= radius ** 2])) for x, y in zip(xs, ys)]
+
+
+def model_roi_cutouts(data, noisemap, psf, subsampling_factor, xs_pixels, ys_pixels, angles_to_north=None,
+                      initial_a=None, aperture_radius=3.0, fix_point_source_astrometry=False,
+                      starting_background=None, further_optimize_background=True, regularization=None,
+                      roi_deconv_translations_iters=300, roi_deconv_all_iters=2000, rescale=True):
+    """data, noisemap (E, n, n); psf (E, N, N); xs_pixels, ys_pixels: point-source positions in pixels of
+    the first epoch (0-based, as astropy's world_to_pixel returns them).
+
+    Returns a dict: kwargs_final, kwargs_stage1, loss_history (stage 2), loss_history_stage1, scale, model,
+    and the pieces needed downstream (model object, kwargs_up / kwargs_down).
+    """
+    reg = dict(DEFAULT_REGULARIZATION)
+    reg.update(regularization or {})
+    data = np.array(data, dtype=np.float64)
+    noisemap = np.array(noisemap, dtype=np.float64)
+    scale = float(np.nanmax(data)) if rescale else 1.0
+    data /= scale
+    noisemap /= scale
+    E, n, _ = data.shape
+    xs = np.atleast_1d(np.asarray(xs_pixels, dtype=np.float64))
+    ys = np.atleast_1d(np.asarray(ys_pixels, dtype=np.float64))
+    M = xs.size
+    if angles_to_north is None:
+        angles = np.zeros(E)
+    else:
+        angles = np.asarray(angles_to_north, dtype=np.float64) - float(np.asarray(angles_to_north)[0])
+    if initial_a is None:
+        initial_a = initial_point_source_fluxes(data, xs, ys, aperture_radius)
+    offset = (n - 1) / 2.0  # STARRED's origin is the stamp centre
+    c_x0, c_y0 = xs - offset, ys - offset
+    model, k_init, k_up, k_down, _ = setup_model(data, noisemap ** 2, psf, c_x0, c_y0, subsampling_factor,
+                                                 E * list(initial_a))
+    k_init['kwargs_analytic']['alpha'] = angles
+
+    prior = None
+    fix_astrometry = fix_point_source_astrometry
+    if isinstance(fix_astrometry, float):
+        prior = Prior(prior_analytic=[['c_x', c_x0, np.full(M, fix_astrometry)], ['c_y', c_y0, np.full(M, fix_astrometry)]])
+    h_fixed_to_start = starting_background is not None
+    if h_fixed_to_start:
+        k_init['kwargs_background']['h'] = np.asarray(starting_background, dtype=np.float64).ravel() / scale
+
+    # ---- stage 1: translations + fluxes --------------------------------------------------------------
+    fixed = deepcopy(k_init)
+    for name in ('dx', 'dy', 'a'):
+        del fixed['kwargs_analytic'][name]
+    pars = ParametersDeconv(kwargs_init=k_init, kwargs_fixed=fixed, kwargs_up=k_up, kwargs_down=k_down)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        loss = Loss(data, model, pars, noisemap ** 2, prior=prior,
+                    regularization_strength_flux_uniformity=reg['regularization_scatter_fluxes_pre_optim'])
+    optim1 = Optimizer(loss, pars, method='l-bfgs-b')
+    optim1.minimize(maxiter=int(roi_deconv_translations_iters))
+    k_stage1 = deepcopy(pars.best_fit_values(as_kwargs=True))
+
+    # ---- stage 2: everything (but the rotation) --------------------------------------------------------
+    fixed = deepcopy(k_stage1)
+    if further_optimize_background:
+        del fixed['kwargs_background']['h']
+    del fixed['kwargs_background']['mean']
+    for name in ('a', 'c_x', 'c_y', 'dx', 'dy'):
+        del fixed['kwargs_analytic'][name]
+    if isinstance(fix_astrometry, bool) and fix_astrometry:
+        fixed['kwargs_analytic']['c_x'] = c_x0
+        fixed['kwargs_analytic']['c_y'] = c_y0
+    W = propagate_noise(model, noisemap, k_init, wavelet_type_list=['starlet'], method='SLIT', num_samples=500, seed=1,
+                        likelihood_type='chi2', verbose=False, upsampling_factor=subsampling_factor)[0]
+    pars = ParametersDeconv(kwargs_init=k_stage1, kwargs_fixed=fixed, kwargs_up=k_up, kwargs_down=k_down)
+    loss = Loss(data, model, pars, noisemap ** 2, regularization_terms='l1_starlet',
+                regularization_strength_scales=reg['regularization_strength_scales'],
+                regularization_strength_hf=reg['regularization_strength_hf'],
+                regularization_strength_positivity=reg['regularization_strength_positivity'],
+                regularization_strength_pts_source=reg['regularization_strength_pts_source'],
+                regularization_strength_flux_uniformity=reg['regularization_scatter_fluxes_main_optim'],
+                W=W, prior=prior)
+    optim2 = Optimizer(loss, pars, method='adabelief')
+    optim2.minimize(max_iterations=int(roi_deconv_all_iters), init_learning_rate=1e-4, schedule_learning_rate=False,
+                    restart_from_init=False, stop_at_loss_increase=False, progress_bar=True, return_param_history=True)
+    k_final = deepcopy(pars.best_fit_values(as_kwargs=True))
+    # position of the sources in the first epoch, back in pixels (roi_modelling.py:339-340)
+    x_pix = np.array(k_final['kwargs_analytic']['c_x']) + np.array(k_final['kwargs_analytic']['dx'])[0] + offset
+    y_pix = np.array(k_final['kwargs_analytic']['c_y']) + np.array(k_final['kwargs_analytic']['dy'])[0] + offset
+    return dict(kwargs_final=k_final, kwargs_stage1=k_stage1, loss_history=optim2.loss_history,
+                loss_history_stage1=optim1.loss_history, scale=scale, model=model, kwargs_up=k_up, kwargs_down=k_down,
+                data=data, noisemap=noisemap, x_pixels=x_pix, y_pixels=y_pix, W=W)
+
+
+def fluxes_from_model(model, kwargs, kwargs_up, kwargs_down, data, noisemap, n_sources, model_scale,
+                      normalization_errors):
+    """Numeric part of get_fluxes_dataframe_from_model (roi_modelling.py:450-474): per-source light
+    curves (a is epoch-major: curve i = a[i::M]), their uncertainties (Fisher 1-sigma compounded with the
+    frame normalisation error), residuals and the per-frame reduced chi2."""
+    a = np.array(kwargs['kwargs_analytic']['a'])
+    sigma_a = np.array(get_flux_uncertainties(kwargs=kwargs, kwargs_up=kwargs_up, kwargs_down=kwargs_down,
+                                              data=data, noisemap=noisemap, model=model))
+    norm_err = np.asarray(normalization_errors, dtype=np.float64)
+    curves, d_curves = [], []
+    for i in range(n_sources):
+        curve = a[i::n_sources] * model_scale
+        photon = sigma_a[i::n_sources] * model_scale
+        curves.append(curve)
+        d_curves.append(np.sqrt(photon ** 2 + (norm_err * curve) ** 2))
+    residuals = data - model.model(kwargs)
+    chi2_per_frame = np.nansum(residuals ** 2 / noisemap ** 2, axis=(1, 2)) / model.image_size ** 2
+    return dict(fluxes=np.array(curves), d_fluxes=np.array(d_curves), residuals=residuals,
+                reduced_chi2=np.array(chi2_per_frame))

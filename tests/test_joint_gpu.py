@@ -51,10 +51,10 @@ def test_model_loss_and_gradients(ctx, E, M, n, ss, alpha):
     ds, j, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 100 + n + M, alpha_sigma=alpha)
     N = n * ss
     W = om.propagate_noise_deconv(sig2, psf, ss)
-    lam = dict(lam_scales=1.5, lam_hf=0.8, lam_pos=20.0, lam_pos_ps=5.0, lam_fu=0.7)
+    lam = dict(lam_scales=1.5, lam_hf=0.8, lam_pos=20.0, lam_pos_ps=5.0, lam_fu=0.7, lam_pts=0.3)
     prior = [('c_x', po['c_x'] + 0.05, np.full(M, 0.5)), ('c_y', po['c_y'] - 0.02, np.full(M, 0.7))]
     j.set_loss(W=W.numpy(), lam_scales=1.5, lam_hf=0.8, lam_positivity=20.0, lam_positivity_ps=5.0,
-               lam_flux_uniformity=0.7,
+               lam_flux_uniformity=0.7, lam_pts_source=0.3,
                prior=dict(c_x_mean=prior[0][1].numpy(), c_x_sigma=prior[0][2], c_y_mean=prior[1][1].numpy(),
                           c_y_sigma=prior[1][2]))
     j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean'])

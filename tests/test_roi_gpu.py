@@ -1,0 +1,73 @@
+"""The two-stage ROI fit (reference roi_modelling.py:198-335) end to end on synthetic cutouts: recovers
+the light curves, astrometry and background of the simulated scene, with the default regularisation of
+the reference's config (pts_source term included)."""
+import numpy as np
+import pytest
+
+from lightcurver_amd.synthetic import make_roi_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_stage_roi_fit_recovers_light_curves():
+    from lightcurver_amd.processes.roi_modelling import fluxes_from_model, model_roi_cutouts
+    E, M, n, ss = 24, 2, 32, 2
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=77)
+    t = ds['truth']
+    off = (n - 1) / 2.0
+    rng = np.random.default_rng(0)
+    out = model_roi_cutouts(ds['data'] * ds['scale'], ds['noisemap'] * ds['scale'], ds['psf'], ss,
+                            t['c_x'] + off + rng.normal(0, 0.3, M), t['c_y'] + off + rng.normal(0, 0.3, M),
+                            angles_to_north=np.zeros(E), fix_point_source_astrometry=2.0,
+                            regularization={'regularization_scatter_fluxes_pre_optim': 1.0,
+                                            'regularization_scatter_fluxes_main_optim': 0.0},
+                            roi_deconv_translations_iters=300, roi_deconv_all_iters=1500)
+    k = out['kwargs_final']
+    assert len(out['loss_history']) == 1500 and np.all(np.isfinite(out['loss_history']))
+    assert out['loss_history'][-1] < out['loss_history'][0]
+    res = fluxes_from_model(out['model'], k, out['kwargs_up'], out['kwargs_down'], out['data'], out['noisemap'], M,
+                            out['scale'], np.full(E, 0.01))
+    assert res['fluxes'].shape == (M, E) and res['d_fluxes'].shape == (M, E)
+    assert np.median(res['reduced_chi2']) < 2.0  # acceptance criterion of the reference's integration test
+    truth = (t['a'] * ds['scale']).reshape(E, M).T
+    rel = np.abs(res['fluxes'] - truth) / truth
+    # stage 1 runs with h = 0, so the fluxes absorb part of the background; with the reference's stage-2
+    # settings (lr 1e-4, no schedule) they can only travel ~0.15 back: this bounds the recipe, not the kernels
+    assert np.median(rel) < 0.35
+    # the sinusoidal variability of each source is recovered (shape of the light curve)
+    for i in range(M):
+        cc = np.corrcoef(res['fluxes'][i], truth[i])[0, 1]
+        assert cc > 0.5, cc
+    assert np.all(res['d_fluxes'] > 0)
+
+
+def test_shifts_and_fluxes_recovered_without_background():
+    """Clean problem (one point source, no background): the L-BFGS-B stage driven by device loss/gradient
+    recovers the per-epoch translations and fluxes of the simulation."""
+    from lightcurver_amd.starred.deconvolution.deconvolution import setup_model
+    from lightcurver_amd.starred.deconvolution.loss import Loss
+    from lightcurver_amd.starred.deconvolution.parameters import ParametersDeconv
+    from lightcurver_amd.starred.optim.optimization import Optimizer
+    from copy import deepcopy
+    import warnings
+    E, M, n, ss = 12, 1, 16, 2
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=5, with_background=False)
+    t = ds['truth']
+    data, noise = ds['data'].astype(np.float64), ds['noisemap'].astype(np.float64)
+    model, k_init, k_up, k_down, _ = setup_model(data, noise ** 2, ds['psf'], t['c_x'], t['c_y'], ss,
+                                                 list(np.full(E, 0.7 * t['a'].mean())))
+    fixed = deepcopy(k_init)
+    for name in ('dx', 'dy', 'a'):
+        del fixed['kwargs_analytic'][name]
+    pars = ParametersDeconv(k_init, fixed, k_up, k_down)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        loss = Loss(data, model, pars, noise ** 2)
+    optim = Optimizer(loss, pars, method='l-bfgs-b')
+    optim.minimize(maxiter=200)
+    k = pars.best_fit_values(as_kwargs=True)
+    assert np.abs(np.array(k['kwargs_analytic']['dx']) - t['dx']).max() < 0.08  # photon-noise limited
+    assert np.abs(np.array(k['kwargs_analytic']['dy']) - t['dy']).max() < 0.08
+    assert np.abs(np.array(k['kwargs_analytic']['a']) / t['a'] - 1).max() < 0.05
+    chi2 = np.sum((data - model.model(k)) ** 2 / noise ** 2, axis=(1, 2)) / n ** 2
+    assert 0.7 < chi2.mean() < 1.3
