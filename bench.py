@@ -57,6 +57,39 @@ def cpu_baseline(ds, ss, n_frames=3, n_iter=100, threads=8):
                        'torch float64 oracle')
 
 
+def joint_fit_secondary(ctx, iters=100):
+    """Secondary figure (not the contract metric): joint ROI forward-model iterations of BASELINE.json
+    configs[3] (C4: 200 epochs, 64x64 ROI, 2 point sources + starlet-regularised background) on this GPU."""
+    from lightcurver_amd.joint import JointFit
+    from lightcurver_amd.synthetic import make_roi_dataset
+    E, n, M, ss = 200, 64, 2, 2
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=104)
+    j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
+    p = dict(ds['truth'])
+    p['a'] = p['a'] * 0.9
+    j.set_params(**p)
+    W = j.propagate_noise()
+    j.set_loss(W=W, lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0)
+    j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
+    ab = dict(init_learning_rate=1e-4, schedule_learning_rate=False)
+    j.run_adabelief(5, **ab)
+    ctx.synchronize()
+    ctx.timer_start()
+    j.run_adabelief(iters, **ab)
+    ms = ctx.timer_stop()
+    hist = j.loss_history()
+    N = n * ss
+    J = int(math.log2(N))
+    bytes_per = 8 * n * n + 4 * N * N + (24 + 4 * J) * N * N / E
+    rate = E * iters / (ms * 1e-3)
+    j.close()
+    return {'workload': f'C4: {E} epochs x {n}x{n} ROI, {M} point sources + background, all parameters free, '
+                        f'{iters} AdaBelief iterations (3 launches per iteration)',
+            'cutouts_per_sec': rate, 'us_per_iteration': ms * 1e3 / iters,
+            'algorithmic_bytes_per_cutout_iteration': bytes_per,
+            'hbm_roofline_frac': rate * bytes_per / 1e9 / HBM_PEAK_GBS, 'loss_finite': bool(np.all(np.isfinite(hist)))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -64,6 +97,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-joint', action='store_true', help='skip the secondary joint-fit figure')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -167,6 +201,11 @@ def main():
                          'fp32_valu_tflops': F * S * ITERS_PER_STEP * flops_per / launch_s / 1e12,
                          'fp32_valu_frac_of_157': F * S * ITERS_PER_STEP * flops_per / launch_s / 1e12 / 157.3},
         }
+        if world == 1 and not args.no_joint:
+            try:
+                out['config']['joint_fit'] = joint_fit_secondary(ctx)
+            except Exception as e:
+                out['config']['joint_fit'] = {'error': repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out['cpu_baseline'] = cpu_baseline(ds, ss)

@@ -56,23 +56,23 @@ typedef void (*update_fn)(JointUpdArgs);
 struct JointVariant {
   int n, ss, L;
   epoch_fn ek;
-  int e_lds;
+  int e_lds, e_thr;
   update_fn uk;
   int u_thr, u_lds;
 };
-template <int N, int SS, int L, int PX>
+template <int N, int SS, int L, int PX, int NW>
 JointVariant make_jv() {
-  typedef JointCfg<N, SS, L> C;
-  return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, joint_update_kernel<N, PX>, N * N / PX,
+  typedef JointCfg<N, SS, L, NW> C;
+  return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, joint_update_kernel<N, PX>, N * N / PX,
                       (int)(StarletLds<N>::FLOATS * sizeof(float))};
 }
 const JointVariant *find_jv(int n, int ss) {
   static const JointVariant table[] = {
-      make_jv<16, 1, 32, 4>(),     // n = 16, ss = 1 (reference test fixture)
-      make_jv<32, 2, 64, 4>(),     // n = 16, ss = 2
-      make_jv<48, 2, 128, 4>(),    // n = 24 (default stamp_size_stars)
-      make_jv<64, 2, 128, 8>(),    // n = 32 (default stamp_size_ROI)
-      make_jv<128, 2, 256, 16>(),  // n = 64 (C4)
+      make_jv<16, 1, 32, 4, 8>(),     // n = 16, ss = 1 (reference test fixture)
+      make_jv<32, 2, 64, 4, 16>(),     // n = 16, ss = 2
+      make_jv<48, 2, 128, 4, 16>(),    // n = 24 (default stamp_size_stars)
+      make_jv<64, 2, 128, 8, 16>(),    // n = 32 (default stamp_size_ROI)
+      make_jv<128, 2, 256, 16, 6>(),  // n = 64 (C4)
   };
   for (const auto &v : table)
     if (v.n == n && v.ss == ss) return &v;
@@ -167,7 +167,7 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   A.model_out = model_out;
   A.fisher_out = j->fisher;
   LC_HIP(j->ctx, hipFuncSetAttribute((const void *)v->ek, hipFuncAttributeMaxDynamicSharedMemorySize, v->e_lds));
-  hipLaunchKernelGGL(v->ek, dim3(j->E), dim3(256), v->e_lds, j->ctx->stream, A);
+  hipLaunchKernelGGL(v->ek, dim3(j->E), dim3(v->e_thr), v->e_lds, j->ctx->stream, A);
   LC_HIP(j->ctx, hipGetLastError());
   return A.need_hgrad;
 }

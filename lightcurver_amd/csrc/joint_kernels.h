@@ -53,10 +53,10 @@ __device__ __forceinline__ float bilinear_h(const float *h, float Xs, float Ys, 
   return top + fy * (bot - top);
 }
 
-template <int N_, int SS_, int L_>
+template <int N_, int SS_, int L_, int NW_>
 struct JointCfg {
   static constexpr int N = N_, SS = SS_, L = L_, n = N / SS;
-  static constexpr int NTHR = 256, NW = 4;
+  static constexpr int NW = NW_, NTHR = 64 * NW_;  // waves per epoch workgroup: as many as the LDS workspace allows
   static constexpr int KH = L / 2 + 1;           // stored spectrum columns
   static constexpr int OFF_SPEC = 0;             // float2 units
   static constexpr int SZ_SPEC = N * KH;
@@ -65,7 +65,7 @@ struct JointCfg {
   static constexpr int OFF_TW = OFF_WS + SZ_WS;
   static constexpr int SZ_TW = L / 2;
   static constexpr int OFF_RED = OFF_TW + SZ_TW;  // float2 units; reduction scratch as floats
-  static constexpr int SZ_RED = NW * (4 + 3 * kMaxSources) / 2 + 8;
+  static constexpr int SZ_RED = (NW * (4 + 3 * kMaxSources) + 1) / 2 + 8;
   static constexpr int LDS_BYTES = (OFF_RED + SZ_RED) * 8;
   static constexpr int CREF = (N - 1) / 2;
   static_assert(N % 2 == 0, "row pairs");
@@ -234,7 +234,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     if (lane == 0) RED[wid] = v0;
     __syncthreads();
     if (tid == 0) {
-      const float s = (RED[0] + RED[1]) + (RED[2] + RED[3]);
+      float s = 0.f;
+      for (int w = 0; w < C::NW; ++w) s += RED[w];
       if (A.mode == 2) A.fisher_out[e * M + A.isrc] = 1.0f / sqrtf(s);
       else A.chi2_e[e] = s;
     }
@@ -329,7 +330,11 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     __syncthreads();
     if (tid == 0) {
       float t[NQ];
-      for (int q = 0; q < NQ; ++q) t[q] = (RED[q] + RED[NQ + q]) + (RED[2 * NQ + q] + RED[3 * NQ + q]);
+      for (int q = 0; q < NQ; ++q) {
+        float acc = 0.f;
+        for (int w = 0; w < C::NW; ++w) acc += RED[w * NQ + q];
+        t[q] = acc;
+      }
       A.chi2_e[e] = t[0];
       A.g_mean[e] = t[1];
       float gdx = t[2], gdy = t[3];
@@ -358,6 +363,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       const float rx = (float)kx - c0, ry = (float)ky - c0;
       const float px = c0 + (ca * rx - sa * ry) + sdx, py = c0 + (sa * rx + ca * ry) + sdy;
       int vlo = (int)floorf(px) - 1, vhi = vlo + 3, ulo = (int)floorf(py) - 1, uhi = ulo + 3;
+      if (sa == 0.f) {  // pure translation: only the two samples on either side can touch pixel k
+        vlo += 1;
+        vhi = vlo + 1;
+        ulo += 1;
+        uhi = ulo + 1;
+      }
       if (kx == 0) { vlo = min(vlo, 0); ulo -= mext; uhi += mext; }
       if (kx == N - 1) { vhi = max(vhi, N - 1); ulo -= mext; uhi += mext; }
       if (ky == 0) { ulo = min(ulo, 0); vlo -= mext; vhi += mext; }

@@ -1,0 +1,69 @@
+"""Array-level restatement of the per-frame work of the reference's ``model_all_psfs``
+(lightcurver/processes/psf_modelling.py:126-160 stamp preparation, :164-171 PSF build, :177-180 and
+:205-208 quality numbers) with the whole list of frames fitted in one device batch.  Reading the stamps
+from regions.h5, source masking with ``sep`` (:35-61), plots and the sqlite bookkeeping stay with the
+caller (out of scope)."""
+import numpy as np
+
+from ..starred.procedures.psf_routines import build_psf_batch
+
+
+def prepare_psf_stamps(datas, noisemaps, cosmics_masks, automatic_masks=None, mask_threshold_fraction=0.4):
+    """Masks and clean-up of one frame's star stamps.
+
+    cosmics_masks: True where a cosmic / bad pixel was flagged (as stored in regions.h5);
+    automatic_masks: True for good pixels (neighbouring objects masked out), optional.
+    Returns (datas, noisemaps, masks, keep): arrays restricted to the stamps that survive the
+    more-than-40 %-masked cut (psf_modelling.py:144-153), masks True = usable pixel, keep = boolean selector.
+    """
+    datas = np.array(datas, dtype=np.float64)
+    noisemaps = np.array(noisemaps, dtype=np.float64)
+    good = ~np.asarray(cosmics_masks, dtype=bool)
+    if automatic_masks is not None:
+        good = good & np.asarray(automatic_masks, dtype=bool)
+    both_nan = np.isnan(datas) & np.isnan(noisemaps)
+    datas[both_nan] = 0.0
+    noisemaps[both_nan] = 1.0
+    good[both_nan] = False
+    n_masked = np.sum(~good, axis=(1, 2))
+    keep = ~(n_masked > mask_threshold_fraction * datas.shape[1] * datas.shape[2])
+    return datas[keep], noisemaps[keep], good[keep], keep
+
+
+def relative_loss_differential(loss_history):
+    """(max - min of the last 10 %) / (max - min of the first 90 %) of the loss curve (:205-208)."""
+    lh = np.asarray(loss_history, dtype=np.float64)
+    cut = int(0.9 * lh.size)
+    start = np.nanmax(lh[:cut]) - np.nanmin(lh[:cut])
+    end = np.nanmax(lh[cut:]) - np.nanmin(lh[cut:])
+    return float(end / start)
+
+
+def model_psfs_of_frames(frames, subsampling_factor=2, psf_n_iter_analytic=100, psf_n_iter_pixels=3000,
+                         field_distortion=False, **build_kwargs):
+    """frames: iterable of dicts with 'datas', 'noisemaps', 'cosmics_masks' (and optionally
+    'automatic_masks', 'seeing_pixels', 'pixel_scale', 'id').  Frames whose stamps are all rejected are
+    skipped (psf_modelling.py:154-160).  Returns a list of (frame, result-or-None) with the quantities the
+    reference stores: narrow_psf, full_psf, chi2, relative_loss_differential, fwhm_moffat_pixels."""
+    prepared, index = [], []
+    for k, fr in enumerate(frames):
+        d, nmap, m, keep = prepare_psf_stamps(fr['datas'], fr['noisemaps'], fr['cosmics_masks'], fr.get('automatic_masks'))
+        if len(d) == 0:
+            continue
+        prepared.append((d, nmap, m, float(fr.get('seeing_pixels', 3.0)), keep))
+        index.append(k)
+    out = [(fr, None) for fr in frames]
+    if not prepared:
+        return out
+    results = build_psf_batch([p[0] for p in prepared], [p[1] for p in prepared], subsampling_factor,
+                              masks=[p[2] for p in prepared], n_iter_analytic=psf_n_iter_analytic,
+                              n_iter_adabelief=psf_n_iter_pixels, guess_method_star_position='center',
+                              guess_fwhm_pixels=np.array([p[3] for p in prepared]), field_distortion=field_distortion,
+                              **build_kwargs)
+    for k, p, res in zip(index, prepared, results):
+        km = res['kwargs_psf']['kwargs_moffat']
+        res['fwhm_moffat_pixels'] = float((0.5 * (km['fwhm_x'] + km['fwhm_y'])).item())
+        res['relative_loss_differential'] = relative_loss_differential(res['adabelief_extra_fields']['loss_history'])
+        res['stars_kept'] = p[4]
+        out[k] = (frames[k], res)
+    return out

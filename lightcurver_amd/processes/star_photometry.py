@@ -12,6 +12,23 @@ from ..starred.utils.noise_utils import propagate_noise
 from ..utilities.starred_utilities import get_flux_uncertainties
 
 
+def prepare_star_epochs(data, noisemap, cosmics_mask):
+    """Clean-up of one star's epoch stack before the joint fit, as the reference does it at
+    star_photometry.py:309-316: pixels where BOTH data and noise are NaN become (0, 1e7); then every EPOCH
+    that contains at least one flagged pixel has its whole noise map multiplied by 1000 (the reference
+    indexes epochs there, ``noisemap[np.where(~mask)[0]] *= 1000``, once per epoch: SURVEY.md 8(a) row a5).
+    cosmics_mask: True where flagged.  Returns (data, noisemap) as new float64 arrays."""
+    data = np.array(data, dtype=np.float64)
+    noisemap = np.array(noisemap, dtype=np.float64)
+    both_nan = np.isnan(data) & np.isnan(noisemap)
+    data[both_nan] = 0.0
+    noisemap[both_nan] = 1e7
+    good = ~np.asarray(cosmics_mask, dtype=bool)
+    flagged_epochs = np.unique(np.where(~good)[0])
+    noisemap[flagged_epochs] *= 1000.0
+    return data, noisemap
+
+
 def _border_level(stack):
     """Sky estimate: mean over the four borders of the per-epoch median of the outermost row / column."""
     edges = [stack[:, :1, :], stack[:, :, :1], stack[:, -1:, :], stack[:, :, -1:]]

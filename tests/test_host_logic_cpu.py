@@ -62,6 +62,38 @@ def test_initial_positions():
     assert x0[0] == 1.5 and y0[0] == -1.5
 
 
+def test_psf_stamp_preparation_follows_the_reference_rules():
+    from lightcurver_amd.processes.psf_modelling import prepare_psf_stamps, relative_loss_differential
+    rng = np.random.default_rng(0)
+    d = rng.standard_normal((3, 10, 10))
+    nm = np.ones((3, 10, 10))
+    cosmics = np.zeros((3, 10, 10), bool)
+    cosmics[1, :5, :] = True            # 50 % masked -> dropped
+    cosmics[2, 0, :4] = True            # 4 % masked -> kept
+    d[0, 3, 3] = np.nan
+    nm[0, 3, 3] = np.nan                # both NaN -> (0, 1), masked
+    d[0, 4, 4] = np.nan                 # only data NaN -> left alone (the C ABI zero-weights it later)
+    dd, nn, mm, keep = prepare_psf_stamps(d, nm, cosmics)
+    assert keep.tolist() == [True, False, True] and dd.shape == (2, 10, 10)
+    assert dd[0, 3, 3] == 0.0 and nn[0, 3, 3] == 1.0 and not mm[0, 3, 3]
+    assert np.isnan(dd[0, 4, 4]) and mm[0, 4, 4]
+    assert mm[1].sum() == 96
+    lh = np.concatenate([np.linspace(10, 1, 90), np.linspace(1, 0.9, 10)])
+    assert abs(relative_loss_differential(lh) - 0.1 / 9.0) < 1e-12
+
+
+def test_star_epoch_preparation_downweights_whole_epochs():
+    from lightcurver_amd.processes.star_photometry import prepare_star_epochs
+    d = np.ones((4, 6, 6))
+    nm = np.full((4, 6, 6), 2.0)
+    cm = np.zeros((4, 6, 6), bool)
+    cm[2, 1, 1] = cm[2, 2, 2] = True     # two flagged pixels, one epoch: x1000 once
+    d[0, 0, 0] = nm[0, 0, 0] = np.nan
+    dd, nn = prepare_star_epochs(d, nm, cm)
+    assert dd[0, 0, 0] == 0.0 and nn[0, 0, 0] == 1e7
+    assert np.all(nn[2] == 2000.0) and np.all(nn[1] == 2.0) and np.all(nn[3] == 2.0)
+
+
 def test_epoch_sharding_covers_everything_once():
     from lightcurver_amd.distributed import shard_epochs, shard_kwargs
     for E in (1, 7, 200, 1000):
