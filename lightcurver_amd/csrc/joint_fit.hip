@@ -27,6 +27,10 @@ struct lc_joint {
   int free_mask[LC_P_COUNT] = {};
   bool have_W = false, h_nonzero = false;
   lc_joint_loss_cfg cfg{};
+  float *greg = nullptr, *regs = nullptr;
+  hipStream_t streamB = nullptr;      // the h regulariser runs here, concurrently with the epoch kernel
+  hipEvent_t evReg = nullptr, evUpd = nullptr;
+  bool reg_pending = false;
   std::vector<float> h_sigma2, h_psf;  // host copies for the one-time noise propagation
   std::vector<void *> allocs;
 };
@@ -173,14 +177,17 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
 }
 
 int launch_reduce(lc_joint *j, int need_h) {
-  const int NN = j->N * j->N, total = NN + 4 * j->M + 2;
-  hipLaunchKernelGGL(joint_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, j->ctx->stream, j->E, j->M, NN,
+  const int NN = j->N * j->N;
+  const int nimg = (NN + kRedPix - 1) / kRedPix;
+  hipLaunchKernelGGL(joint_reduce_kernel, dim3(nimg + 1), dim3(kRedPix * kRedParts), 0, j->ctx->stream, j->E, j->M, NN,
                      need_h, j->HG, j->g_cx_e, j->g_cy_e, j->chi2_e, j->par[LC_P_A], j->shared);
   LC_HIP(j->ctx, hipGetLastError());
   return LC_OK;
 }
 
-int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, bool write_hist, bool all_grads) {
+int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, bool write_hist, bool all_grads,
+                  int reg_mode = 0, hipStream_t stream = nullptr) {
+  if (!stream) stream = j->ctx->stream;
   const JointVariant *v = find_jv(j->n, j->ss);
   JointUpdArgs A;
   std::memset(&A, 0, sizeof(A));
@@ -189,6 +196,9 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   A.mode = mode;
   A.t = t;
   A.ss = j->ss;
+  A.reg_mode = reg_mode;
+  A.greg = j->greg;
+  A.regs = j->regs;
   for (int k = 0; k < LC_P_COUNT; ++k) {
     A.free_mask[k] = j->free_mask[k];
     A.par[k] = j->par[k];
@@ -223,7 +233,7 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   A.prior_cy_sigma = j->prior + 3 * j->M;
   if (cfg) A.ab = *cfg; else lc_adabelief_defaults(&A.ab);
   LC_HIP(j->ctx, hipFuncSetAttribute((const void *)v->uk, hipFuncAttributeMaxDynamicSharedMemorySize, v->u_lds));
-  hipLaunchKernelGGL(v->uk, dim3(1), dim3(v->u_thr), v->u_lds, j->ctx->stream, A);
+  hipLaunchKernelGGL(v->uk, dim3(1), dim3(v->u_thr), v->u_lds, stream, A);
   LC_HIP(j->ctx, hipGetLastError());
   return LC_OK;
 }
@@ -273,7 +283,7 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   TRY(dmalloc(j, &j->data, E * nn));
   TRY(dmalloc(j, &j->wgt, E * nn));
   TRY(dmalloc(j, &j->St, (size_t)E * KH * L));
-  TRY(dmalloc(j, &j->twid, L / 2));
+  TRY(dmalloc(j, &j->twid, L));
   TRY(dmalloc(j, &j->tabs, (size_t)E * 4 * std::max(M, 1) * N));
   TRY(dmalloc(j, &j->GS, E * NN));
   TRY(dmalloc(j, &j->HG, E * NN));
@@ -293,6 +303,12 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   TRY(dmalloc(j, &j->atoms, (size_t)(j->J + 1) * 3 * N));
   TRY(dmalloc(j, &j->qscr, (size_t)(j->J + 1) * NN));
   TRY(dmalloc(j, &j->out_loss, 4));
+  TRY(dmalloc(j, &j->greg, NN));
+  TRY(dmalloc(j, &j->regs, 4));
+  LC_HIP(ctx, hipStreamCreate(&j->streamB));
+  LC_HIP(ctx, hipEventCreateWithFlags(&j->evReg, hipEventDisableTiming));
+  LC_HIP(ctx, hipEventCreateWithFlags(&j->evUpd, hipEventDisableTiming));
+  LC_HIP(ctx, hipEventRecord(j->evUpd, ctx->stream));
   TRY(dmalloc(j, &j->scene2, 2 * NN));
   TRY(dmalloc(j, &j->prior, 4 * std::max(M, 1)));
   TRY(ensure_hist(j, 64));
@@ -312,8 +328,8 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
     TRY(h2d(j, j->wgt, w.data(), w.size() * sizeof(float)));
   }
   {
-    std::vector<float2> tw(L / 2);
-    for (int k = 0; k < L / 2; ++k) tw[k] = make_float2((float)std::cos(-2.0 * M_PI * k / L), (float)std::sin(-2.0 * M_PI * k / L));
+    std::vector<float2> tw(L);
+    for (int k = 0; k < L; ++k) tw[k] = make_float2((float)std::cos(-2.0 * M_PI * k / L), (float)std::sin(-2.0 * M_PI * k / L));
     TRY(h2d(j, j->twid, tw.data(), tw.size() * sizeof(float2)));
     std::vector<float> norms, atoms;
     starlet_noise_tables(N, j->J, norms, atoms);
@@ -345,6 +361,12 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
 void lc_joint_destroy(lc_joint *j) {
   if (!j) return;
   hipStreamSynchronize(j->ctx->stream);
+  if (j->streamB) {
+    hipStreamSynchronize(j->streamB);
+    hipStreamDestroy(j->streamB);
+  }
+  if (j->evReg) hipEventDestroy(j->evReg);
+  if (j->evUpd) hipEventDestroy(j->evUpd);
   for (void *p : j->allocs) hipFree(p);
   if (j->hist) hipFree(j->hist);
   delete j;
@@ -455,6 +477,16 @@ int lc_joint_propagate_noise(lc_joint *j, float *W_out) {
 
 int lc_joint_step_local(lc_joint *j) {
   if (!j) return LC_ERR_INVALID;
+  j->reg_pending = false;
+  if (reg_h_on(j)) {
+    // starlet l1 + positivity of h depend on h alone: evaluate them on a second stream while the epoch
+    // kernel (which leaves CUs idle whenever E < 256) runs; the update kernel joins the two
+    LC_HIP(j->ctx, hipStreamWaitEvent(j->streamB, j->evUpd, 0));
+    int rc = launch_update(j, 0, 0, nullptr, false, false, 1, j->streamB);
+    if (rc) return rc;
+    LC_HIP(j->ctx, hipEventRecord(j->evReg, j->streamB));
+    j->reg_pending = true;
+  }
   int need = launch_epochs(j, 0, 0, false, nullptr);
   if (need < 0) return need;
   return launch_reduce(j, need);
@@ -477,8 +509,11 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   if (!j) return LC_ERR_INVALID;
   int rc = ensure_hist(j, j->iters_done + 2);
   if (rc) return rc;
-  rc = launch_update(j, 1, j->iters_done, cfg, true, false);
+  if (j->reg_pending) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
+  rc = launch_update(j, 1, j->iters_done, cfg, true, false, j->reg_pending ? 2 : 0);
   if (rc) return rc;
+  LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
+  j->reg_pending = false;
   j->iters_done += 1;
   return LC_OK;
 }

@@ -21,7 +21,7 @@ struct JointArgs {
   int h_active, need_hgrad;   // h present in the scene; produce T^T slabs
   const float *data, *wgt;    // [E][n][n], wgt = 1 / sigma^2 (0 where invalid)
   const float2 *St;           // [E][L/2+1][L] PSF spectrum / L^2, transposed
-  const float2 *twid;         // [L/2]
+  const float2 *twid;         // [L] exp(-2 pi i m / L)
   const float *a, *cx, *cy, *dx, *dy, *alpha, *h, *mean;
   float *tabs;                // [E][4][M][N] gx, dgx, gy, dgy scratch
   float *GS;                  // [E][N*N] scene-gradient scratch
@@ -63,7 +63,7 @@ struct JointCfg {
   static constexpr int OFF_WS = OFF_SPEC + SZ_SPEC;
   static constexpr int SZ_WS = NW * 2 * L;
   static constexpr int OFF_TW = OFF_WS + SZ_WS;
-  static constexpr int SZ_TW = L / 2;
+  static constexpr int SZ_TW = L;
   static constexpr int OFF_RED = OFF_TW + SZ_TW;  // float2 units; reduction scratch as floats
   static constexpr int SZ_RED = (NW * (4 + 3 * kMaxSources) + 1) / 2 + 8;
   static constexpr int LDS_BYTES = (OFF_RED + SZ_RED) * 8;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   const float meane = A.mean[e];
   float *tab = A.tabs + (size_t)e * 4 * M * N;
 
-  for (int k = tid; k < L / 2; k += C::NTHR) TW[k] = A.twid[k];
+  for (int k = tid; k < L; k += C::NTHR) TW[k] = A.twid[k];
   // separable Gaussian factors of every point source (full grid, as the oracle evaluates them)
   {
     const float inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm = 0.3989422804014327f / kSigmaG;
@@ -403,34 +403,77 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 
 // ---- kernel 2: ordered reduction over the epochs of this rank -------------------------------------
 // shared = [ dL/dh (N*N) | dL/dc_x (M) | dL/dc_y (M) | sum_e a (M) | sum_e a^2 (M) | chi2 | n_epochs ]
-__global__ void joint_reduce_kernel(int E, int M, int NN, int need_h, const float *HG, const float *g_cx_e,
-                                    const float *g_cy_e, const float *chi2_e, const float *a, float *shared) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < NN) {
+// Image part: a block owns 32 consecutive pixels; its 8 groups of 32 lanes each sum one eighth of the epochs
+// (coalesced 128-byte rows, 4 independent loads in flight per lane), then the 8 partials are added in a fixed
+// order, so the result does not depend on scheduling.  Scalars: last block, one thread each, in double.
+constexpr int kRedPix = 32, kRedParts = 8;
+__global__ __launch_bounds__(kRedPix *kRedParts) void joint_reduce_kernel(int E, int M, int NN, int need_h, const float *HG,
+                                                                           const float *g_cx_e, const float *g_cy_e,
+                                                                           const float *chi2_e, const float *a,
+                                                                           float *shared) {
+  __shared__ float part[kRedParts][kRedPix];
+  const int nimg = (NN + kRedPix - 1) / kRedPix;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < nimg) {
+    const int px = blockIdx.x * kRedPix + (tid % kRedPix), p = tid / kRedPix;
+    const int e0 = (int)(((long long)E * p) / kRedParts), e1 = (int)(((long long)E * (p + 1)) / kRedParts);
     float acc = 0.f;
-    if (need_h)
-      for (int e = 0; e < E; ++e) acc += HG[(size_t)e * NN + k];
-    shared[k] = acc;
-  } else if (k < NN + 4 * M) {
-    const int q = (k - NN) / M, i = (k - NN) % M;
-    double acc = 0.0;
-    for (int e = 0; e < E; ++e) {
-      const float ai = a[e * M + i];
-      acc += (q == 0) ? (double)g_cx_e[e * M + i] : (q == 1) ? (double)g_cy_e[e * M + i] : (q == 2) ? (double)ai : (double)ai * ai;
+    if (need_h && px < NN) {
+      int e = e0;
+      for (; e + 4 <= e1; e += 4) {
+        const float v0 = HG[(size_t)e * NN + px], v1 = HG[(size_t)(e + 1) * NN + px];
+        const float v2 = HG[(size_t)(e + 2) * NN + px], v3 = HG[(size_t)(e + 3) * NN + px];
+        acc += v0;
+        acc += v1;
+        acc += v2;
+        acc += v3;
+      }
+      for (; e < e1; ++e) acc += HG[(size_t)e * NN + px];
     }
-    shared[k] = (float)acc;
-  } else if (k == NN + 4 * M) {
-    double acc = 0.0;
-    for (int e = 0; e < E; ++e) acc += chi2_e[e];
-    shared[k] = (float)acc;
-  } else if (k == NN + 4 * M + 1) {
-    shared[k] = (float)E;
+    part[p][tid % kRedPix] = acc;
+    __syncthreads();
+    if (tid < kRedPix && px < NN) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < kRedParts; ++q) t += part[q][tid];
+      shared[px] = t;
+    }
+    return;
   }
+  // scalar block: quantity q in [0, 4M] (dc_x, dc_y, sum a, sum a^2 per source, then chi2), one wave per
+  // quantity at a time; lanes stride over the epochs in double, partials combined in lane order
+  __shared__ double lanes[kRedPix * kRedParts];
+  const int lane = tid & 63, wid = tid >> 6, nw = (kRedPix * kRedParts) / 64;
+  for (int q = wid; q <= 4 * M; q += nw) {
+    double acc = 0.0;
+    for (int e = lane; e < E; e += 64) {
+      if (q == 4 * M) {
+        acc += chi2_e[e];
+      } else {
+        const int kind = q / M, i = q % M;
+        const float ai = a[e * M + i];
+        acc += (kind == 0) ? (double)g_cx_e[e * M + i] : (kind == 1) ? (double)g_cy_e[e * M + i] : (kind == 2) ? (double)ai : (double)ai * ai;
+      }
+    }
+    lanes[tid] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {
+      double t = 0.0;
+      for (int l = 0; l < 64; ++l) t += lanes[wid * 64 + l];
+      shared[NN + q] = (float)t;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (tid == 0) shared[NN + 4 * M + 1] = (float)E;
 }
 
 // ---- kernel 3: regularisers, loss, AdaBelief -------------------------------------------------------
 struct JointUpdArgs {
   int E, M, mode, t, hist_stride, ss;  // mode 1 = update, 0 = gradients only
+  int reg_mode;                        // 0 = background regulariser inline, 1 = compute it only (-> greg, regs), 2 = use greg / regs
+  float *greg, *regs;                  // [N*N] sub-gradient of the h regularisers, [2] = l1, positivity values
   int free_mask[LC_P_COUNT];
   const float *shared;             // reduced (and, multi-GPU, all-reduced) block
   float *h, *mh, *sh;              // [N*N]
@@ -478,18 +521,58 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
     g[4 * q] = gs.x; g[4 * q + 1] = gs.y; g[4 * q + 2] = gs.z; g[4 * q + 3] = gs.w;
   }
   float l1 = 0.f, pos = 0.f;
-  if (A.lam_sc != 0.f || A.lam_hf != 0.f) {
+  if (A.reg_mode == 2) {
+    // the regulariser of h was evaluated by a concurrent launch (it only depends on h)
+#pragma unroll
+    for (int q = 0; q < PX / 4; ++q) {
+      const float4 gr = *(const float4 *)(A.greg + pix + 4 * q);
+      g[4 * q] += gr.x; g[4 * q + 1] += gr.y; g[4 * q + 2] += gr.z; g[4 * q + 3] += gr.w;
+    }
+    if (tid == 0) {
+      l1 = A.regs[0];
+      pos = A.regs[1];
+    }
+  }
+  float greg_own[PX];
+#pragma unroll
+  for (int p = 0; p < PX; ++p) greg_own[p] = 0.f;
+  if (A.reg_mode != 2 && (A.lam_sc != 0.f || A.lam_hf != 0.f)) {
     float z[PX];
     starlet_l1_grad<N, PX>(hp, A.W, A.norms, A.qscr, A.lam_sc, A.lam_hf, lds, tid, l1, z);
 #pragma unroll
-    for (int p = 0; p < PX; ++p) g[p] += z[p];
+    for (int p = 0; p < PX; ++p) {
+      g[p] += z[p];
+      greg_own[p] += z[p];
+    }
   }
-  if (A.lam_pos != 0.f) {
+  if (A.reg_mode != 2 && A.lam_pos != 0.f) {
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
       pos += (hp[p] < 0.f) ? -A.lam_pos * hp[p] : 0.f;
       g[p] += (hp[p] < 0.f) ? -A.lam_pos : 0.f;
+      greg_own[p] += (hp[p] < 0.f) ? -A.lam_pos : 0.f;
     }
+  }
+  if (A.reg_mode == 1) {  // regulariser-only launch: publish and leave
+#pragma unroll
+    for (int q = 0; q < PX / 4; ++q)
+      *(float4 *)(A.greg + pix + 4 * q) = make_float4(greg_own[4 * q], greg_own[4 * q + 1], greg_own[4 * q + 2], greg_own[4 * q + 3]);
+    const float s1 = wave_sum(l1), s2 = wave_sum(pos);
+    if (lane == 0) {
+      red[wid * 2] = s1;
+      red[wid * 2 + 1] = s2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int w = 0; w < NWV; ++w) {
+        t1 += red[w * 2];
+        t2 += red[w * 2 + 1];
+      }
+      A.regs[0] = t1;
+      A.regs[1] = t2;
+    }
+    return;
   }
   // ---- regularization_strength_pts_source: lam * sum W_0 |starlet_0(Pbar)|, Pbar = sum_i mean_e(a_i) G(c_i)
   //      (the point-source channel at the target resolution in the reference frame, DESIGN.md SPEC) ----
