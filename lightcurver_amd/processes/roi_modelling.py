@@ -143,3 +143,44 @@ def fluxes_from_model(model, kwargs, kwargs_up, kwargs_down, data, noisemap, n_s
     chi2_per_frame = np.nansum(residuals ** 2 / noisemap ** 2, axis=(1, 2)) / model.image_size ** 2
     return dict(fluxes=np.array(curves), d_fluxes=np.array(d_curves), residuals=residuals,
                 reduced_chi2=np.array(chi2_per_frame))
+
+
+# ---- diagnostics of roi_modelling.py:34-125 ---------------------------------------------
+def align_data_interpolation(array, starred_kwargs):
+    """De-translate and de-rotate every epoch with the fitted dx, dy, alpha (spline interpolation, for
+    diagnostics only; reference roi_modelling.py:34-57: shift by (-dy, -dx), then rotate by +alpha degrees)."""
+    from scipy.ndimage import rotate, shift
+    ka = starred_kwargs['kwargs_analytic']
+    return np.array([rotate(shift(img, (-ddy, -ddx)), ang, reshape=False)
+                     for img, ddx, ddy, ang in zip(array, ka['dx'], ka['dy'], ka['alpha'])])
+
+
+def sigma_clipped_weighted_stack(data, noisemap, n_sigma=3.0):
+    """Average stack with one pass of rejection around the per-pixel median (threshold n_sigma standard
+    deviations) and weights 1 / noise: what the reference obtains from ccdproc's Combiner
+    (roi_modelling.py:60-83), written out since ccdproc is not a dependency here."""
+    data = np.asarray(data, dtype=np.float64)
+    weights = 1.0 / np.asarray(noisemap, dtype=np.float64)
+    med = np.nanmedian(data, axis=0)
+    dev = np.nanstd(data, axis=0)
+    keep = np.abs(data - med) <= n_sigma * dev
+    keep |= ~np.isfinite(dev)[None]
+    w = np.where(keep & np.isfinite(data), weights, 0.0)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        return np.nansum(w * np.nan_to_num(data), axis=0) / np.sum(w, axis=0)
+
+
+def stack_data_diagnostic(data, noisemap, starred_kwargs, starred_model):
+    """Three aligned stacks: the data, the data minus the point sources, the data minus the background
+    (reference roi_modelling.py:86-125).  Two extra forward models on the device, the rest on the host."""
+    only_ps = deepcopy(starred_kwargs)
+    only_ps['kwargs_background']['h'] = np.array(only_ps['kwargs_background']['h']) * 0.0
+    no_ps = deepcopy(starred_kwargs)
+    no_ps['kwargs_analytic']['a'] = np.array(no_ps['kwargs_analytic']['a']) * 0.0
+    data = np.asarray(data, dtype=np.float64)
+    minus_ps = align_data_interpolation(data - starred_model.model(only_ps), only_ps)
+    minus_bg = align_data_interpolation(data - starred_model.model(no_ps), no_ps)
+    aligned = align_data_interpolation(data, starred_kwargs)
+    return {'stack': sigma_clipped_weighted_stack(aligned, noisemap),
+            'stack_no_ps': sigma_clipped_weighted_stack(minus_ps, noisemap),
+            'stack_no_background': sigma_clipped_weighted_stack(minus_bg, noisemap)}

@@ -94,6 +94,16 @@ def test_star_epoch_preparation_downweights_whole_epochs():
     assert np.all(nn[2] == 2000.0) and np.all(nn[1] == 2.0) and np.all(nn[3] == 2.0)
 
 
+def test_sigma_clipped_stack_rejects_outliers():
+    from lightcurver_amd.processes.roi_modelling import sigma_clipped_weighted_stack
+    rng = np.random.default_rng(1)
+    data = 5.0 + 0.1 * rng.standard_normal((30, 8, 8))
+    data[3, 2, 2] = 500.0  # cosmic
+    noise = np.full_like(data, 0.1)
+    st = sigma_clipped_weighted_stack(data, noise)
+    assert st.shape == (8, 8) and abs(st[2, 2] - 5.0) < 0.1 and abs(st.mean() - 5.0) < 0.05
+
+
 def test_epoch_sharding_covers_everything_once():
     from lightcurver_amd.distributed import shard_epochs, shard_kwargs
     for E in (1, 7, 200, 1000):

@@ -39,6 +39,12 @@ def test_two_stage_roi_fit_recovers_light_curves():
         cc = np.corrcoef(res['fluxes'][i], truth[i])[0, 1]
         assert cc > 0.5, cc
     assert np.all(res['d_fluxes'] > 0)
+    # diagnostics of roi_modelling.py:86-125: three (n, n) stacks; removing the point sources removes most of the flux
+    from lightcurver_amd.processes.roi_modelling import stack_data_diagnostic
+    stacks = stack_data_diagnostic(out['data'], out['noisemap'], k, out['model'])
+    assert set(stacks) == {'stack', 'stack_no_ps', 'stack_no_background'}
+    assert all(v.shape == (n, n) and np.all(np.isfinite(v)) for v in stacks.values())
+    assert stacks['stack_no_ps'].sum() < 0.7 * stacks['stack'].sum()
 
 
 def test_shifts_and_fluxes_recovered_without_background():
