@@ -3,6 +3,7 @@
 // work on different rows / columns, so no workgroup barrier is needed inside a transform.
 #pragma once
 #include "lc_common.h"
+#include "starlet_device.h"
 
 namespace lc {
 
@@ -11,14 +12,6 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 }
 __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) {  // a * conj(b)
   return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
-}
-
-// LDS traffic of one wave is issued and completed in order; this only stops the compiler from
-// moving LDS accesses of different lanes' data across the point.
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // a: L complex samples (natural order), b: L complex scratch, tw[m] = exp(-2 pi i m / L), m < L.

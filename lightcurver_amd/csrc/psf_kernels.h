@@ -43,9 +43,12 @@ struct PsfArgs {
   lc_adabelief_cfg ab;
 };
 
-template <int N_, int SS_, int PX_, int SG_>
+template <int N_, int SS_, int PX_, int SG_, bool WC_ = false>
 struct PsfCfg {
   static constexpr int N = N_, SS = SS_, PX = PX_, SG = SG_;
+  // WC: the row pass, column pass and transposed column pass of one (star, block of JB down-sampled columns)
+  // run inside ONE wave with wave-level synchronisation only (per-wave LDS scratch)
+  static constexpr bool WC = WC_;
   static constexpr int n = N / SS;
   static constexpr int NTHR = N * N / PX;
   static constexpr int NW = (NTHR + kWave - 1) / kWave;
@@ -58,26 +61,37 @@ struct PsfCfg {
   static constexpr int RS = n + 1;  // padded LDS row stride of n-long rows
   // LDS carve-up (floats)
   static constexpr int OFF_T = 0;
-  static constexpr int SZ_T = N * TS;
+  static constexpr int SZ_T = WC_ ? N * (N + 2 * (N / 4 + 10) + 1) : N * TS;
   static constexpr int OFF_R = OFF_T + SZ_T;
   static constexpr int SZ_R2 = SG * n * TS;  // R2t / R2xt: [SG][n][TS]
   static constexpr int SZ_V = SG * N * RS;   // V: [SG][N][RS]
-  static constexpr int SZ_R = (2 * SZ_R2 > SZ_V) ? 2 * SZ_R2 : SZ_V;
+  static constexpr int JB = LR;                       // down-sampled columns per wave task (WC)
+  // WC tiles carry zero aprons so that the filter windows are read without clamping or selects.  The star
+  // offsets are limited to +-N/4 high-res pixels (tap_entry), which bounds every window by AP / APR.
+  static constexpr int AP = N / 4 + 10;               // apron of N-long rows (high-res pixels)
+  static constexpr int TSA = N + 2 * AP + 1;          // row stride of T, R2, R2x in the WC layout
+  static constexpr int APR = AP / SS + 2;             // apron of the residual rows (data pixels)
+  static constexpr int WSZ = 2 * JB * TSA + (n + 2 * APR) * JB;  // per-wave scratch: R2, R2x [JB][TSA], residuals [n+2APR][JB]
+  static constexpr int SZ_VR = (SZ_V > StarletLds<N>::FLOATS) ? SZ_V : StarletLds<N>::FLOATS;  // V, reused by the starlet
+  static constexpr int OFF_WSC = OFF_R + SZ_VR;
+  static constexpr int SZ_R = WC ? (SZ_VR + NW * WSZ) : ((2 * SZ_R2 > SZ_V) ? 2 * SZ_R2 : SZ_V);
   static constexpr int OFF_RES = OFF_R + SZ_R;
-  static constexpr int SZ_RES = SG * n * n;
+  static constexpr int SZ_RES = WC ? 0 : SG * n * n;
   static constexpr int OFF_TAPS = OFF_RES + SZ_RES;
   static constexpr int SZ_TAPS = 16 * 4 * NT;  // every star of the frame
   static constexpr int OFF_RED = OFF_TAPS + SZ_TAPS;
   static constexpr int IPS = n * n / LC;  // column-pass items per star
   static constexpr int IPS_PAD = (IPS + kWave - 1) / kWave * kWave;
   static constexpr int SLOTS = IPS_PAD / kWave;
-  static constexpr int SZ_RED = SG * SLOTS * 5 + NW + 8;
+  static constexpr int SZ_RED = (WC ? 16 * (n / JB) * 5 : SG * SLOTS * 5) + NW + 8;
+  static constexpr int OFF_REDW = OFF_RED + (WC ? 16 * (n / JB) * 5 : SG * SLOTS * 5);
   static constexpr int OFF_STAR = OFF_RED + SZ_RED;  // star params, grads, moments, ints
   static constexpr int MAXS = 16;
   static constexpr int SZ_STAR = MAXS * 20 + 16;
   static constexpr int LDS_FLOATS = OFF_STAR + SZ_STAR;
-  static_assert(StarletLds<N>::FLOATS <= SZ_T + SZ_R + SZ_RES, "starlet ping-pong buffers must fit over T + R + RES");
+  static_assert(WC || StarletLds<N>::FLOATS <= SZ_T + SZ_R + SZ_RES, "starlet ping-pong buffers must fit over T + R + RES");
   static_assert(PX % SS == 0 && N % PX == 0 && n % LR == 0 && n % LC == 0 && n % LA == 0, "tiling");
+  static_assert(LDS_FLOATS * 4 <= 163840, "LDS");
   static_assert(NTHR <= 1024 && NTHR % kWave == 0, "threads");
 };
 
@@ -86,7 +100,7 @@ struct PsfCfg {
 // Phi(m) = sum_{dv<SS} phi(m + dv), phi(t) = N(t; delta, sigma) truncated to |t - round(delta)| <= kRg.
 template <int SS, int NT>
 __device__ inline void tap_entry(float delta, int k, float &tap, float &dtap, int &bq) {
-  const int o = (int)nearbyintf(delta);
+  const int o = (int)nearbyintf(delta);  // |delta| is limited by the caller
   const int base = o - kRg - (SS - 1);
   int q = base / SS;
   if (q * SS > base) --q;  // floor division
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
   float *RES = lds + C::OFF_RES;
   float *TAPS = lds + C::OFF_TAPS;  // [S][4][NT]: tx, dtx, ty, dty
   float *RED = lds + C::OFF_RED;    // [SG][SLOTS][5] + [NW] + scalars
-  float *REDW = RED + SG * C::SLOTS * 5;
+  float *REDW = lds + C::OFF_REDW;
   float *SCAL = REDW + C::NW;  // lr, bc1, bc2, l1, loss
   float *SP = lds + C::OFF_STAR;    // star params [MAXS][4]
   float *SGR = SP + C::MAXS * 4;    // star grads [MAXS][5]: chi2, ga, gx, gy, gsky
@@ -136,6 +150,10 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
   const float *dataf = A.data + (size_t)f * S * n * n;
   const float *wgtf = A.wgt + (size_t)f * S * n * n;
 
+  if constexpr (C::WC) {  // aprons (and everything else) of T and of the per-wave tiles start at zero and stay zero
+    for (int i = tid0; i < C::SZ_T; i += NTHR) lds[C::OFF_T + i] = 0.f;
+    for (int i = tid0; i < C::NW * C::WSZ; i += NTHR) lds[C::OFF_WSC + i] = 0.f;
+  }
   if (tid0 < S * 4) {
     SP[tid0] = A.stars[(size_t)f * S * 4 + tid0];
     SM[tid0] = A.stars_m[(size_t)f * S * 4 + tid0];
@@ -182,7 +200,10 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     LC_STAMP(0);
     // ---- P1: T = Moffat + B into LDS -----------------------------------------------------
     float gB[PX];
-    if (STATE_REGS) {
+    if (C::WC && STATE_REGS) {
+#pragma unroll
+      for (int p = 0; p < PX; ++p) T[pu * C::TSA + C::AP + pv + p] = Bp[p] + Tp[p];
+    } else if (STATE_REGS) {
 #pragma unroll
       for (int p = 0; p < PX; ++p) T[pu * TS + pv + p] = Bp[p] + Tp[p];
     } else {
@@ -207,7 +228,8 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       float tap, dtap;
       int bq;
       const float c_off = (N % 2 == 0) ? 0.5f : 0.0f;  // (N-1)/2 - (N-1)//2
-      const float delta = SS * SP[s * 4 + 1 + ax] + c_off;
+      // a star further than N/4 high-res pixels from the stamp centre is a broken fit: pin the kernel there
+      const float delta = fminf(fmaxf(SS * SP[s * 4 + 1 + ax], -(float)(N / 4)), (float)(N / 4)) + c_off;
       tap_entry<SS, NT>(delta, k, tap, dtap, bq);
       TAPS[(s * 4 + 2 * ax) * NT + k] = tap;
       TAPS[(s * 4 + 2 * ax + 1) * NT + k] = dtap;
@@ -217,6 +239,171 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     for (int g0 = 0; g0 < S; g0 += SG) {
       __syncthreads();  // T and taps visible; previous group's P5 (reads V) done before P2 rewrites R
       LC_STAMP(1 + 5 * (g0 / SG));
+      if constexpr (C::WC) {
+        // ---- wave tasks: (star, block of JB down-sampled columns), everything up to V inside the wave ----
+        constexpr int JB = C::JB, NBLK = n / JB;
+        float *wsc = lds + C::OFF_WSC + wid * C::WSZ;
+        constexpr int TSA = C::TSA, AP = C::AP, APR = C::APR;
+        float *R2w = wsc + AP, *R2xw = wsc + JB * TSA + AP, *RESw = wsc + 2 * JB * TSA + APR * JB;
+        for (int task = wid; task < SG * NBLK; task += C::NW) {
+          const int sl = task / NBLK, blk = task % NBLK, s = g0 + sl;
+          if (s >= S) continue;  // wave-uniform
+          const int jd0 = blk * JB;
+          const float *tx = TAPS + (s * 4 + 0) * NT, *dtx = tx + NT, *ty = tx + 2 * NT, *dty = tx + 3 * NT;
+          const int bqx = BQ[s * 2 + 0], bqy = BQ[s * 2 + 1];
+          const float amp = SP[s * 4 + 0], sky = SP[s * 4 + 3];
+          // data / weights of the task's pixels: requested now, used after the row pass
+          constexpr int NI3 = (JB * (n / LC) + 63) / 64;
+          float dpre[NI3][LC], wpre[NI3][LC];
+#pragma unroll
+          for (int i3 = 0; i3 < NI3; ++i3) {
+            const int item = lane + 64 * i3;
+            const bool ok = item < JB * (n / LC);
+            const int jl = item % JB, a0 = (item / JB) * LC;
+#pragma unroll
+            for (int j = 0; j < LC; ++j) {
+              const size_t pix = ok ? ((size_t)s * n * n + (size_t)(a0 + j) * n + jd0 + jl) : 0;
+              const float dv = dataf[pix], wv = wgtf[pix];
+              dpre[i3][j] = ok ? dv : 0.f;
+              wpre[i3][j] = ok ? wv : 0.f;
+            }
+          }
+          // row pass (x taps) fused with the column down-sampling: lane = high-res row
+          {
+            constexpr int WL = SS * (JB - 1) + NT;
+            const int ws = SS * (jd0 - bqx) - (NT - 1);
+            float tk[NT], dk[NT];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+              tk[k] = tx[k];
+              dk[k] = dtx[k];
+            }
+            for (int u = lane; u < N; u += 64) {
+              float win[WL];
+              const float *trow = T + u * TSA + AP + ws;
+#pragma unroll
+              for (int i = 0; i < WL; ++i) win[i] = trow[i];
+#pragma unroll
+              for (int j = 0; j < JB; ++j) {
+                float acc = 0.f, accd = 0.f;
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                  const float w = win[SS * j - k + NT - 1];
+                  acc = fmaf(tk[k], w, acc);
+                  accd = fmaf(dk[k], w, accd);
+                }
+                R2w[j * TSA + u] = acc;
+                R2xw[j * TSA + u] = accd;
+              }
+            }
+          }
+          wave_lds_sync();
+          // column pass (y taps) fused with the row down-sampling, residuals, reductions: lane = (column, row strip)
+          float chi = 0.f, ga = 0.f, gx = 0.f, gy = 0.f, gs = 0.f;
+          {
+            constexpr int WL = SS * (LC - 1) + NT;
+            float tk[NT], dk[NT];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+              tk[k] = ty[k];
+              dk[k] = dty[k];
+            }
+#pragma unroll
+            for (int i3 = 0; i3 < NI3; ++i3) {
+              const int item = lane + 64 * i3;
+              if (item < JB * (n / LC)) {
+                const int jl = item % JB, a0 = (item / JB) * LC;
+                const int ws = SS * (a0 - bqy) - (NT - 1);
+                float win[WL], winx[WL];
+                const float *r2 = R2w + jl * TSA + ws, *r2x = R2xw + jl * TSA + ws;
+#pragma unroll
+                for (int i = 0; i < WL; ++i) {
+                  win[i] = r2[i];
+                  winx[i] = r2x[i];
+                }
+                float lgx = 0.f, lgy = 0.f;
+#pragma unroll
+                for (int j = 0; j < LC; ++j) {
+                  float fv = 0.f, fx = 0.f, fy = 0.f;
+#pragma unroll
+                  for (int k = 0; k < NT; ++k) {
+                    const float w = win[SS * j - k + NT - 1];
+                    fv = fmaf(tk[k], w, fv);
+                    fy = fmaf(dk[k], w, fy);
+                    fx = fmaf(tk[k], winx[SS * j - k + NT - 1], fx);
+                  }
+                  const float model = fmaf(amp, fv, sky);
+                  const float res = model - dpre[i3][j];
+                  const float rw = wpre[i3][j] * res;
+                  chi = fmaf(rw, res, chi);
+                  ga = fmaf(rw, fv, ga);
+                  lgx = fmaf(rw, fx, lgx);
+                  lgy = fmaf(rw, fy, lgy);
+                  gs += rw;
+                  RESw[(a0 + j) * JB + jl] = rw;
+                  if (A.out_model) A.out_model[(size_t)f * S * n * n + (size_t)s * n * n + (size_t)(a0 + j) * n + jd0 + jl] = model;
+                }
+                gx += lgx * amp * SS;
+                gy += lgy * amp * SS;
+              }
+            }
+          }
+          chi = wave_sum(chi);
+          ga = wave_sum(ga);
+          gx = wave_sum(gx);
+          gy = wave_sum(gy);
+          gs = wave_sum(gs);
+          if (lane == 0) {
+            float *r = RED + (s * NBLK + blk) * 5;
+            r[0] = chi;
+            r[1] = ga;
+            r[2] = gx;
+            r[3] = gy;
+            r[4] = gs;
+          }
+          wave_lds_sync();
+          // transposed column pass: V[u][jd] = sum_id PhiY(ss*id - u) r[id][jd]: lane = (column, strip of high-res rows)
+          {
+            constexpr int WI = (SS * LA - 1 + NT - 1) / SS + 1;
+            constexpr int NI4 = (JB * (n / LA) + 63) / 64;
+            float tk[NT];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) tk[k] = ty[k];
+#pragma unroll
+            for (int i4 = 0; i4 < NI4; ++i4) {
+              const int item = lane + 64 * i4;
+              if (item < JB * (n / LA)) {
+                const int jl = item % JB, a0 = (item / JB) * LA;
+                float out[SS * LA];
+#pragma unroll
+                for (int r = 0; r < SS * LA; ++r) out[r] = 0.f;
+                const float *rcol = RESw + (bqy + a0) * JB + jl;
+#pragma unroll
+                for (int i = 0; i < WI; ++i) {
+                  const float rv = rcol[i * JB];
+#pragma unroll
+                  for (int k = 0; k < NT; ++k) {
+                    const int rel = SS * i - k;
+                    if (rel >= 0 && rel < SS * LA) out[rel] = fmaf(tk[k], rv, out[rel]);
+                  }
+                }
+#pragma unroll
+                for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * RS + jd0 + jl] = out[r];
+              }
+            }
+          }
+          wave_lds_sync();  // the scratch is rewritten by the wave's next task
+        }
+        __syncthreads();
+        if (tid < SG * 5) {
+          const int sl = tid / 5, q = tid % 5;
+          if (g0 + sl < S) {
+            float acc = 0.f;
+            for (int k = 0; k < NBLK; ++k) acc += RED[((g0 + sl) * NBLK + k) * 5 + q];
+            SGR[(g0 + sl) * 5 + q] = acc;
+          }
+        }
+      } else {
       // data / weights of this group's column-pass pixels: issued now, consumed in P3, so the L2/HBM
       // latency hides behind the row pass
       constexpr int NIT3 = (SG * C::IPS_PAD + NTHR - 1) / NTHR;
@@ -400,6 +587,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       }
       __syncthreads();
       LC_STAMP(4 + 5 * (g0 / SG));
+      }
       // ---- P5: transposed row pass, summed over the stars of the group into registers ------
       {
         constexpr int WJ = (PX - 1 + NT - 1) / SS + 1;
@@ -459,7 +647,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         }
       }
       starlet_l1_grad<N, PX>(bpix, A.W ? A.W + (size_t)f * J * N * N : nullptr, A.norms,
-                             A.qscratch + (size_t)f * J * N * N, A.lam_sc, A.lam_hf, lds, tid, l1, z);
+                             A.qscratch + (size_t)f * J * N * N, A.lam_sc, A.lam_hf, C::WC ? lds + C::OFF_R : lds, tid, l1, z);
     }
     LC_STAMP(42);
     // ---- loss ------------------------------------------------------------------------------

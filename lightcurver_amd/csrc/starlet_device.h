@@ -15,6 +15,14 @@ namespace lc {
 #define LC_LAUNDER(x) asm volatile("" : "+v"(x))
 #endif
 
+// LDS traffic of one wave is issued and completed in order; this only stops the compiler from
+// moving LDS accesses of different lanes' data across the point.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ inline float wave_sum_shfl(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

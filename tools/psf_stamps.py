@@ -22,7 +22,8 @@ out = (C.c_longlong * 64)()
 _lib.lib().lc_debug_get_stamps.argtypes = [C.POINTER(C.c_longlong)]
 assert _lib.lib().lc_debug_get_stamps(out) == 0
 s = np.array(out[:], dtype=np.int64)
-names = {0: 'start', 1: 'g0 taps done', 2: 'g0 P2 row', 3: 'g0 P3 col+res', 4: 'g0 P4 colT', 6: 'g1 taps (incl g0 P5)',
+names = {0: 'start', 1: 'P1 + taps (to first barrier)', 40: 'conv: wave tasks + P5', 42: 'starlet', 43: 'loss+update'}
+names_old = {0: 'start', 1: 'g0 taps done', 2: 'g0 P2 row', 3: 'g0 P3 col+res', 4: 'g0 P4 colT', 6: 'g1 taps (incl g0 P5)',
          7: 'g1 P2', 8: 'g1 P3', 9: 'g1 P4', 40: 'groups end (g1 P5)', 41: 'starlet fwd', 42: 'starlet bwd', 43: 'loss+update'}
 keys = [k for k in sorted(names) if s[k] != 0]
 tot = s[43] - s[0]
