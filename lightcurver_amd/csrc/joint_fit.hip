@@ -590,4 +590,10 @@ int lc_joint_fisher_flux_sigma(lc_joint *j, float *sigma_a) {
   return d2h(j, sigma_a, j->fisher, (size_t)j->E * j->M * sizeof(float));
 }
 
+#ifdef LC_STAMPS
+int lc_debug_get_jstamps(long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::g_jstamps), 16 * sizeof(long long)) == hipSuccess ? 0 : -2;
+}
+#endif
+
 }  // extern "C"

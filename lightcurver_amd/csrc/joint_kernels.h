@@ -16,6 +16,16 @@ namespace lc {
 
 constexpr int kMaxSources = 8;
 
+#ifdef LC_STAMPS
+__device__ long long g_jstamps[16];
+#define LC_JSTAMP(k)                                                \
+  do {                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_jstamps[k] = clock64(); \
+  } while (0)
+#else
+#define LC_JSTAMP(k) do {} while (0)
+#endif
+
 struct JointArgs {
   int E, M, mode, isrc;       // mode 0 = forward + backward, 1 = forward only, 2 = Fisher diagonal of source isrc
   int h_active, need_hgrad;   // h present in the scene; produce T^T slabs
@@ -65,7 +75,7 @@ struct JointCfg {
   static constexpr int OFF_TW = OFF_WS + SZ_WS;
   static constexpr int SZ_TW = L;
   static constexpr int OFF_RED = OFF_TW + SZ_TW;  // float2 units; reduction scratch as floats
-  static constexpr int SZ_RED = (NW * (4 + 3 * kMaxSources) + 1) / 2 + 8;
+  static constexpr int SZ_RED = ((NW + 1) * (4 + 3 * kMaxSources) + 1) / 2 + 8;
   static constexpr int LDS_BYTES = (OFF_RED + SZ_RED) * 8;
   static constexpr int CREF = (N - 1) / 2;
   static_assert(N % 2 == 0, "row pairs");
@@ -91,6 +101,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   const float meane = A.mean[e];
   float *tab = A.tabs + (size_t)e * 4 * M * N;
 
+  LC_JSTAMP(0);
   for (int k = tid; k < L; k += C::NTHR) TW[k] = A.twid[k];
   // separable Gaussian factors of every point source (full grid, as the oracle evaluates them)
   {
@@ -113,6 +124,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   for (int i = 0; i < kMaxSources; ++i) amp[i] = (i < M) ? ((A.mode == 2) ? ((i == A.isrc) ? 1.f : 0.f) : A.a[e * M + i]) : 0.f;
   const bool use_h = A.h_active && A.mode != 2;
 
+  LC_JSTAMP(1);
   // ---- phase A: scene rows, two real rows per complex FFT ---------------------------------------
   for (int rp = wid; rp < N / 2; rp += C::NW) {
     const int u0 = 2 * rp;
@@ -145,6 +157,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     wave_lds_sync();
   }
   __syncthreads();
+  LC_JSTAMP(2);
   // ---- phase B: columns: FFT, multiply by the PSF spectrum, inverse FFT, keep the 'same' window ----
   const float2 *Ste = A.St + (size_t)e * KH * L;
   for (int k = wid; k < KH; k += C::NW) {
@@ -157,6 +170,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     wave_lds_sync();
   }
   __syncthreads();
+  LC_JSTAMP(3);
   // ---- phase C: inverse rows -> model, residuals; forward rows of the up-sampled weighted residual ----
   float acc_chi = 0.f, acc_mean = 0.f, acc_fis = 0.f;
   const float *de = A.data + (size_t)e * n * n, *we = A.wgt + (size_t)e * n * n;
@@ -242,6 +256,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     return;
   }
   __syncthreads();
+  LC_JSTAMP(4);
   // ---- phase B': adjoint columns (rows sit at offset CREF), multiply by conj(spectrum) ------------
   for (int k = wid; k < KH; k += C::NW) {
     for (int r = lane; r < L; r += 64) {
@@ -256,12 +271,16 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     wave_lds_sync();
   }
   __syncthreads();
+  LC_JSTAMP(5);
   // ---- phase C': adjoint inverse rows -> scene gradient rows; parameter gradients ------------------
   float pa[kMaxSources], pX[kMaxSources], pY[kMaxSources];
 #pragma unroll
   for (int i = 0; i < kMaxSources; ++i) pa[i] = pX[i] = pY[i] = 0.f;
   float acc_dx = 0.f, acc_dy = 0.f;
-  float *GSe = A.GS + (size_t)e * N * N;
+  // scene-gradient rows overwrite the spectrum rows they were computed from (row u: N floats inside the
+  // KH float2 of spectrum row u), so the T^T gather below reads LDS, not global memory
+  float *GSl = (float *)SPEC;
+  constexpr int GST = 2 * KH;
   for (int rp = wid; rp < N / 2; rp += C::NW) {
     const int u0 = 2 * rp;
     for (int k = lane; k < L; k += 64) {
@@ -278,6 +297,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     float2 *Y = wave_fft<L, true>(wsA, wsB, TW, lane);
     for (int v = lane; v < N; v += 64) {
       const float2 g = Y[v];
+      float gsx = 0.f, gsy = 0.f;
 #pragma unroll
       for (int i = 0; i < kMaxSources; ++i) {
         if (i < M) {
@@ -301,13 +321,18 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         acc_dx = fmaf(g.y, SS * (sa * hy - ca * hx), acc_dx);
         acc_dy = fmaf(g.y, -SS * (sa * hx + ca * hy), acc_dy);
         if (A.need_hgrad) {
-          GSe[u0 * N + v] = g.x;
-          GSe[(u0 + 1) * N + v] = g.y;
+          gsx = g.x;
+          gsy = g.y;
         }
+      }
+      if (use_h && A.need_hgrad) {
+        GSl[u0 * GST + v] = gsx;
+        GSl[(u0 + 1) * GST + v] = gsy;
       }
     }
     wave_lds_sync();
   }
+  LC_JSTAMP(6);
   // reductions: lanes by shuffles, the four waves in fixed order
   {
     constexpr int NQ = 4 + 3 * kMaxSources;
@@ -328,13 +353,15 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       if (lane == 0) RED[wid * NQ + q] = s;
     }
     __syncthreads();
+    float *TOT = RED + C::NW * NQ;
+    if (tid < NQ) {
+      float acc = 0.f;
+      for (int w = 0; w < C::NW; ++w) acc += RED[w * NQ + tid];
+      TOT[tid] = acc;
+    }
+    __syncthreads();
     if (tid == 0) {
-      float t[NQ];
-      for (int q = 0; q < NQ; ++q) {
-        float acc = 0.f;
-        for (int w = 0; w < C::NW; ++w) acc += RED[w * NQ + q];
-        t[q] = acc;
-      }
+      const float *t = TOT;
       A.chi2_e[e] = t[0];
       A.g_mean[e] = t[1];
       float gdx = t[2], gdy = t[3];
@@ -351,28 +378,48 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       A.g_dy[e] = gdy;
     }
   }
+  LC_JSTAMP(7);
   // ---- phase D: T_e^T of the scene gradient by an exact, ordered gather -----------------------------
   if (use_h && A.need_hgrad) {
-    __syncthreads();  // GS of this epoch complete and visible inside the workgroup
+    __syncthreads();  // scene gradient of this epoch complete in LDS
     float *HGe = A.HG + (size_t)e * N * N;
     const float asa = fabsf(sa);
     const int band = (int)ceilf(fmaxf(fabsf(sdx), fabsf(sdy)) + N * asa) + 3;
     const int mext = (int)ceilf(asa * (band + 2)) + 2;
-    for (int k = tid; k < N * N; k += C::NTHR) {
-      const int ky = k / N, kx = k % N;
+    // pure translation: every scene pixel samples h at the same fractional offset, so an interior pixel k of
+    // h collects exactly four scene pixels with constant weights (the adjoint of a 2 x 2 interpolation stencil).
+    // Border pixels (and every pixel when the epoch is rotated) take the exact ordered gather instead; the two
+    // sets are walked by separate loops so that no wave mixes the cheap and the expensive path.
+    const float nsx = -sdx, nsy = -sdy;
+    const float ixf = floorf(nsx), iyf = floorf(nsy);
+    const float fxc = nsx - ixf, fyc = nsy - iyf;
+    const int ixc = (int)ixf, iyc = (int)iyf;
+    const int marg = (sa == 0.f) ? min((int)ceilf(fmaxf(fabsf(sdx), fabsf(sdy))) + 2, N / 2) : N / 2;
+    const int NI = N - 2 * marg;
+    for (int q = tid; q < NI * NI; q += C::NTHR) {
+      const int ky = marg + q / NI, kx = marg + q % NI;
+      const float *g0 = GSl + (ky - iyc) * GST + (kx - ixc);
+      HGe[ky * N + kx] = (1.f - fyc) * ((1.f - fxc) * g0[0] + fxc * g0[-1]) + fyc * ((1.f - fxc) * g0[-GST] + fxc * g0[-GST - 1]);
+    }
+    const int n_rows = 2 * marg * N, n_cols = 2 * marg * NI;
+    for (int q = tid; q < n_rows + n_cols; q += C::NTHR) {
+      int ky, kx;
+      if (q < n_rows) {
+        const int r = q / N;
+        kx = q % N;
+        ky = (r < marg) ? r : N - 2 * marg + r;
+      } else {
+        const int q2 = q - n_rows, r = q2 / (2 * marg), cidx = q2 % (2 * marg);
+        ky = marg + r;
+        kx = (cidx < marg) ? cidx : N - 2 * marg + cidx;
+      }
       const float rx = (float)kx - c0, ry = (float)ky - c0;
       const float px = c0 + (ca * rx - sa * ry) + sdx, py = c0 + (sa * rx + ca * ry) + sdy;
       int vlo = (int)floorf(px) - 1, vhi = vlo + 3, ulo = (int)floorf(py) - 1, uhi = ulo + 3;
-      if (sa == 0.f) {  // pure translation: only the two samples on either side can touch pixel k
-        vlo += 1;
-        vhi = vlo + 1;
-        ulo += 1;
-        uhi = ulo + 1;
-      }
-      if (kx == 0) { vlo = min(vlo, 0); ulo -= mext; uhi += mext; }
-      if (kx == N - 1) { vhi = max(vhi, N - 1); ulo -= mext; uhi += mext; }
-      if (ky == 0) { ulo = min(ulo, 0); vlo -= mext; vhi += mext; }
-      if (ky == N - 1) { uhi = max(uhi, N - 1); vlo -= mext; vhi += mext; }
+      if (kx == 0) { ulo -= mext; uhi += mext; }
+      if (kx == N - 1) { ulo -= mext; uhi += mext; }
+      if (ky == 0) { vlo -= mext; vhi += mext; }
+      if (ky == N - 1) { vlo -= mext; vhi += mext; }
       if (kx == 0) vlo = 0;
       if (kx == N - 1) vhi = N - 1;
       if (ky == 0) ulo = 0;
@@ -393,12 +440,13 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
           const int ya = min(max(y0, 0), N - 1), yb = min(max(y0 + 1, 0), N - 1);
           const float wx = ((xa == kx) ? (1.f - fx) : 0.f) + ((xb == kx) ? fx : 0.f);
           const float wy = ((ya == ky) ? (1.f - fy) : 0.f) + ((yb == ky) ? fy : 0.f);
-          acc = fmaf(wx * wy, GSe[u * N + v], acc);
+          acc = fmaf(wx * wy, GSl[u * GST + v], acc);
         }
       }
-      HGe[k] = acc;
+      HGe[ky * N + kx] = acc;
     }
   }
+  LC_JSTAMP(8);
 }
 
 // ---- kernel 2: ordered reduction over the epochs of this rank -------------------------------------
