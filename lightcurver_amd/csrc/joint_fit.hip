@@ -76,7 +76,7 @@ const JointVariant *find_jv(int n, int ss) {
       make_jv<32, 2, 64, 4, 16>(),     // n = 16, ss = 2
       make_jv<48, 2, 128, 4, 16>(),    // n = 24 (default stamp_size_stars)
       make_jv<64, 2, 128, 8, 16>(),    // n = 32 (default stamp_size_ROI)
-      make_jv<128, 2, 256, 16, 6>(),  // n = 64 (C4)
+      make_jv<128, 2, 256, 16, 8>(),  // n = 64 (C4)
   };
   for (const auto &v : table)
     if (v.n == n && v.ss == ss) return &v;

@@ -71,7 +71,10 @@ struct JointCfg {
   static constexpr int OFF_SPEC = 0;             // float2 units
   static constexpr int SZ_SPEC = N * KH;
   static constexpr int OFF_WS = OFF_SPEC + SZ_SPEC;
-  static constexpr int SZ_WS = NW * 2 * L;
+  // linear row buffer(s) for the data-space step: one per quarter-wave when LDS allows (N <= 64), else one per
+  // wave that the four quarters use in turn
+  static constexpr bool WSQ = (N <= 64);
+  static constexpr int SZ_WS = NW * (WSQ ? 4 : 1) * L;
   static constexpr int OFF_TW = OFF_WS + SZ_WS;
   static constexpr int SZ_TW = L;
   static constexpr int OFF_RED = OFF_TW + SZ_TW;  // float2 units; reduction scratch as floats
@@ -91,7 +94,6 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   float2 *TW = lds2 + C::OFF_TW;
   float *RED = (float *)(lds2 + C::OFF_RED);
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  float2 *wsA = lds2 + C::OFF_WS + wid * 2 * L, *wsB = wsA + L;
   const int M = A.M;
   const float c0 = (N - 1) * 0.5f;
   const float al = A.alpha[e] * 0.017453292519943295f;
@@ -125,12 +127,57 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   const bool use_h = A.h_active && A.mode != 2;
 
   LC_JSTAMP(1);
-  // ---- phase A: scene rows, two real rows per complex FFT ---------------------------------------
-  for (int rp = wid; rp < N / 2; rp += C::NW) {
-    const int u0 = 2 * rp;
-    for (int v = lane; v < L; v += 64) {
+  // Every FFT below is a quarter-wave register transform (fft_device.h): each group of 16 lanes owns one row pair
+  // or one spectrum column, so a wave works on four of them side by side.
+  constexpr int N2 = L / 16;
+  const int l16 = lane & 15, qid = lane >> 4, qbase = lane & 48;
+  const int kbase = N2 * bitrev4(l16);                       // first bin of this lane in the block layout
+  const int lane_mirror = qbase | (15 - l16);                // holds bins L - k for k2 != 0
+  const int lane_neg = qbase | bitrev4((16 - bitrev4(l16)) & 15);  // holds bin (L - k) mod L for k2 == 0
+  float2 *wsq = lds2 + C::OFF_WS + (C::WSQ ? (wid * 4 + qid) : wid) * L;  // linear workspace (L samples)
+
+  // two real rows -> two half spectra (2-for-1): Z = FFT(x1 + i x2), X1 = (Z[k] + conj Z[L-k]) / 2, X2 = (Z[k] - conj Z[L-k]) / 2i
+  auto unpack_rows = [&](float2 (&x)[N2], int u0, bool active) {
+#pragma unroll
+    for (int k2 = 0; k2 < N2; ++k2) {
+      const float2 zk = x[k2];
+      const float2 zc = (k2 == 0) ? shfl2(x[0], lane_neg) : shfl2(x[(N2 - k2) % N2], lane_mirror);
+      const int k = kbase + k2;
+      if (active && k <= L / 2) {
+        SPEC[u0 * KH + k] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+        SPEC[(u0 + 1) * KH + k] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+      }
+    }
+  };
+  // two half spectra -> Z[k] = X1[k] + i X2[k] over all L bins (Hermitian extension), block layout
+  auto pack_rows = [&](float2 (&x)[N2], int u0, bool active) {
+#pragma unroll
+    for (int k2 = 0; k2 < N2; ++k2) {
+      const int k = kbase + k2;
       float2 z = make_float2(0.f, 0.f);
-      if (v < N) {
+      if (active) {
+        if (k <= L / 2) {
+          const float2 x1 = SPEC[u0 * KH + k], x2 = SPEC[(u0 + 1) * KH + k];
+          z = make_float2(x1.x - x2.y, x1.y + x2.x);
+        } else {
+          const float2 x1 = SPEC[u0 * KH + (L - k)], x2 = SPEC[(u0 + 1) * KH + (L - k)];
+          z = make_float2(x1.x + x2.y, x2.x - x1.y);
+        }
+      }
+      x[k2] = z;
+    }
+  };
+
+  // ---- phase A: scene rows, two real rows per complex FFT ---------------------------------------
+  for (int rp0 = wid * 4; rp0 < N / 2; rp0 += C::NW * 4) {
+    const int rp = rp0 + qid, u0 = 2 * rp;
+    const bool active = rp < N / 2;
+    float2 x[N2];
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) {
+      const int v = l16 + 16 * n2;
+      float2 z = make_float2(0.f, 0.f);
+      if (active && v < N) {
         float s0 = 0.f, s1 = 0.f;
         for (int i = 0; i < M; ++i) {
           const float gx = tab[(0 * M + i) * N + v];
@@ -146,100 +193,131 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         }
         z = make_float2(s0, s1);
       }
-      wsA[v] = z;
+      x[n2] = z;
     }
-    float2 *Z = wave_fft<L, false>(wsA, wsB, TW, lane);
-    for (int k = lane; k < KH; k += 64) {
-      const float2 zk = Z[k], zc = Z[(L - k) & (L - 1)];
-      SPEC[u0 * KH + k] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-      SPEC[(u0 + 1) * KH + k] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
-    }
-    wave_lds_sync();
+    quarter_fft_fwd<L>(x, l16, TW);
+    unpack_rows(x, u0, active);
   }
   __syncthreads();
   LC_JSTAMP(2);
   // ---- phase B: columns: FFT, multiply by the PSF spectrum, inverse FFT, keep the 'same' window ----
   const float2 *Ste = A.St + (size_t)e * KH * L;
-  for (int k = wid; k < KH; k += C::NW) {
-    for (int r = lane; r < L; r += 64) wsA[r] = (r < N) ? SPEC[r * KH + k] : make_float2(0.f, 0.f);
-    float2 *Z = wave_fft<L, false>(wsA, wsB, TW, lane);
-    float2 *O = (Z == wsA) ? wsB : wsA;
-    for (int r = lane; r < L; r += 64) Z[r] = cmul(Z[r], Ste[(size_t)k * L + r]);
-    float2 *Y = wave_fft<L, true>(Z, O, TW, lane);
-    for (int r = lane; r < N; r += 64) SPEC[r * KH + k] = Y[r + CREF];
-    wave_lds_sync();
+  for (int kc0 = wid * 4; kc0 < KH; kc0 += C::NW * 4) {
+    const int kc = kc0 + qid;
+    const bool active = kc < KH;
+    const int kcs = active ? kc : 0;
+    float2 x[N2];
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) {
+      const int r = l16 + 16 * n2;
+      x[n2] = (active && r < N) ? SPEC[r * KH + kcs] : make_float2(0.f, 0.f);
+    }
+    quarter_fft_fwd<L>(x, l16, TW);
+#pragma unroll
+    for (int k2 = 0; k2 < N2; ++k2) x[k2] = cmul(x[k2], Ste[(size_t)kcs * L + kbase + k2]);
+    quarter_fft_inv<L>(x, l16, TW);
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) {
+      const int r = l16 + 16 * n2 - CREF;
+      if (active && r >= 0 && r < N) SPEC[r * KH + kcs] = x[n2];
+    }
   }
   __syncthreads();
   LC_JSTAMP(3);
   // ---- phase C: inverse rows -> model, residuals; forward rows of the up-sampled weighted residual ----
   float acc_chi = 0.f, acc_mean = 0.f, acc_fis = 0.f;
   const float *de = A.data + (size_t)e * n * n, *we = A.wgt + (size_t)e * n * n;
-  for (int rp = wid; rp < N / 2; rp += C::NW) {
-    const int u0 = 2 * rp;
-    for (int k = lane; k < L; k += 64) {
-      float2 z;
-      if (k <= L / 2) {
-        const float2 x1 = SPEC[u0 * KH + k], x2 = SPEC[(u0 + 1) * KH + k];
-        z = make_float2(x1.x - x2.y, x1.y + x2.x);
-      } else {
-        const float2 x1 = SPEC[u0 * KH + (L - k)], x2 = SPEC[(u0 + 1) * KH + (L - k)];
-        z = make_float2(x1.x + x2.y, x2.x - x1.y);
-      }
-      wsA[k] = z;
+  for (int rp0 = wid * 4; rp0 < N / 2; rp0 += C::NW * 4) {
+    const int rp = rp0 + qid, u0 = 2 * rp;
+    const bool active = rp < N / 2;
+    float2 x[N2];
+    pack_rows(x, u0, active);
+    quarter_fft_inv<L>(x, l16, TW);
+    constexpr int NTURN = C::WSQ ? 1 : 4;
+#pragma unroll
+    for (int turn = 0; turn < NTURN; ++turn) {
+    const bool mine = C::WSQ || (qid == turn);  // with a per-wave buffer the quarters take turns
+    if (!C::WSQ) wave_lds_sync();
+    if (mine) {
+#pragma unroll
+      for (int n2 = 0; n2 < N2; ++n2) wsq[l16 + 16 * n2] = x[n2];  // linear order for the data-space step
     }
-    float2 *Y = wave_fft<L, true>(wsA, wsB, TW, lane);
-    float2 *O = (Y == wsA) ? wsB : wsA;
-    // model, residual; O receives the adjoint input rows (offset by CREF), zero elsewhere
-    for (int v = lane; v < L; v += 64) O[v] = make_float2(0.f, 0.f);
     wave_lds_sync();
-    if (SS == 2) {
-      const int I = rp;
-      for (int jd = lane; jd < n; jd += 64) {
-        const float2 y0 = Y[2 * jd + CREF], y1 = Y[2 * jd + 1 + CREF];
-        const float conv = (y0.x + y1.x) + (y0.y + y1.y);
-        const float model = conv + meane;
-        const float w = we[I * n + jd];
-        if (A.mode == 2) {
-          acc_fis = fmaf(w * conv, conv, acc_fis);
-        } else {
-          const float res = model - de[I * n + jd];
-          const float rw = w * res;
-          acc_chi = fmaf(rw, res, acc_chi);
-          acc_mean += rw;
-          if (A.model_out) A.model_out[(size_t)e * n * n + I * n + jd] = model;
-          O[2 * jd + CREF] = make_float2(rw, rw);
-          O[2 * jd + 1 + CREF] = make_float2(rw, rw);
-        }
-      }
-    } else {
-      for (int v = lane; v < n; v += 64) {
-        const float2 y = Y[v + CREF];
-        const float w0 = we[u0 * n + v], w1 = we[(u0 + 1) * n + v];
-        if (A.mode == 2) {
-          acc_fis = fmaf(w0 * y.x, y.x, acc_fis);
-          acc_fis = fmaf(w1 * y.y, y.y, acc_fis);
-        } else {
-          const float m0 = y.x + meane, m1 = y.y + meane;
-          const float r0 = m0 - de[u0 * n + v], r1 = m1 - de[(u0 + 1) * n + v];
-          const float rw0 = w0 * r0, rw1 = w1 * r1;
-          acc_chi = fmaf(rw0, r0, acc_chi);
-          acc_chi = fmaf(rw1, r1, acc_chi);
-          acc_mean += rw0 + rw1;
-          if (A.model_out) {
-            A.model_out[(size_t)e * n * n + u0 * n + v] = m0;
-            A.model_out[(size_t)e * n * n + (u0 + 1) * n + v] = m1;
+    constexpr int NDP = (n + 15) / 16;  // data pixels of this quarter's row(s) per lane
+    float rw0[NDP], rw1[NDP];
+#pragma unroll
+    for (int t = 0; t < NDP; ++t) {
+      rw0[t] = rw1[t] = 0.f;
+      const int jd = l16 + 16 * t;
+      if (mine && active && jd < n) {
+        if (SS == 2) {
+          const int I = rp;
+          const float2 y0 = wsq[2 * jd + CREF], y1 = wsq[2 * jd + 1 + CREF];
+          const float conv = (y0.x + y1.x) + (y0.y + y1.y);
+          const float w = we[I * n + jd];
+          if (A.mode == 2) {
+            acc_fis = fmaf(w * conv, conv, acc_fis);
+          } else {
+            const float model = conv + meane;
+            const float res = model - de[I * n + jd];
+            const float rw = w * res;
+            acc_chi = fmaf(rw, res, acc_chi);
+            acc_mean += rw;
+            if (A.model_out) A.model_out[(size_t)e * n * n + I * n + jd] = model;
+            rw0[t] = rw;
           }
-          O[v + CREF] = make_float2(rw0, rw1);
+        } else {
+          const float2 y = wsq[jd + CREF];
+          const float w0 = we[u0 * n + jd], w1 = we[(u0 + 1) * n + jd];
+          if (A.mode == 2) {
+            acc_fis = fmaf(w0 * y.x, y.x, acc_fis);
+            acc_fis = fmaf(w1 * y.y, y.y, acc_fis);
+          } else {
+            const float m0 = y.x + meane, m1 = y.y + meane;
+            const float r0 = m0 - de[u0 * n + jd], r1 = m1 - de[(u0 + 1) * n + jd];
+            rw0[t] = w0 * r0;
+            rw1[t] = w1 * r1;
+            acc_chi = fmaf(rw0[t], r0, acc_chi);
+            acc_chi = fmaf(rw1[t], r1, acc_chi);
+            acc_mean += rw0[t] + rw1[t];
+            if (A.model_out) {
+              A.model_out[(size_t)e * n * n + u0 * n + jd] = m0;
+              A.model_out[(size_t)e * n * n + (u0 + 1) * n + jd] = m1;
+            }
+          }
         }
       }
     }
     if (A.mode == 0) {
-      float2 *Z = wave_fft<L, false>(O, Y, TW, lane);
-      for (int k = lane; k < KH; k += 64) {
-        const float2 zk = Z[k], zc = Z[(L - k) & (L - 1)];
-        SPEC[u0 * KH + k] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-        SPEC[(u0 + 1) * KH + k] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+      // adjoint input rows: up-sampled weighted residuals at offset CREF, zero elsewhere
+      wave_lds_sync();
+      if (mine) {
+#pragma unroll
+        for (int n2 = 0; n2 < N2; ++n2) wsq[l16 + 16 * n2] = make_float2(0.f, 0.f);
       }
+      wave_lds_sync();
+#pragma unroll
+      for (int t = 0; t < NDP; ++t) {
+        const int jd = l16 + 16 * t;
+        if (mine && active && jd < n) {
+          if (SS == 2) {
+            wsq[2 * jd + CREF] = make_float2(rw0[t], rw0[t]);
+            wsq[2 * jd + 1 + CREF] = make_float2(rw0[t], rw0[t]);
+          } else {
+            wsq[jd + CREF] = make_float2(rw0[t], rw1[t]);
+          }
+        }
+      }
+      wave_lds_sync();
+      if (mine) {
+#pragma unroll
+        for (int n2 = 0; n2 < N2; ++n2) x[n2] = wsq[l16 + 16 * n2];
+      }
+    }
+    }  // turns
+    if (A.mode == 0) {
+      quarter_fft_fwd<L>(x, l16, TW);
+      unpack_rows(x, u0, active);
     }
     wave_lds_sync();
   }
@@ -258,17 +336,25 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   __syncthreads();
   LC_JSTAMP(4);
   // ---- phase B': adjoint columns (rows sit at offset CREF), multiply by conj(spectrum) ------------
-  for (int k = wid; k < KH; k += C::NW) {
-    for (int r = lane; r < L; r += 64) {
-      const int rr = r - CREF;
-      wsA[r] = (rr >= 0 && rr < N) ? SPEC[rr * KH + k] : make_float2(0.f, 0.f);
+  for (int kc0 = wid * 4; kc0 < KH; kc0 += C::NW * 4) {
+    const int kc = kc0 + qid;
+    const bool active = kc < KH;
+    const int kcs = active ? kc : 0;
+    float2 x[N2];
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) {
+      const int r = l16 + 16 * n2 - CREF;
+      x[n2] = (active && r >= 0 && r < N) ? SPEC[r * KH + kcs] : make_float2(0.f, 0.f);
     }
-    float2 *Z = wave_fft<L, false>(wsA, wsB, TW, lane);
-    float2 *O = (Z == wsA) ? wsB : wsA;
-    for (int r = lane; r < L; r += 64) Z[r] = cmul_conj(Z[r], Ste[(size_t)k * L + r]);
-    float2 *Y = wave_fft<L, true>(Z, O, TW, lane);
-    for (int r = lane; r < N; r += 64) SPEC[r * KH + k] = Y[r];
-    wave_lds_sync();
+    quarter_fft_fwd<L>(x, l16, TW);
+#pragma unroll
+    for (int k2 = 0; k2 < N2; ++k2) x[k2] = cmul_conj(x[k2], Ste[(size_t)kcs * L + kbase + k2]);
+    quarter_fft_inv<L>(x, l16, TW);
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) {
+      const int r = l16 + 16 * n2;
+      if (active && r < N) SPEC[r * KH + kcs] = x[n2];
+    }
   }
   __syncthreads();
   LC_JSTAMP(5);
@@ -281,56 +367,46 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   // KH float2 of spectrum row u), so the T^T gather below reads LDS, not global memory
   float *GSl = (float *)SPEC;
   constexpr int GST = 2 * KH;
-  for (int rp = wid; rp < N / 2; rp += C::NW) {
-    const int u0 = 2 * rp;
-    for (int k = lane; k < L; k += 64) {
-      float2 z;
-      if (k <= L / 2) {
-        const float2 x1 = SPEC[u0 * KH + k], x2 = SPEC[(u0 + 1) * KH + k];
-        z = make_float2(x1.x - x2.y, x1.y + x2.x);
-      } else {
-        const float2 x1 = SPEC[u0 * KH + (L - k)], x2 = SPEC[(u0 + 1) * KH + (L - k)];
-        z = make_float2(x1.x + x2.y, x2.x - x1.y);
-      }
-      wsA[k] = z;
-    }
-    float2 *Y = wave_fft<L, true>(wsA, wsB, TW, lane);
-    for (int v = lane; v < N; v += 64) {
-      const float2 g = Y[v];
-      float gsx = 0.f, gsy = 0.f;
+  for (int rp0 = wid * 4; rp0 < N / 2; rp0 += C::NW * 4) {
+    const int rp = rp0 + qid, u0 = 2 * rp;
+    const bool active = rp < N / 2;
+    float2 x[N2];
+    pack_rows(x, u0, active);
+    quarter_fft_inv<L>(x, l16, TW);
 #pragma unroll
-      for (int i = 0; i < kMaxSources; ++i) {
-        if (i < M) {
-          const float gx = tab[(0 * M + i) * N + v], dgx = tab[(1 * M + i) * N + v];
-          const float gy0 = tab[(2 * M + i) * N + u0], gy1 = tab[(2 * M + i) * N + u0 + 1];
-          const float dgy0 = tab[(3 * M + i) * N + u0], dgy1 = tab[(3 * M + i) * N + u0 + 1];
-          const float gg = g.x * gy0 + g.y * gy1;
-          pa[i] = fmaf(gg, gx, pa[i]);
-          pX[i] = fmaf(gg, dgx, pX[i]);
-          pY[i] = fmaf(g.x * dgy0 + g.y * dgy1, gx, pY[i]);
+    for (int n2 = 0; n2 < N2; ++n2) {
+      const int v = l16 + 16 * n2;
+      if (active && v < N) {
+        const float2 g = x[n2];
+#pragma unroll
+        for (int i = 0; i < kMaxSources; ++i) {
+          if (i < M) {
+            const float gx = tab[(0 * M + i) * N + v], dgx = tab[(1 * M + i) * N + v];
+            const float gy0 = tab[(2 * M + i) * N + u0], gy1 = tab[(2 * M + i) * N + u0 + 1];
+            const float dgy0 = tab[(3 * M + i) * N + u0], dgy1 = tab[(3 * M + i) * N + u0 + 1];
+            const float gg = g.x * gy0 + g.y * gy1;
+            pa[i] = fmaf(gg, gx, pa[i]);
+            pX[i] = fmaf(gg, dgx, pX[i]);
+            pY[i] = fmaf(g.x * dgy0 + g.y * dgy1, gx, pY[i]);
+          }
         }
-      }
-      if (use_h) {
-        float Xs, Ys, hx, hy;
-        sample_coords(u0, v, c0, ca, sa, sdx, sdy, Xs, Ys);
-        bilinear_h<N>(A.h, Xs, Ys, hx, hy);
-        acc_dx = fmaf(g.x, SS * (sa * hy - ca * hx), acc_dx);
-        acc_dy = fmaf(g.x, -SS * (sa * hx + ca * hy), acc_dy);
-        sample_coords(u0 + 1, v, c0, ca, sa, sdx, sdy, Xs, Ys);
-        bilinear_h<N>(A.h, Xs, Ys, hx, hy);
-        acc_dx = fmaf(g.y, SS * (sa * hy - ca * hx), acc_dx);
-        acc_dy = fmaf(g.y, -SS * (sa * hx + ca * hy), acc_dy);
-        if (A.need_hgrad) {
-          gsx = g.x;
-          gsy = g.y;
+        if (use_h) {
+          float Xs, Ys, hx, hy;
+          sample_coords(u0, v, c0, ca, sa, sdx, sdy, Xs, Ys);
+          bilinear_h<N>(A.h, Xs, Ys, hx, hy);
+          acc_dx = fmaf(g.x, SS * (sa * hy - ca * hx), acc_dx);
+          acc_dy = fmaf(g.x, -SS * (sa * hx + ca * hy), acc_dy);
+          sample_coords(u0 + 1, v, c0, ca, sa, sdx, sdy, Xs, Ys);
+          bilinear_h<N>(A.h, Xs, Ys, hx, hy);
+          acc_dx = fmaf(g.y, SS * (sa * hy - ca * hx), acc_dx);
+          acc_dy = fmaf(g.y, -SS * (sa * hx + ca * hy), acc_dy);
+          if (A.need_hgrad) {
+            GSl[u0 * GST + v] = g.x;
+            GSl[(u0 + 1) * GST + v] = g.y;
+          }
         }
-      }
-      if (use_h && A.need_hgrad) {
-        GSl[u0 * GST + v] = gsx;
-        GSl[(u0 + 1) * GST + v] = gsy;
       }
     }
-    wave_lds_sync();
   }
   LC_JSTAMP(6);
   // reductions: lanes by shuffles, the four waves in fixed order
