@@ -17,7 +17,7 @@ struct lc_joint {
   float2 *St = nullptr, *twid = nullptr;
   float *par[LC_P_COUNT] = {}, *pm[LC_P_COUNT] = {}, *ps[LC_P_COUNT] = {}, *gout[LC_P_COUNT] = {};
   int psize[LC_P_COUNT] = {};
-  float *tabs = nullptr, *GS = nullptr, *HG = nullptr;
+  float *tabs = nullptr, *HG = nullptr;
   float *chi2_e = nullptr, *g_a = nullptr, *g_cx_e = nullptr, *g_cy_e = nullptr, *g_dx = nullptr, *g_dy = nullptr,
         *g_mean = nullptr;
   float *model = nullptr, *fisher = nullptr, *shared = nullptr, *W = nullptr, *norms = nullptr, *atoms = nullptr,
@@ -159,7 +159,6 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   A.h = j->par[LC_P_H];
   A.mean = j->par[LC_P_MEAN];
   A.tabs = j->tabs;
-  A.GS = j->GS;
   A.HG = j->HG;
   A.chi2_e = j->chi2_e;
   A.g_a = j->g_a;
@@ -285,7 +284,6 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   TRY(dmalloc(j, &j->St, (size_t)E * KH * L));
   TRY(dmalloc(j, &j->twid, L));
   TRY(dmalloc(j, &j->tabs, (size_t)E * 4 * std::max(M, 1) * N));
-  TRY(dmalloc(j, &j->GS, E * NN));
   TRY(dmalloc(j, &j->HG, E * NN));
   TRY(dmalloc(j, &j->chi2_e, E));
   TRY(dmalloc(j, &j->g_a, E * M));

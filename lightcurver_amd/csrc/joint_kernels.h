@@ -34,7 +34,6 @@ struct JointArgs {
   const float2 *twid;         // [L] exp(-2 pi i m / L)
   const float *a, *cx, *cy, *dx, *dy, *alpha, *h, *mean;
   float *tabs;                // [E][4][M][N] gx, dgx, gy, dgy scratch
-  float *GS;                  // [E][N*N] scene-gradient scratch
   float *HG;                  // [E][N*N] T_e^T (scene gradient)
   float *chi2_e, *g_a, *g_cx_e, *g_cy_e, *g_dx, *g_dy, *g_mean;
   float *model_out;           // [E][n][n] or null
