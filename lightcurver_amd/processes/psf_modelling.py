@@ -8,6 +8,39 @@ import numpy as np
 from ..starred.procedures.psf_routines import build_psf_batch
 
 
+def mask_surrounding_stars(data, noisemap, thresh=3.0, minarea=15):
+    """Mask (False) every detected object of a stamp except the one closest to the stamp centre.
+
+    The reference does this with ``sep.extract(data, thresh=3, err=noisemap, minarea=15, deblend_cont=0.001)``
+    (psf_modelling.py:35-61); ``sep`` is a C extension that is not a dependency here, so the segmentation is
+    the SExtractor core without de-blending: 8-connected regions of pixels above ``thresh`` sigma with at
+    least ``minarea`` pixels, object position = flux-weighted barycentre.  Blended neighbours that ``sep``
+    would split stay attached to the central object and are therefore not masked (conservative).
+    """
+    from scipy import ndimage
+    data = np.asarray(data, dtype=np.float64)
+    noisemap = np.asarray(noisemap, dtype=np.float64)
+    mask = np.ones(data.shape, dtype=bool)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        above = np.nan_to_num(data / noisemap, nan=0.0, posinf=0.0, neginf=0.0) > thresh
+    labels, n_obj = ndimage.label(above, structure=np.ones((3, 3), dtype=int))
+    if n_obj == 0:
+        return mask
+    idx = np.arange(1, n_obj + 1)
+    areas = ndimage.sum(above, labels, idx)
+    keep = idx[areas >= minarea]
+    if keep.size == 0:
+        return mask
+    flux = np.where(above, np.clip(data, 0, None), 0.0)
+    centres = np.array(ndimage.center_of_mass(flux, labels, keep))  # (y, x)
+    cy, cx = (data.shape[0] - 1) / 2.0, (data.shape[1] - 1) / 2.0
+    central = keep[np.argmin(np.hypot(centres[:, 0] - cy, centres[:, 1] - cx))]
+    for lab in keep:
+        if lab != central:
+            mask[labels == lab] = False
+    return mask
+
+
 def prepare_psf_stamps(datas, noisemaps, cosmics_masks, automatic_masks=None, mask_threshold_fraction=0.4):
     """Masks and clean-up of one frame's star stamps.
 

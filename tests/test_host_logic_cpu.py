@@ -82,6 +82,20 @@ def test_psf_stamp_preparation_follows_the_reference_rules():
     assert abs(relative_loss_differential(lh) - 0.1 / 9.0) < 1e-12
 
 
+def test_mask_surrounding_stars_keeps_the_central_object():
+    from lightcurver_amd.processes.psf_modelling import mask_surrounding_stars
+    n = 32
+    yy, xx = np.mgrid[0:n, 0:n]
+    star = lambda x0, y0, a: a * np.exp(-0.5 * ((xx - x0) ** 2 + (yy - y0) ** 2) / 2.0 ** 2)
+    data = star(15.3, 15.8, 100.0) + star(5.0, 26.0, 60.0) + 0.1 * np.random.default_rng(0).standard_normal((n, n))
+    noise = np.ones((n, n))
+    m = mask_surrounding_stars(data, noise)
+    assert m.dtype == bool and m.shape == (n, n)
+    assert m[16, 15] and not m[26, 5]            # central star kept, neighbour masked
+    assert (~m).sum() >= 15
+    assert mask_surrounding_stars(0.1 * np.ones((n, n)), noise).all()  # nothing detected: all good
+
+
 def test_star_epoch_preparation_downweights_whole_epochs():
     from lightcurver_amd.processes.star_photometry import prepare_star_epochs
     d = np.ones((4, 6, 6))
