@@ -131,6 +131,10 @@ typedef struct {
 } lc_joint_loss_cfg;
 
 int lc_joint_supported(int n, int ss);
+/* Diagnostic: when on, objects created afterwards for n = 16 or 32 (ss = 2) use the large-grid kernels
+   (spectrum scratch in HBM, multi-block starlet / update) that n = 128 always uses, so that those kernels
+   can be checked against the oracle at sizes the oracle finishes in seconds. Not for production use. */
+int lc_joint_set_debug_global(int on);
 int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data, const float *sigma2,
                     const float *psf, lc_joint **out);
 void lc_joint_destroy(lc_joint *j);

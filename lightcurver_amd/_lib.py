@@ -65,6 +65,7 @@ SIGNATURES = {
     'lc_psf_batch_get_loss_history': (C.c_int, [vp, fp, C.c_int]),
     'lc_psf_batch_get_results': (C.c_int, [vp, fp, fp, fp, fp]),
     'lc_joint_supported': (C.c_int, [C.c_int, C.c_int]),
+    'lc_joint_set_debug_global': (C.c_int, [C.c_int]),
     'lc_joint_create': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.POINTER(vp)]),
     'lc_joint_destroy': (None, [vp]),
     'lc_joint_set_param': (C.c_int, [vp, C.c_int, fp, C.c_int]),

@@ -92,18 +92,13 @@ __device__ __forceinline__ float2 *wave_fft(float2 *a, float2 *b, const float2 *
 __device__ __forceinline__ int bitrev4(int x) {
   return ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3);
 }
-__device__ __forceinline__ float2 w16(int k) {  // exp(-2 pi i k / 16), k in [0, 8)
-  constexpr float c1 = 0.9238795325112867f, s1 = 0.3826834323650898f, r2 = 0.7071067811865476f;
-  switch (k) {
-    case 0: return make_float2(1.f, 0.f);
-    case 1: return make_float2(c1, -s1);
-    case 2: return make_float2(r2, -r2);
-    case 3: return make_float2(s1, -c1);
-    case 4: return make_float2(0.f, -1.f);
-    case 5: return make_float2(-s1, -c1);
-    case 6: return make_float2(-r2, -r2);
-    default: return make_float2(-c1, -s1);
-  }
+__device__ __forceinline__ float2 w32(int k) {  // exp(-2 pi i k / 32), k in [0, 16): compile-time k folds to literals
+  constexpr float c[9] = {1.f, 0.9807852804032304f, 0.9238795325112867f, 0.8314696123025452f, 0.7071067811865476f,
+                          0.5555702330196022f, 0.3826834323650898f, 0.19509032201612825f, 0.f};
+  // cos(pi k / 16) = c[k] for k <= 8, -c[16 - k] above; sin(pi k / 16) = c[8 - k] for k <= 8, c[k - 8] above
+  const float co = (k <= 8) ? c[k] : -c[16 - k];
+  const float si = (k <= 8) ? c[8 - k] : c[k - 8];
+  return make_float2(co, -si);
 }
 __host__ __device__ constexpr int brev_bits(int i, int bits) {
   int r = 0;
@@ -127,7 +122,7 @@ __device__ __forceinline__ void inlane_fft(float2 (&x)[N2]) {
 #pragma unroll
     for (int i = 0; i < N2; ++i) {
       if ((i & h) == 0) {
-        float2 w = w16((i & (h - 1)) * (16 / (2 * h)));
+        float2 w = w32((i & (h - 1)) * (32 / (2 * h)));
         if (INV) w.y = -w.y;
         const float2 a = x[i], b = cmul(x[i + h], w);
         x[i] = make_float2(a.x + b.x, a.y + b.y);
@@ -194,6 +189,7 @@ __device__ __forceinline__ void dit_stage_inv(float2 (&x)[L / 16], int l16, cons
 template <int L>
 __device__ __forceinline__ void quarter_fft_fwd(float2 (&x)[L / 16], int l16, const float2 *tw) {
   constexpr int N2 = L / 16;
+  if constexpr (L >= 512) LC_LAUNDER(l16);  // keep the 2 * N2 twiddle registers from being hoisted out of the caller's loops
   inlane_fft<N2, false>(x);
 #pragma unroll
   for (int k2 = 1; k2 < N2; ++k2) x[k2] = cmul(x[k2], tw[l16 * k2]);
@@ -205,6 +201,7 @@ __device__ __forceinline__ void quarter_fft_fwd(float2 (&x)[L / 16], int l16, co
 template <int L>
 __device__ __forceinline__ void quarter_fft_inv(float2 (&x)[L / 16], int l16, const float2 *tw) {
   constexpr int N2 = L / 16;
+  if constexpr (L >= 512) LC_LAUNDER(l16);
   dit_stage_inv<L, 1>(x, l16, tw);
   dit_stage_inv<L, 2>(x, l16, tw);
   dit_stage_inv<L, 4>(x, l16, tw);

@@ -5,13 +5,26 @@
 #include <cstring>
 
 #include "joint_kernels.h"
+#include "joint_gm.h"
 #include "noise_host.h"
 #include "noise_kernels.h"
 
 using namespace lc;
 
+typedef void (*epoch_fn)(JointArgs);
+typedef void (*update_fn)(JointUpdArgs);
+struct JointVariant {
+  int n, ss, L;
+  epoch_fn ek;
+  int e_lds, e_thr;
+  update_fn uk;  // null: regulariser + update run as global-memory kernels (joint_gm.h)
+  int u_thr, u_lds;
+  bool gspec;
+};
+
 struct lc_joint {
   lc_ctx *ctx = nullptr;
+  const JointVariant *v = nullptr;
   int E = 0, M = 0, n = 0, ss = 0, N = 0, L = 0, J = 0, KH = 0;
   float *data = nullptr, *wgt = nullptr;
   float2 *St = nullptr, *twid = nullptr;
@@ -28,6 +41,8 @@ struct lc_joint {
   bool have_W = false, h_nonzero = false;
   lc_joint_loss_cfg cfg{};
   float *greg = nullptr, *regs = nullptr;
+  float2 *spec = nullptr;             // [E][N][KH] spectrum scratch of the large-grid epoch kernel
+  float *gm_c = nullptr, *gm_t = nullptr, *gm_n = nullptr, *gm_y = nullptr, *gm_l1 = nullptr, *gm_pos = nullptr;
   hipStream_t streamB = nullptr;      // the h regulariser runs here, concurrently with the epoch kernel
   hipEvent_t evReg = nullptr, evUpd = nullptr;
   bool reg_pending = false;
@@ -55,28 +70,35 @@ int d2h(lc_joint *j, void *dst, const void *src, size_t bytes) {
   return LC_OK;
 }
 
-typedef void (*epoch_fn)(JointArgs);
-typedef void (*update_fn)(JointUpdArgs);
-struct JointVariant {
-  int n, ss, L;
-  epoch_fn ek;
-  int e_lds, e_thr;
-  update_fn uk;
-  int u_thr, u_lds;
-};
 template <int N, int SS, int L, int PX, int NW>
 JointVariant make_jv() {
   typedef JointCfg<N, SS, L, NW> C;
   return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, joint_update_kernel<N, PX>, N * N / PX,
-                      (int)(StarletLds<N>::FLOATS * sizeof(float))};
+                      (int)(StarletLds<N>::FLOATS * sizeof(float)), false};
 }
+// large grids: spectrum scratch in HBM, starlet / update as multi-block kernels
+template <int N, int SS, int L, int NW>
+JointVariant make_jv_gm() {
+  typedef JointCfg<N, SS, L, NW, true> C;
+  return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, nullptr, 0, 0, true};
+}
+int g_debug_global = 0;  // lc_joint_set_debug_global: small stamps through the large-grid kernels (parity tests)
 const JointVariant *find_jv(int n, int ss) {
+  if (g_debug_global) {
+    static const JointVariant dbg[] = {
+        make_jv_gm<32, 2, 64, 4>(),
+        make_jv_gm<64, 2, 128, 8>(),
+    };
+    for (const auto &v : dbg)
+      if (v.n == n && v.ss == ss) return &v;
+  }
   static const JointVariant table[] = {
       make_jv<16, 1, 32, 4, 8>(),     // n = 16, ss = 1 (reference test fixture)
       make_jv<32, 2, 64, 4, 16>(),     // n = 16, ss = 2
       make_jv<48, 2, 128, 4, 16>(),    // n = 24 (default stamp_size_stars)
       make_jv<64, 2, 128, 8, 16>(),    // n = 32 (default stamp_size_ROI)
       make_jv<128, 2, 256, 16, 8>(),  // n = 64 (C4)
+      make_jv_gm<256, 2, 512, 8>(),  // n = 128 (C5)
   };
   for (const auto &v : table)
     if (v.n == n && v.ss == ss) return &v;
@@ -137,7 +159,7 @@ bool reg_h_on(const lc_joint *j) {
 }
 
 int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model_out) {
-  const JointVariant *v = find_jv(j->n, j->ss);
+  const JointVariant *v = j->v;
   JointArgs A;
   std::memset(&A, 0, sizeof(A));
   A.E = j->E;
@@ -149,6 +171,7 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   A.data = j->data;
   A.wgt = j->wgt;
   A.St = j->St;
+  A.spec = j->spec;
   A.twid = j->twid;
   A.a = j->par[LC_P_A];
   A.cx = j->par[LC_P_CX];
@@ -184,10 +207,52 @@ int launch_reduce(lc_joint *j, int need_h) {
   return LC_OK;
 }
 
+// starlet l1 + positivity of h as multi-block kernels: -> greg, regs (same contract as reg_mode 1 of joint_update_kernel)
+int launch_reg_gm(lc_joint *j, hipStream_t stream) {
+  const int N = j->N, NN = N * N, J = j->J, nb = (NN + kGmThreads - 1) / kGmThreads;
+  const dim3 grid(nb), block(kGmThreads);
+  const float *W = j->have_W ? j->W : nullptr;
+  LC_HIP(j->ctx, hipMemcpyAsync(j->gm_c, j->par[LC_P_H], (size_t)NN * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  const bool l1_on = (j->cfg.lam_scales != 0.f || j->cfg.lam_hf != 0.f);
+  if (l1_on) {
+    for (int s = 0; s < J; ++s) {
+      const int d = 1 << s;
+      const float lam = (s == 0) ? j->cfg.lam_hf : j->cfg.lam_scales;
+      hipLaunchKernelGGL(gm_pass_kernel, grid, block, 0, stream, N, d, 1, j->gm_c, j->gm_t);
+      hipLaunchKernelGGL(gm_pass_kernel, grid, block, 0, stream, N, d, 0, j->gm_t, j->gm_n);
+      hipLaunchKernelGGL(gm_coef_kernel, grid, block, 0, stream, N, j->gm_n, j->gm_c, W ? W + (size_t)s * NN : nullptr,
+                         j->norms + s, lam, j->qscr + (size_t)s * NN, j->gm_l1 + (size_t)s * nb);
+    }
+    // z_J = 0; z_j = q_j + Row_j^T Col_j^T (z_{j+1} - q_j)
+    LC_HIP(j->ctx, hipMemsetAsync(j->greg, 0, (size_t)NN * sizeof(float), stream));
+    for (int s = J - 1; s >= 0; --s) {
+      const int d = 1 << s;
+      const float *q = j->qscr + (size_t)s * NN;
+      hipLaunchKernelGGL(gm_sub_kernel, grid, block, 0, stream, NN, j->greg, q, j->gm_y);
+      hipLaunchKernelGGL(gm_pass_adjoint_kernel, grid, block, 0, stream, N, d, 0, j->gm_y, (const float *)nullptr, j->gm_t);
+      hipLaunchKernelGGL(gm_pass_adjoint_kernel, grid, block, 0, stream, N, d, 1, j->gm_t, q, j->greg);
+    }
+  } else {
+    LC_HIP(j->ctx, hipMemsetAsync(j->greg, 0, (size_t)NN * sizeof(float), stream));
+  }
+  hipLaunchKernelGGL(gm_positivity_kernel, grid, block, 0, stream, NN, j->par[LC_P_H], j->cfg.lam_positivity, j->greg, j->gm_pos);
+  hipLaunchKernelGGL(gm_regs_kernel, dim3(1), dim3(64), 0, stream, l1_on ? J * nb : 0, nb, j->gm_l1, j->gm_pos, j->regs);
+  LC_HIP(j->ctx, hipGetLastError());
+  return LC_OK;
+}
+
 int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, bool write_hist, bool all_grads,
                   int reg_mode = 0, hipStream_t stream = nullptr) {
   if (!stream) stream = j->ctx->stream;
-  const JointVariant *v = find_jv(j->n, j->ss);
+  const JointVariant *v = j->v;
+  if (!v->uk) {
+    if (reg_mode == 1) return launch_reg_gm(j, stream);
+    if (reg_mode == 0 && reg_h_on(j)) {
+      int rc = launch_reg_gm(j, stream);
+      if (rc) return rc;
+      reg_mode = 2;
+    }
+  }
   JointUpdArgs A;
   std::memset(&A, 0, sizeof(A));
   A.E = j->E;
@@ -231,6 +296,12 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   A.prior_cy_mean = j->prior + 2 * j->M;
   A.prior_cy_sigma = j->prior + 3 * j->M;
   if (cfg) A.ab = *cfg; else lc_adabelief_defaults(&A.ab);
+  if (!v->uk) {
+    const int NN = j->N * j->N;
+    hipLaunchKernelGGL(joint_update_gm_kernel, dim3((NN + kGmThreads - 1) / kGmThreads), dim3(kGmThreads), 0, stream, A, j->N);
+    LC_HIP(j->ctx, hipGetLastError());
+    return LC_OK;
+  }
   LC_HIP(j->ctx, hipFuncSetAttribute((const void *)v->uk, hipFuncAttributeMaxDynamicSharedMemorySize, v->u_lds));
   hipLaunchKernelGGL(v->uk, dim3(1), dim3(v->u_thr), v->u_lds, stream, A);
   LC_HIP(j->ctx, hipGetLastError());
@@ -242,6 +313,10 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
 extern "C" {
 
 int lc_joint_supported(int n, int ss) { return find_jv(n, ss) != nullptr; }
+int lc_joint_set_debug_global(int on) {
+  g_debug_global = on ? 1 : 0;
+  return LC_OK;
+}
 
 int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data, const float *sigma2,
                     const float *psf, lc_joint **out) {
@@ -255,6 +330,7 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   LC_HIP(ctx, hipSetDevice(ctx->device));
   lc_joint *j = new lc_joint();
   j->ctx = ctx;
+  j->v = v;
   j->E = E;
   j->M = M;
   j->n = n;
@@ -303,6 +379,16 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   TRY(dmalloc(j, &j->out_loss, 4));
   TRY(dmalloc(j, &j->greg, NN));
   TRY(dmalloc(j, &j->regs, 4));
+  if (v->gspec) TRY(dmalloc(j, &j->spec, (size_t)E * N * KH));
+  if (!v->uk) {
+    const size_t nb = (NN + kGmThreads - 1) / kGmThreads;
+    TRY(dmalloc(j, &j->gm_c, NN));
+    TRY(dmalloc(j, &j->gm_t, NN));
+    TRY(dmalloc(j, &j->gm_n, NN));
+    TRY(dmalloc(j, &j->gm_y, NN));
+    TRY(dmalloc(j, &j->gm_l1, (size_t)(j->J + 1) * nb));
+    TRY(dmalloc(j, &j->gm_pos, nb));
+  }
   LC_HIP(ctx, hipStreamCreate(&j->streamB));
   LC_HIP(ctx, hipEventCreateWithFlags(&j->evReg, hipEventDisableTiming));
   LC_HIP(ctx, hipEventCreateWithFlags(&j->evUpd, hipEventDisableTiming));
@@ -337,18 +423,26 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   {
     // PSF spectra: FFT2 of the zero-padded narrow PSF, stored transposed and pre-divided by L^2
     j->h_psf.assign(psf, psf + E * NN);
-    std::vector<cd> a((size_t)L * L);
-    std::vector<float2> st((size_t)KH * L);
+    std::vector<float2> st((size_t)E * KH * L);
     const double sc = 1.0 / ((double)L * L);
-    for (int e = 0; e < E; ++e) {
-      std::fill(a.begin(), a.end(), cd(0, 0));
-      for (int r = 0; r < N; ++r)
-        for (int c = 0; c < N; ++c) a[(size_t)r * L + c] = psf[(size_t)e * NN + (size_t)r * N + c];
-      host_fft2d(a, L, 0, N, false);
-      for (int k = 0; k < KH; ++k)
-        for (int r = 0; r < L; ++r) st[(size_t)k * L + r] = make_float2((float)(a[(size_t)r * L + k].real() * sc), (float)(a[(size_t)r * L + k].imag() * sc));
-      TRY(h2d(j, j->St + (size_t)e * KH * L, st.data(), st.size() * sizeof(float2)));
-    }
+    const int T = noise_threads(E);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; ++t)
+      pool.emplace_back([&, t]() {
+        std::vector<cd> a((size_t)L * L);
+        for (int e = t; e < E; e += T) {
+          std::fill(a.begin(), a.end(), cd(0, 0));
+          for (int r = 0; r < N; ++r)
+            for (int c = 0; c < N; ++c) a[(size_t)r * L + c] = psf[(size_t)e * NN + (size_t)r * N + c];
+          host_fft2d(a, L, 0, N, false);
+          float2 *se = st.data() + (size_t)e * KH * L;
+          for (int k = 0; k < KH; ++k)
+            for (int r = 0; r < L; ++r)
+              se[(size_t)k * L + r] = make_float2((float)(a[(size_t)r * L + k].real() * sc), (float)(a[(size_t)r * L + k].imag() * sc));
+        }
+      });
+    for (auto &th : pool) th.join();
+    TRY(h2d(j, j->St, st.data(), st.size() * sizeof(float2)));
   }
   for (int k = 0; k < LC_P_COUNT; ++k) j->free_mask[k] = 0;
 #undef TRY
@@ -402,6 +496,8 @@ int lc_joint_set_free(lc_joint *j, const int32_t *free_mask) {
 }
 int lc_joint_set_loss(lc_joint *j, const lc_joint_loss_cfg *cfg, const float *W) {
   if (!j || !cfg) return LC_ERR_INVALID;
+  if (!j->v->uk && cfg->lam_pts_source != 0.f)
+    LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "regularization_strength_pts_source is not available for this stamp size");
   j->cfg = *cfg;
   j->n_prior = 0;
   if (cfg->n_prior > 0) {

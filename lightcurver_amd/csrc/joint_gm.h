@@ -1,0 +1,232 @@
+// Global-memory variant of the regularise + update step of the joint fit, for background grids whose
+// starlet no longer fits one workgroup's LDS (N = 256: 128 x 128 ROIs, BASELINE.json configs[4]).
+// Same arithmetic as joint_update_kernel / starlet_device.h, spread over plain multi-block kernels:
+//   forward  : per scale j   tmp = Row_j c ; c' = Col_j tmp ; w = c - c' ; q_j = lam_j W_j sign(w) ; l1 partials
+//   backward : per scale j   y = z - q_j ; tmp = Col_j^T y ; z = q_j + Row_j^T tmp      (exact edge-replicating adjoint)
+// then one kernel applies AdaBelief to h (all blocks) and to the small parameter blocks (block 0).
+// The launches go on the second stream and overlap the epoch kernel, which is long at this size.
+#pragma once
+#include "joint_kernels.h"
+
+namespace lc {
+
+constexpr int kGmThreads = 256;
+
+__device__ __forceinline__ float gm_b3(int t) { return (t == 0) ? 0.375f : ((t == 1 || t == -1) ? 0.25f : 0.0625f); }
+
+// out = pass along rows (axis 1) or columns (axis 0) of the edge-replicating 5-tap filter with dilation d
+__global__ void gm_pass_kernel(int N, int d, int axis, const float *in, float *out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N * N) return;
+  const int u = k / N, v = k % N;
+  float acc = 0.f;
+#pragma unroll
+  for (int t = -2; t <= 2; ++t) {
+    const int uu = axis == 0 ? min(max(u + t * d, 0), N - 1) : u;
+    const int vv = axis == 1 ? min(max(v + t * d, 0), N - 1) : v;
+    acc = fmaf(gm_b3(t), in[uu * N + vv], acc);
+  }
+  out[k] = acc;
+}
+
+// c holds c_j on entry and c_{j+1} = cn on exit; q_j = lam W_j sign(c_j - c_{j+1}); per-block l1 partial sums
+__global__ void gm_coef_kernel(int N, const float *cn, float *c, const float *Wj, const float *norm, float lam, float *q,
+                               float *l1_part) {
+  __shared__ float red[kGmThreads / 64];
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  float l1 = 0.f;
+  if (k < N * N) {
+    const float w = c[k] - cn[k];
+    const float lw = lam * (Wj ? Wj[k] : norm[0]);
+    l1 = lw * fabsf(w);
+    q[k] = (w > 0.f) ? lw : ((w < 0.f) ? -lw : 0.f);
+    c[k] = cn[k];
+  }
+  l1 = wave_sum_shfl(l1);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kGmThreads / 64; ++w) t += red[w];
+    l1_part[blockIdx.x] = t;
+  }
+}
+
+__global__ void gm_sub_kernel(int NN, const float *z, const float *q, float *y) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < NN) y[k] = z[k] - q[k];
+}
+
+// adjoint of gm_pass_kernel along `axis`; when q != null the result is q + adjoint (the recursion step)
+__global__ void gm_pass_adjoint_kernel(int N, int d, int axis, const float *in, const float *q, float *out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N * N) return;
+  const int u = k / N, v = k % N;
+  const int x = axis == 0 ? u : v;               // position along the line
+  const int stride = axis == 0 ? N : 1;
+  const float *line = in + (axis == 0 ? v : u * N);
+  float acc;
+  if (x > 0 && x < N - 1) {
+    acc = 0.f;
+#pragma unroll
+    for (int t = -2; t <= 2; ++t) {
+      const int xx = x - t * d;
+      if (xx >= 0 && xx <= N - 1) acc = fmaf(gm_b3(t), line[xx * stride], acc);
+    }
+  } else if (x == 0) {
+    float s1 = 0.f, s2 = 0.f;
+    const int m1 = min(d, N - 1), m2 = min(2 * d, N - 1);
+    for (int xx = 0; xx <= m2; ++xx) {
+      const float g = line[xx * stride];
+      if (xx <= m1) s1 += g;
+      s2 += g;
+    }
+    acc = 0.375f * line[0] + 0.25f * s1 + 0.0625f * s2;
+  } else {
+    float s1 = 0.f, s2 = 0.f;
+    const int m1 = max(N - 1 - d, 0), m2 = max(N - 1 - 2 * d, 0);
+    for (int xx = m2; xx <= N - 1; ++xx) {
+      const float g = line[xx * stride];
+      if (xx >= m1) s1 += g;
+      s2 += g;
+    }
+    acc = 0.375f * line[(N - 1) * stride] + 0.25f * s1 + 0.0625f * s2;
+  }
+  out[k] = (q ? q[k] : 0.f) + acc;
+}
+
+// greg += positivity sub-gradient; per-block positivity partial sums
+__global__ void gm_positivity_kernel(int NN, const float *h, float lam_pos, float *greg, float *pos_part) {
+  __shared__ float red[kGmThreads / 64];
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  float pos = 0.f;
+  if (k < NN && lam_pos != 0.f && h[k] < 0.f) {
+    pos = -lam_pos * h[k];
+    greg[k] -= lam_pos;
+  }
+  pos = wave_sum_shfl(pos);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pos;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kGmThreads / 64; ++w) t += red[w];
+    pos_part[blockIdx.x] = t;
+  }
+}
+
+// ordered sums of the partials -> regs[0] = l1, regs[1] = positivity
+__global__ void gm_regs_kernel(int nparts_l1, int nblocks, const float *l1_part, const float *pos_part, float *regs) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < nparts_l1; ++i) a += l1_part[i];
+    for (int i = 0; i < nblocks; ++i) b += pos_part[i];
+    regs[0] = a;
+    regs[1] = b;
+  }
+}
+
+// AdaBelief on h (every block) and on the small blocks + loss (block 0).  A.greg / A.regs hold the h regulariser.
+__global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArgs A, int N) {
+  __shared__ float sc[8];
+  __shared__ float red[kGmThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int E = A.E, M = A.M, NN = N * N;
+  const float Etot = A.shared[NN + 4 * M + 1];
+  const bool use_reg = (A.reg_mode == 2);
+  if (tid == 0) {
+    const double t1 = (double)(A.t + 1);
+    double lr = A.ab.init_learning_rate;
+    if (A.ab.schedule_learning_rate) lr *= pow((double)A.ab.decay_rate, (double)A.t / (double)A.ab.transition_steps);
+    sc[0] = (float)lr;
+    sc[1] = (float)(1.0 / (1.0 - pow((double)A.ab.b1, t1)));
+    sc[2] = (float)(1.0 / (1.0 - pow((double)A.ab.b2, t1)));
+  }
+  __syncthreads();
+  const float lr = sc[0], bc1 = sc[1], bc2 = sc[2];
+  const int k = blockIdx.x * blockDim.x + tid;
+  if (k < NN) {
+    const float g = A.shared[k] + (use_reg ? A.greg[k] : 0.f);
+    if (A.mode == 0 && A.gout[LC_P_H]) A.gout[LC_P_H][k] = g;
+    if (A.mode == 1 && A.free_mask[LC_P_H]) {
+      float hv = A.h[k], m = A.mh[k], s = A.sh[k];
+      adabelief_step(hv, m, s, g, lr, bc1, bc2, A.ab);
+      A.h[k] = hv;
+      A.mh[k] = m;
+      A.sh[k] = s;
+    }
+  }
+  if (blockIdx.x != 0) return;
+  // ---- block 0: small parameter blocks and the loss (same rules as joint_update_kernel) ----
+  float pos_ps = 0.f;
+  for (int idx = tid; idx < E * M; idx += kGmThreads) {
+    const int i = idx % M;
+    float av = A.par[LC_P_A][idx];
+    float ga = A.g_a[idx];
+    if (A.lam_pos_ps != 0.f && av < 0.f) {
+      pos_ps += -A.lam_pos_ps * av;
+      ga -= A.lam_pos_ps;
+    }
+    if (A.lam_fu != 0.f && Etot > 1.f) {
+      const float mean = A.shared[NN + 2 * M + i] / Etot;
+      const float var = fmaxf(A.shared[NN + 3 * M + i] / Etot - mean * mean, 0.f);
+      const float sd = sqrtf(var);
+      if (sd > 0.f) ga += A.lam_fu * (av - mean) / (Etot * sd);
+    }
+    if (A.mode == 0) {
+      if (A.gout[LC_P_A]) A.gout[LC_P_A][idx] = ga;
+    } else if (A.free_mask[LC_P_A]) {
+      adabelief_step(av, A.pm[LC_P_A][idx], A.ps[LC_P_A][idx], ga, lr, bc1, bc2, A.ab);
+      A.par[LC_P_A][idx] = av;
+    }
+  }
+  for (int idx = tid; idx < 3 * E; idx += kGmThreads) {
+    const int which = (idx / E == 0) ? LC_P_DX : (idx / E == 1) ? LC_P_DY : LC_P_MEAN;
+    const int e = idx % E;
+    const float gv = (which == LC_P_DX) ? A.g_dx[e] : (which == LC_P_DY) ? A.g_dy[e] : A.g_mean[e];
+    if (A.mode == 0) {
+      if (A.gout[which]) A.gout[which][e] = gv;
+    } else if (A.free_mask[which]) {
+      float pv_ = A.par[which][e];
+      adabelief_step(pv_, A.pm[which][e], A.ps[which][e], gv, lr, bc1, bc2, A.ab);
+      A.par[which][e] = pv_;
+    }
+  }
+  double prior_loss = 0.0;
+  if (tid < 2 * M) {
+    const int which = (tid < M) ? LC_P_CX : LC_P_CY, i = tid % M;
+    float gv = A.shared[NN + (which == LC_P_CX ? 0 : M) + i];
+    float cv = A.par[which][i];
+    if (A.n_prior > 0) {
+      const float mu = (which == LC_P_CX) ? A.prior_cx_mean[i] : A.prior_cy_mean[i];
+      const float sg = (which == LC_P_CX) ? A.prior_cx_sigma[i] : A.prior_cy_sigma[i];
+      gv += (cv - mu) / (sg * sg);
+      const double zz = ((double)cv - mu) / sg;
+      prior_loss = 0.5 * zz * zz;
+    }
+    if (A.mode == 0) {
+      if (A.gout[which]) A.gout[which][i] = gv;
+    } else if (A.free_mask[which]) {
+      adabelief_step(cv, A.pm[which][i], A.ps[which][i], gv, lr, bc1, bc2, A.ab);
+      A.par[which][i] = cv;
+    }
+  }
+  // loss = 0.5 chi2 + l1 + positivity + positivity of fluxes + flux uniformity + prior
+  float part = wave_sum_shfl(pos_ps + (float)prior_loss);
+  if (lane == 0) red[wid] = part;
+  __syncthreads();
+  if (tid == 0) {
+    double loss = 0.5 * (double)A.shared[NN + 4 * M];
+    for (int w = 0; w < kGmThreads / 64; ++w) loss += red[w];
+    if (use_reg) loss += (double)A.regs[0] + (double)A.regs[1];
+    if (A.lam_fu != 0.f && Etot > 1.f)
+      for (int i = 0; i < M; ++i) {
+        const double mean = A.shared[NN + 2 * M + i] / Etot;
+        const double var = fmax((double)A.shared[NN + 3 * M + i] / Etot - mean * mean, 0.0);
+        loss += A.lam_fu * sqrt(var);
+      }
+    if (A.hist) A.hist[A.t] = (float)loss;
+    if (A.out_loss) *A.out_loss = (float)loss;
+  }
+}
+
+}  // namespace lc

@@ -31,6 +31,7 @@ struct JointArgs {
   int h_active, need_hgrad;   // h present in the scene; produce T^T slabs
   const float *data, *wgt;    // [E][n][n], wgt = 1 / sigma^2 (0 where invalid)
   const float2 *St;           // [E][L/2+1][L] PSF spectrum / L^2, transposed
+  float2 *spec;               // [E][N][L/2+1] global spectrum scratch (GSPEC kernels only)
   const float2 *twid;         // [L] exp(-2 pi i m / L)
   const float *a, *cx, *cy, *dx, *dy, *alpha, *h, *mean;
   float *tabs;                // [E][4][M][N] gx, dgx, gy, dgy scratch
@@ -62,13 +63,15 @@ __device__ __forceinline__ float bilinear_h(const float *h, float Xs, float Ys, 
   return top + fy * (bot - top);
 }
 
-template <int N_, int SS_, int L_, int NW_>
+template <int N_, int SS_, int L_, int NW_, bool GSPEC_ = false>
 struct JointCfg {
   static constexpr int N = N_, SS = SS_, L = L_, n = N / SS;
+  // GSPEC: the N x (L/2+1) half spectrum of the epoch lives in a global scratch instead of LDS (N = 256 does not fit)
+  static constexpr bool GSPEC = GSPEC_;
   static constexpr int NW = NW_, NTHR = 64 * NW_;  // waves per epoch workgroup: as many as the LDS workspace allows
   static constexpr int KH = L / 2 + 1;           // stored spectrum columns
   static constexpr int OFF_SPEC = 0;             // float2 units
-  static constexpr int SZ_SPEC = N * KH;
+  static constexpr int SZ_SPEC = GSPEC ? 0 : N * KH;
   static constexpr int OFF_WS = OFF_SPEC + SZ_SPEC;
   // linear row buffer(s) for the data-space step: one per quarter-wave when LDS allows (N <= 64), else one per
   // wave that the four quarters use in turn
@@ -89,7 +92,7 @@ template <class C>
 __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   constexpr int N = C::N, SS = C::SS, L = C::L, n = C::n, KH = C::KH, CREF = C::CREF;
   extern __shared__ __align__(16) float2 lds2[];
-  float2 *SPEC = lds2 + C::OFF_SPEC;
+  float2 *SPEC = C::GSPEC ? (A.spec + (size_t)blockIdx.x * N * KH) : (lds2 + C::OFF_SPEC);
   float2 *TW = lds2 + C::OFF_TW;
   float *RED = (float *)(lds2 + C::OFF_RED);
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
