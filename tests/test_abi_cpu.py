@@ -39,7 +39,7 @@ def test_no_cpu_fallback_without_gpu():
         _lib.Context(0)
     # stamp-size queries need no device
     assert lib.lc_psf_supported(32, 2) == 1 and lib.lc_psf_supported(33, 2) == 0
-    assert lib.lc_joint_supported(64, 2) == 1 and lib.lc_joint_supported(128, 2) == 0
+    assert lib.lc_joint_supported(64, 2) == 1 and lib.lc_joint_supported(128, 2) == 1 and lib.lc_joint_supported(100, 2) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):
