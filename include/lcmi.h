@@ -42,6 +42,9 @@ int lc_ctx_create(int device, lc_ctx **out);
 void lc_ctx_destroy(lc_ctx *ctx);
 const char *lc_last_error(const lc_ctx *ctx); /* ctx may be NULL: last error of a failed create */
 int lc_ctx_synchronize(lc_ctx *ctx);
+/* the hipStream_t every kernel of this context is enqueued on (and its device ordinal), so that a caller can
+ * order its own work -- e.g. the RCCL all-reduce of the joint fit's shared block -- without a host sync */
+int lc_ctx_stream(lc_ctx *ctx, void **hip_stream, int *device);
 /* HIP-event timer on the context's stream (the stream every kernel of this library runs on). */
 int lc_timer_start(lc_ctx *ctx);
 int lc_timer_stop(lc_ctx *ctx, float *elapsed_ms);
@@ -162,7 +165,7 @@ int lc_joint_fisher_flux_sigma(lc_joint *j, float *sigma_a);
 int lc_joint_step_local(lc_joint *j);                      /* forward/backward of local epochs */
 int lc_joint_shared_buffer_dev(lc_joint *j, void **dev_ptr, int *count);
 int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg); /* regularise + AdaBelief */
-/* host-staged access to the shared block (round-1 collective path: D2H, all-reduce, H2D) */
+/* host-staged access to the shared block (gloo / CPU collectives: D2H, all-reduce, H2D) */
 int lc_joint_shared_get(lc_joint *j, float *host, int count);
 int lc_joint_shared_set(lc_joint *j, const float *host, int count);
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     'lc_ctx_create': (C.c_int, [C.c_int, C.POINTER(vp)]),
     'lc_ctx_destroy': (None, [vp]),
     'lc_last_error': (C.c_char_p, [vp]),
+    'lc_ctx_stream': (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     'lc_ctx_synchronize': (C.c_int, [vp]),
     'lc_timer_start': (C.c_int, [vp]),
     'lc_timer_stop': (C.c_int, [vp, fp]),
@@ -90,6 +91,26 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """A process can drive the GPU through ONE HIP runtime.  The PyTorch-ROCm wheel bundles its own
+    libamdhip64 / libhsa-runtime64; if liblcmi.so pulled in the system copies first, a later torch.cuda (RCCL
+    collectives of the sharded joint fit) would find no device.  So when torch is installed its runtime is
+    loaded first and liblcmi.so binds to it (same soname); without torch the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if 'torch' in sys.modules:
+        return
+    spec = importlib.util.find_spec('torch')
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load liblcmi.so and attach the prototypes; raises if the HIP extension is missing."""
     global _lib
@@ -98,6 +119,7 @@ def lib():
             raise RuntimeError(
                 f'{LIB_PATH} is missing: the HIP extension has not been built '
                 '(run __graft_entry__.build() or make -C lightcurver_amd/csrc). There is no CPU fallback.')
+        _share_hip_runtime_with_torch()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the library does not export a declared symbol
@@ -143,6 +165,13 @@ class Context:
 
     def synchronize(self):
         self.check(self._l.lc_ctx_synchronize(self.h), 'lc_ctx_synchronize')
+
+    def stream(self):
+        """(hipStream_t as int, device ordinal) of this context."""
+        p = C.c_void_p()
+        d = C.c_int()
+        self.check(self._l.lc_ctx_stream(self.h, C.byref(p), C.byref(d)), 'lc_ctx_stream')
+        return int(p.value or 0), d.value
 
     def timer_start(self):
         self.check(self._l.lc_timer_start(self.h), 'lc_timer_start')

@@ -65,6 +65,13 @@ int lc_ctx_synchronize(lc_ctx *ctx) {
   return LC_OK;
 }
 
+int lc_ctx_stream(lc_ctx *ctx, void **hip_stream, int *device) {
+  if (!ctx || !hip_stream) return LC_ERR_INVALID;
+  *hip_stream = (void *)ctx->stream;
+  if (device) *device = ctx->device;
+  return LC_OK;
+}
+
 int lc_timer_start(lc_ctx *ctx) {
   if (!ctx) return LC_ERR_INVALID;
   LC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));

@@ -8,10 +8,19 @@ is sum-all-reduced, and every rank applies the identical regularisation + AdaBel
 replicas stay in lock step.  The reference has no counterpart: it keeps all epochs in
 one JAX array on one device (lightcurver/processes/roi_modelling.py:154-160,213).
 
-Round 1 stages the block through the host (works with the gloo and the nccl backend alike); the PSF
-fit needs no collective at all (frames shard, see bench.py).
+With the nccl (= RCCL) backend the block is all-reduced in place in device memory, enqueued on the
+library's own HIP stream (no host synchronisation inside the loop); with gloo (CPU tests) it is staged
+through the host.  The PSF fit needs no collective at all (frames shard, see bench.py).
 """
 import numpy as np
+
+
+class _DeviceBlock:
+    """Exposes a raw device pointer through __cuda_array_interface__ so that torch can view it."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = dict(shape=(int(count),), typestr='<f4', data=(int(ptr), False),
+                                             version=2, strides=None)
 
 
 def shard_epochs(n_epochs, world_size, rank):
@@ -44,6 +53,32 @@ class ShardedJointOptimizer:
     def __init__(self, local_fit, group=None):
         self.fit = local_fit
         self.group = group
+        self._dev = None  # (tensor view of the shared block, torch ExternalStream of the library's stream)
+
+    def _device_collective(self):
+        """RCCL path: available when the process group is nccl and the fit is a device object."""
+        import torch
+        import torch.distributed as dist
+        if self._dev is not None:
+            return self._dev
+        if not (dist.is_initialized() and dist.get_backend(self.group) == 'nccl'
+                and hasattr(self.fit, 'shared_buffer') and hasattr(self.fit, 'ctx')):
+            self._dev = False
+            return False
+        ptr, count = self.fit.shared_buffer()
+        stream_ptr, device = self.fit.ctx.stream()
+        view = torch.as_tensor(_DeviceBlock(ptr, count), device=torch.device('cuda', device))
+        ext = torch.cuda.ExternalStream(stream_ptr, device=torch.device('cuda', device))
+        self._dev = (view, ext)
+        return self._dev
+
+    def all_reduce_device(self):
+        """Sum-all-reduce the shared block where it lives, ordered on the library's stream."""
+        import torch
+        import torch.distributed as dist
+        view, ext = self._dev
+        with torch.cuda.stream(ext):
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
 
     def all_reduce(self, buf):
         import torch
@@ -55,9 +90,13 @@ class ShardedJointOptimizer:
         return t.numpy()
 
     def run(self, n_iter, **adabelief_cfg):
+        on_device = bool(self._device_collective())
         for _ in range(int(n_iter)):
             self.fit.step_local()
-            self.fit.shared_set(self.all_reduce(self.fit.shared_get()))
+            if on_device:
+                self.all_reduce_device()
+            else:
+                self.fit.shared_set(self.all_reduce(self.fit.shared_get()))
             self.fit.step_update(**adabelief_cfg)
 
 
