@@ -90,6 +90,45 @@ def joint_fit_secondary(ctx, iters=100):
             'hbm_roofline_frac': rate * bytes_per / 1e9 / HBM_PEAK_GBS, 'loss_finite': bool(np.all(np.isfinite(hist)))}
 
 
+def sharded_joint_fit(ctx, rank, world, iters=100):
+    """Opt-in (--sharded-joint): C4's 200 epochs sharded over the ranks, shared block all-reduced in place by
+    RCCL every iteration (lightcurver_amd/distributed.py).  Strong scaling: the total work is fixed."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from lightcurver_amd.distributed import ShardedJointOptimizer, shard_epochs
+    from lightcurver_amd.joint import JointFit
+    from lightcurver_amd.synthetic import make_roi_dataset
+    E, n, M, ss = 200, 64, 2, 2
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=104)  # same seed on every rank: identical full problem
+    lo, hi = shard_epochs(E, world, rank)
+    j = JointFit(ds['data'][lo:hi], ds['noisemap'][lo:hi].astype(np.float64) ** 2, ds['psf'][lo:hi], ss, M, ctx)
+    p = dict(ds['truth'])
+    p['a'] = (np.asarray(p['a']).reshape(E, M) * 0.9)[lo:hi].reshape(-1)
+    for k in ('dx', 'dy', 'alpha', 'mean'):
+        p[k] = np.asarray(p[k])[lo:hi]
+    j.set_params(**p)
+    j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0)
+    j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
+    torch.cuda.set_device(ctx.stream()[1])
+    group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=120))
+    opt = ShardedJointOptimizer(j, group)
+    ab = dict(init_learning_rate=1e-4, schedule_learning_rate=False)
+    opt.run(5, **ab)
+    ctx.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    opt.run(iters, **ab)
+    ctx.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    hist = j.loss_history()
+    j.close()
+    return {'workload': f'C4 sharded: {E} epochs x {n}x{n} ROI over {world} ranks, RCCL all-reduce of the shared block',
+            'cutouts_per_sec': E * iters / dt, 'us_per_iteration': dt * 1e6 / iters, 'scaling': 'strong',
+            'device_collective': bool(opt._dev), 'loss_finite': bool(np.all(np.isfinite(hist)))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -98,6 +137,8 @@ def main():
     ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-joint', action='store_true', help='skip the secondary joint-fit figure')
+    ap.add_argument('--sharded-joint', action='store_true',
+                    help='also time the epoch-sharded joint fit with the in-place RCCL all-reduce (every rank takes part)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -163,6 +204,19 @@ def main():
     hist = b.loss_history()
     finite = bool(np.all(np.isfinite(hist)))
     res = b.results()
+    sharded = None
+    if args.sharded_joint:
+        import torch.distributed as tdist
+        own_group = False
+        if not tdist.is_initialized():
+            tdist.init_process_group('gloo', init_method='tcp://127.0.0.1:29531', rank=0, world_size=1)
+            own_group = True
+        try:
+            sharded = sharded_joint_fit(ctx, rank, world)
+        except Exception as e:
+            sharded = {'error': repr(e)}
+        if own_group:
+            tdist.destroy_process_group()
 
     if rank == 0:
         cutouts = F * S * world
@@ -206,6 +260,8 @@ def main():
                 out['config']['joint_fit'] = joint_fit_secondary(ctx)
             except Exception as e:
                 out['config']['joint_fit'] = {'error': repr(e)}
+        if sharded is not None:
+            out['config']['sharded_joint_fit'] = sharded
         if not args.no_cpu_baseline and world == 1:
             try:
                 out['cpu_baseline'] = cpu_baseline(ds, ss)
