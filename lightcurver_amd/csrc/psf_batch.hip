@@ -7,6 +7,8 @@
 
 #include "noise_host.h"
 #include "noise_kernels.h"
+#include <cstdlib>
+
 #include "psf_kernels.h"
 
 using namespace lc;
@@ -18,6 +20,9 @@ struct lc_psf_batch {
   float *B = nullptr, *mB = nullptr, *sB = nullptr;
   float *stars = nullptr, *stars_m = nullptr, *stars_s = nullptr, *moffat = nullptr;
   float *hist = nullptr, *qscratch = nullptr;
+  float *xch = nullptr;   // two-workgroup form: exchange slabs, flags, abort word
+  int *xflags = nullptr;
+  bool split_used = false;
   float *o_loss = nullptr, *o_chi2 = nullptr, *o_gstars = nullptr, *o_ggrid = nullptr, *o_gT = nullptr,
         *o_model = nullptr, *o_gmoffat = nullptr;
   float *narrow = nullptr, *full = nullptr, *resid = nullptr, *redchi2 = nullptr;
@@ -177,19 +182,22 @@ struct PsfVariant {
   int n, ss;
   psf_kernel_fn fn;
   int nthr, lds_bytes;
+  psf_kernel_fn fn_split;  // two workgroups per frame, or null
 };
 
-template <class C>
+template <class C, bool WITH_SPLIT = false>
 PsfVariant make_variant() {
-  return PsfVariant{C::n, C::SS, psf_fit_kernel<C>, C::NTHR, (int)(C::LDS_FLOATS * sizeof(float))};
+  psf_kernel_fn split = nullptr;
+  if constexpr (WITH_SPLIT) split = psf_fit_kernel<C, true>;
+  return PsfVariant{C::n, C::SS, psf_fit_kernel<C>, C::NTHR, (int)(C::LDS_FLOATS * sizeof(float)), split};
 }
 
 const PsfVariant *find_variant(int n, int ss) {
   static const PsfVariant table[] = {
       make_variant<PsfCfg<16, 1, 4, 8, true>>(),    // n = 16, ss = 1 (reference test fixture size)
-      make_variant<PsfCfg<32, 2, 4, 8, true>>(),    // n = 16, ss = 2
-      make_variant<PsfCfg<48, 2, 4, 8, true>>(),    // n = 24 (lightcurver default stamp_size_stars)
-      make_variant<PsfCfg<64, 2, 8, 4, true>>(),    // n = 32 (C1, C2)
+      make_variant<PsfCfg<32, 2, 4, 8, true>, true>(),    // n = 16, ss = 2
+      make_variant<PsfCfg<48, 2, 4, 8, true>, true>(),    // n = 24 (lightcurver default stamp_size_stars)
+      make_variant<PsfCfg<64, 2, 8, 4, true>, true>(),    // n = 32 (C1, C2)
       make_variant<PsfCfg<128, 2, 16, 1>>(),  // n = 64 (C3)
   };
   for (const auto &v : table)
@@ -233,9 +241,39 @@ int launch_psf(lc_psf_batch *b, int mode, int n_iter, const lc_adabelief_cfg *cf
   A.lam_sc = reg ? b->lam_sc : 0.f;
   A.lam_hf = reg ? b->lam_hf : 0.f;
   if (cfg) A.ab = *cfg; else lc_adabelief_defaults(&A.ab);
-  LC_HIP(b->ctx, hipFuncSetAttribute((const void *)v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes));
-  hipLaunchKernelGGL(v->fn, dim3(b->F), dim3(v->nthr), v->lds_bytes, b->ctx->stream, A);
+  // Two workgroups per frame when the optimisation loop would otherwise leave more than half of the CUs idle.
+  // Every workgroup of that grid must be resident at once (partners wait for each other): one per CU.
+  const int split_grid = ((b->F + 7) / 8) * 16;
+  const bool split = mode == 1 && v->fn_split && (A.lam_sc != 0.f || A.lam_hf != 0.f) && split_grid <= b->ctx->n_cu &&
+                     !std::getenv("LCMI_PSF_SINGLE_WG");
+  if (split) {
+    if (!b->xch) {
+      int rc = dmalloc(b, &b->xch, (size_t)b->F * 4 * ((size_t)b->N * b->N + 64));
+      if (rc) return rc;
+      if ((rc = dmalloc(b, &b->xflags, (size_t)b->F * 2 + 16))) return rc;
+    }
+    LC_HIP(b->ctx, hipMemsetAsync(b->xflags, 0, ((size_t)b->F * 2 + 16) * sizeof(int), b->ctx->stream));
+    A.xch = b->xch;
+    A.xflags = b->xflags;
+    A.xabort = b->xflags + (size_t)b->F * 2;
+    b->split_used = true;
+    LC_HIP(b->ctx, hipFuncSetAttribute((const void *)v->fn_split, hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes));
+    hipLaunchKernelGGL(v->fn_split, dim3(split_grid), dim3(v->nthr), v->lds_bytes, b->ctx->stream, A);
+  } else {
+    LC_HIP(b->ctx, hipFuncSetAttribute((const void *)v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes));
+    hipLaunchKernelGGL(v->fn, dim3(b->F), dim3(v->nthr), v->lds_bytes, b->ctx->stream, A);
+  }
   LC_HIP(b->ctx, hipGetLastError());
+  return LC_OK;
+}
+
+// after a synchronisation point: did a partner workgroup of the two-workgroup form fail to show up?
+int check_split_abort(lc_psf_batch *b) {
+  if (!b->split_used) return LC_OK;
+  int flag = 0;
+  LC_HIP(b->ctx, hipMemcpyAsync(&flag, b->xflags + (size_t)b->F * 2, sizeof(int), hipMemcpyDeviceToHost, b->ctx->stream));
+  LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
+  if (flag) LC_FAIL(b->ctx, LC_ERR_DEVICE, "PSF fit: a partner workgroup timed out; set LCMI_PSF_SINGLE_WG=1");
   return LC_OK;
 }
 
@@ -570,7 +608,7 @@ int lc_psf_batch_get_loss_history(lc_psf_batch *b, float *history, int stride) {
   LC_HIP(b->ctx, hipMemcpy2DAsync(history, stride * sizeof(float), b->hist, b->hist_stride * sizeof(float),
                                    (b->iters_done + 1) * sizeof(float), b->F, hipMemcpyDeviceToHost, b->ctx->stream));
   LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
-  return LC_OK;
+  return check_split_abort(b);
 }
 
 int lc_psf_batch_get_results(lc_psf_batch *b, float *narrow_psf, float *full_psf, float *residuals, float *chi2) {
@@ -590,7 +628,7 @@ int lc_psf_batch_get_results(lc_psf_batch *b, float *narrow_psf, float *full_psf
   if (residuals && (rc = d2h(b, residuals, b->resid, b->F * b->S * nn * sizeof(float)))) return rc;
   if (chi2 && (rc = d2h(b, chi2, b->redchi2, b->F * sizeof(float)))) return rc;
   LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
-  return LC_OK;
+  return check_split_abort(b);
 }
 
 #ifdef LC_STAMPS

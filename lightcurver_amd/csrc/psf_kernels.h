@@ -41,7 +41,38 @@ struct PsfArgs {
   float *out_loss, *out_chi2, *out_gstars, *out_ggrid, *out_gT, *out_model;  // eval outputs (nullable)
   float lam_sc, lam_hf;
   lc_adabelief_cfg ab;
+  // two workgroups per frame (psf_fit_kernel<C, true>): exchange slabs [F][2 buffers][2 roles][N*N + 64],
+  // per-(frame, role) iteration flags [F][2], one abort word
+  float *xch;
+  int *xflags, *xabort;
 };
+
+// Write-through (sc1) stores and L1-bypassing (sc1) loads for data handed from one workgroup to another
+// inside a launch (MI355X_MICROARCH.md, inter-workgroup visibility: all stores and all loads of the handed-off
+// bytes sc1, every storing wave drains vmcnt, workgroup barrier, one lane raises an sc1 flag).
+typedef float lc_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sc1_x4(float *p, lc_v4f v) {
+  // s_nop: a VMEM store of more than 64 bits followed by a VALU write of its data registers needs wait states;
+  // the compiler's hazard recogniser cannot see inside the asm, so they are spelled out here
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_sc1_f(float *p, float v) {
+  asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void load_sc1_2x4(const float *p, lc_v4f &a, lc_v4f &b) {
+  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(a), "=&v"(b)
+               : "v"(p)
+               : "memory");
+}
+__device__ __forceinline__ void load_sc1_x4(const float *p, lc_v4f &a) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(p) : "memory");
+}
+__device__ __forceinline__ float load_sc1_f(const float *p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
 
 template <int N_, int SS_, int PX_, int SG_, bool WC_ = false>
 struct PsfCfg {
@@ -123,7 +154,13 @@ __device__ inline void tap_entry(float delta, int k, float &tap, float &dtap, in
   dtap = d;
 }
 
-template <class C>
+// SPLIT: two workgroups per frame.  Role 0 evaluates the forward model and the chi2 gradient, role 1 the starlet
+// l1 term of the same B; they swap their halves of dL/dB through L2 once per iteration and both apply the
+// identical AdaBelief update to their own register copy of B (same operands, same order => same bits).
+// Block b serves frame (b / 16) * 8 + b % 8 in role (b / 8) % 2: partners are 8 blocks apart, which the
+// dispatcher is observed to place on one XCD (speed only).  The host launches this form only when the whole grid
+// is resident at once (one workgroup per CU), so the partner a workgroup waits for is always running.
+template <class C, bool SPLIT = false>
 __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
   constexpr int N = C::N, SS = C::SS, PX = C::PX, SG = C::SG, n = C::n, NT = C::NT, J = C::J;
   constexpr int NTHR = C::NTHR, TS = C::TS, RS = C::RS, LR = C::LR, LC = C::LC, LA = C::LA;
@@ -143,7 +180,13 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
   float *SV = SM + C::MAXS * 4;     // moments s [MAXS][4]
   int *BQ = (int *)(SV + C::MAXS * 4);  // [S][2]
 
-  const int f = blockIdx.x;
+  int f = blockIdx.x, role = 0;
+  if constexpr (SPLIT) {
+    f = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7);
+    role = ((int)blockIdx.x >> 3) & 1;
+    if (f >= A.F) return;
+  }
+  const bool conv_role = !SPLIT || role == 0, starlet_role = !SPLIT || role == 1;
   const int tid0 = threadIdx.x;
   const int S = A.S;
 
@@ -164,6 +207,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
   // Pixel state of this thread.  With <= 8 pixels per thread it stays in registers for the whole launch
   // (B, both AdaBelief moments and the Moffat): HBM then sees it once per launch instead of per iteration.
   constexpr bool STATE_REGS = (PX <= 8);
+  static_assert(!SPLIT || STATE_REGS, "the two-workgroup form keeps B in registers");
   float Bp[PX], Mp[PX], Sp_[PX], Tp[PX];
   {
     const size_t g0pix = (size_t)f * N * N + (size_t)(tid0 / (N / PX)) * N + (tid0 % (N / PX)) * PX;
@@ -198,8 +242,11 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       SCAL[2] = (float)(1.0 / (1.0 - pow((double)A.ab.b2, t1)));
     }
     LC_STAMP(0);
-    // ---- P1: T = Moffat + B into LDS -----------------------------------------------------
     float gB[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) gB[p] = 0.f;
+    if (conv_role) {
+    // ---- P1: T = Moffat + B into LDS -----------------------------------------------------
     if (C::WC && STATE_REGS) {
 #pragma unroll
       for (int p = 0; p < PX; ++p) T[pu * C::TSA + C::AP + pv + p] = Bp[p] + Tp[p];
@@ -218,8 +265,6 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         T[pu * TS + pv + 4 * q + 3] = b.w + t.w;
       }
     }
-#pragma unroll
-    for (int p = 0; p < PX; ++p) gB[p] = 0.f;
     if (tid < S * 5) SGR[tid] = 0.f;
 
     // ---- tap tables of every star of the frame (once per iteration) ----------------------------
@@ -617,6 +662,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         }
       }
     }  // groups
+    }  // conv_role
     __syncthreads();
     LC_STAMP(40);
 
@@ -630,7 +676,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     float z[PX];
 #pragma unroll
     for (int p = 0; p < PX; ++p) z[p] = 0.f;
-    if (A.lam_sc != 0.f || A.lam_hf != 0.f) {
+    if (starlet_role && (A.lam_sc != 0.f || A.lam_hf != 0.f)) {
       float bpix[PX];
       if (STATE_REGS) {
 #pragma unroll
@@ -656,9 +702,70 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       if (lane == 0) REDW[wid] = wl;
     }
     __syncthreads();
-    if (tid == 0) {
-      float tl1 = 0.f;
+    float tl1 = 0.f;
+    if (tid == 0 && starlet_role)
       for (int w = 0; w < C::NW; ++w) tl1 += REDW[w];
+    if constexpr (SPLIT) {
+      constexpr int XS = N * N + 64;
+      float *mine = A.xch + (((size_t)f * 2 + (it & 1)) * 2 + role) * XS;
+      const float *theirs = A.xch + (((size_t)f * 2 + (it & 1)) * 2 + (1 - role)) * XS;
+      const int poff = pu * N + pv;
+#pragma unroll
+      for (int q = 0; q < PX / 4; ++q) {
+        lc_v4f v;
+        v.x = role ? z[4 * q] : gB[4 * q];
+        v.y = role ? z[4 * q + 1] : gB[4 * q + 1];
+        v.z = role ? z[4 * q + 2] : gB[4 * q + 2];
+        v.w = role ? z[4 * q + 3] : gB[4 * q + 3];
+        store_sc1_x4(mine + poff + 4 * q, v);
+      }
+      if (tid == 0 && role == 1) store_sc1_f(mine + N * N, tl1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int *OK = (int *)(SCAL + 5);
+      if (tid == 0) {
+        __hip_atomic_store(A.xflags + f * 2 + role, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1, spins = 0;
+        while (__hip_atomic_load(A.xflags + f * 2 + (1 - role), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it + 1) {
+          __builtin_amdgcn_s_sleep(2);
+          ++spins;
+          // exit condition every workgroup reaches: a partner that never shows up is reported, not waited for
+          if (spins > (1 << 21) ||
+              ((spins & 255) == 0 && __hip_atomic_load(A.xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            __hip_atomic_store(A.xabort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = 0;
+            break;
+          }
+        }
+        *OK = ok;
+#ifdef LC_XCH_ACQUIRE
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      }
+      __syncthreads();
+      if (*OK == 0) break;
+      float other[PX];
+      if constexpr (PX == 8) {
+        lc_v4f a, b;
+        load_sc1_2x4(theirs + poff, a, b);
+        other[0] = a.x; other[1] = a.y; other[2] = a.z; other[3] = a.w;
+        other[4] = b.x; other[5] = b.y; other[6] = b.z; other[7] = b.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < PX / 4; ++q) {
+          lc_v4f a;
+          load_sc1_x4(theirs + poff + 4 * q, a);
+          other[4 * q] = a.x; other[4 * q + 1] = a.y; other[4 * q + 2] = a.z; other[4 * q + 3] = a.w;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PX; ++p) {
+        if (role) gB[p] = other[p]; else z[p] = other[p];
+      }
+      if (tid == 0 && role == 0) tl1 = load_sc1_f(theirs + N * N);
+    }
+    if (tid == 0 && conv_role) {
       float chi = 0.f;
       for (int s = 0; s < S; ++s) chi += SGR[s * 5];
       const float loss = 0.5f * chi + tl1;
@@ -676,6 +783,9 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     }
     // ---- AdaBelief update ---------------------------------------------------------------------
     if (A.mode == 1) {
+      // no contraction here: which product of b1 * m + (1 - b1) * g gets fused is the compiler's choice per
+      // instantiation, and the one- and two-workgroup forms of this kernel must produce the same bits
+#pragma clang fp contract(off)
       const float lr = SCAL[0], bc1 = SCAL[1], bc2 = SCAL[2];
       const float b1 = A.ab.b1, b2 = A.ab.b2, eps = A.ab.eps, eps_root = A.ab.eps_root;
       if (STATE_REGS) {
@@ -711,7 +821,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         mp[q] = m;
         sp[q] = s;
       }
-      if (tid < S * 3) {
+      if (tid < S * 3 && conv_role) {
         const int s = tid / 3, q = tid % 3;  // a, x0, y0
         const float g = SGR[s * 5 + 1 + q];
         const float mn = b1 * SM[s * 4 + q] + (1.f - b1) * g;
@@ -726,7 +836,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     LC_STAMP(43);
   }  // iterations
 
-  if (A.mode == 1 && STATE_REGS) {
+  if (A.mode == 1 && STATE_REGS && conv_role) {
     const size_t g0pix = (size_t)f * N * N + (size_t)(tid0 / (N / PX)) * N + (tid0 % (N / PX)) * PX;
 #pragma unroll
     for (int q = 0; q < PX / 4; ++q) {
@@ -735,7 +845,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       ((float4 *)(A.sB + g0pix))[q] = make_float4(Sp_[4 * q], Sp_[4 * q + 1], Sp_[4 * q + 2], Sp_[4 * q + 3]);
     }
   }
-  if (A.mode == 1 && tid0 < S * 4) {
+  if (A.mode == 1 && tid0 < S * 4 && conv_role) {
     A.stars[(size_t)f * S * 4 + tid0] = SP[tid0];
     A.stars_m[(size_t)f * S * 4 + tid0] = SM[tid0];
     A.stars_s[(size_t)f * S * 4 + tid0] = SV[tid0];

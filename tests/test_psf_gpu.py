@@ -144,3 +144,29 @@ def test_moffat_stage_reaches_oracle_optimum(ctx):
         fw_gpu = 0.5 * (mof[f, 0] + mof[f, 1])
         fw_or = 0.5 * (float(po['fwhm_x']) + float(po['fwhm_y']))
         assert abs(fw_gpu - fw_or) / fw_or < 2e-2
+
+
+@pytest.mark.parametrize('n,S,F', [(16, 4, 5), (24, 5, 3), (32, 8, 100)])
+def test_two_workgroup_form_is_bit_identical(ctx, n, S, F):
+    """Small batches run the optimisation loop with two workgroups per frame (chi2 gradient / starlet term,
+    swapped through L2 every iteration, psf_kernels.h SPLIT).  Both forms apply the same operations in the
+    same order, so loss history, grid and star parameters must agree bit for bit with the one-workgroup form
+    (LCMI_PSF_SINGLE_WG=1); F = 100 loads 200 CUs at once, the uneven-load case for the hand-off."""
+    import os
+    ss, T = 2, 60
+    out = []
+    for single in (False, True):
+        if single:
+            os.environ['LCMI_PSF_SINGLE_WG'] = '1'
+        try:
+            ds, plist, b = _setup(n, ss, F, S, 900 + n, ctx, jitter=0.1)
+            b.propagate_noise()
+            b.set_regularization(None, 1.0, 1.0)
+            b.run_adabelief(T, init_learning_rate=1e-4, schedule_learning_rate=True)
+            b.run_adabelief(T // 2, init_learning_rate=1e-4, schedule_learning_rate=True)
+            out.append((b.loss_history(), b.get_grid(), b.get_stars()))
+        finally:
+            os.environ.pop('LCMI_PSF_SINGLE_WG', None)
+    for a, c in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, c)
+    assert np.all(np.isfinite(out[0][0]))
