@@ -296,7 +296,10 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   A.prior_cy_mean = j->prior + 2 * j->M;
   A.prior_cy_sigma = j->prior + 3 * j->M;
   if (cfg) A.ab = *cfg; else lc_adabelief_defaults(&A.ab);
-  if (!v->uk) {
+  // the multi-block update serves the large grids always, and the LDS variants whenever nothing is left for one
+  // workgroup to do alone (h regulariser already evaluated on the second stream, no point-source starlet term):
+  // N^2 / 256 blocks finish the AdaBelief sweep of h in a fraction of the single-workgroup latency
+  if (!v->uk || (A.lam_pts == 0.f && (reg_mode == 2 || !rh))) {
     const int NN = j->N * j->N;
     hipLaunchKernelGGL(joint_update_gm_kernel, dim3((NN + kGmThreads - 1) / kGmThreads), dim3(kGmThreads), 0, stream, A, j->N);
     LC_HIP(j->ctx, hipGetLastError());

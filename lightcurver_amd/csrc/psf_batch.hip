@@ -633,7 +633,7 @@ int lc_psf_batch_get_results(lc_psf_batch *b, float *narrow_psf, float *full_psf
 
 #ifdef LC_STAMPS
 int lc_debug_get_stamps(long long *out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::g_stamps), 64 * sizeof(long long)) == hipSuccess ? 0 : -2;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::g_stamps), 128 * sizeof(long long)) == hipSuccess ? 0 : -2;
 }
 #endif
 

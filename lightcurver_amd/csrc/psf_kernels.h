@@ -16,10 +16,11 @@
 namespace lc {
 
 #ifdef LC_STAMPS
-__device__ long long g_stamps[64];
+__device__ long long g_stamps[128];  // [0, 64): block 0, [64, 128): block 8 (role 1 of frame 0 in the two-workgroup form)
 #define LC_STAMP(k)                                                      \
   do {                                                                   \
-    if (blockIdx.x == 0 && threadIdx.x == 0 && it == A.n_iter - 1) g_stamps[k] = clock64(); \
+    if ((blockIdx.x == 0 || blockIdx.x == 8) && threadIdx.x == 0 && it == A.n_iter - 1)  \
+      g_stamps[(k) + (blockIdx.x == 8 ? 64 : 0)] = clock64();            \
   } while (0)
 #else
 #define LC_STAMP(k) do {} while (0)
@@ -705,6 +706,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     float tl1 = 0.f;
     if (tid == 0 && starlet_role)
       for (int w = 0; w < C::NW; ++w) tl1 += REDW[w];
+    LC_STAMP(44);
     if constexpr (SPLIT) {
       constexpr int XS = N * N + 64;
       float *mine = A.xch + (((size_t)f * 2 + (it & 1)) * 2 + role) * XS;
@@ -722,6 +724,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       if (tid == 0 && role == 1) store_sc1_f(mine + N * N, tl1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      LC_STAMP(45);
       int *OK = (int *)(SCAL + 5);
       if (tid == 0) {
         __hip_atomic_store(A.xflags + f * 2 + role, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -744,6 +747,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
 #endif
       }
       __syncthreads();
+      LC_STAMP(46);
       if (*OK == 0) break;
       float other[PX];
       if constexpr (PX == 8) {
@@ -764,6 +768,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         if (role) gB[p] = other[p]; else z[p] = other[p];
       }
       if (tid == 0 && role == 0) tl1 = load_sc1_f(theirs + N * N);
+      LC_STAMP(47);
     }
     if (tid == 0 && conv_role) {
       float chi = 0.f;

@@ -18,17 +18,22 @@ b.set_moffat(np.stack([f0, f0, np.zeros(F), np.full(F, 2.5)], -1))
 st = np.zeros((F, S, 4), np.float32); st[..., 0] = (ds['data'] * ds['masks']).sum((-1, -2)); b.set_stars(st)
 b.set_grid(None); b.propagate_noise(); b.set_regularization(None, 1.0, 1.0)
 b.run_adabelief(50, init_learning_rate=1e-4); ctx.synchronize()
-out = (C.c_longlong * 64)()
+out = (C.c_longlong * 128)()
 _lib.lib().lc_debug_get_stamps.argtypes = [C.POINTER(C.c_longlong)]
 assert _lib.lib().lc_debug_get_stamps(out) == 0
-s = np.array(out[:], dtype=np.int64)
-names = {0: 'start', 1: 'P1 + taps (to first barrier)', 40: 'conv: wave tasks + P5', 42: 'starlet', 43: 'loss+update'}
-names_old = {0: 'start', 1: 'g0 taps done', 2: 'g0 P2 row', 3: 'g0 P3 col+res', 4: 'g0 P4 colT', 6: 'g1 taps (incl g0 P5)',
-         7: 'g1 P2', 8: 'g1 P3', 9: 'g1 P4', 40: 'groups end (g1 P5)', 41: 'starlet fwd', 42: 'starlet bwd', 43: 'loss+update'}
-keys = [k for k in sorted(names) if s[k] != 0]
-tot = s[43] - s[0]
-prev = s[0]
-for k in keys[1:]:
-    print(f'{names[k]:28s} {s[k]-prev:8d} ticks  {100*(s[k]-prev)/tot:5.1f}%')
-    prev = s[k]
-print('total ticks', tot, '(s_memtime ticks @100MHz => us:', tot / 100.0, ')')
+allst = np.array(out[:], dtype=np.int64)
+names = {0: 'start', 1: 'P1 + taps (to first barrier)', 40: 'conv: wave tasks + P5', 42: 'starlet', 44: 'l1 reduce',
+         45: 'publish (stores, drain, barrier)', 46: 'flag + wait for partner', 47: 'read partner slab', 43: 'loss + update'}
+order = [0, 1, 40, 42, 44, 45, 46, 47, 43]
+for blk, label in ((0, 'block 0 (role 0 / single form)'), (64, 'block 8 (role 1)')):
+    s = allst[blk:blk + 64]
+    if s[43] == 0:
+        continue
+    print(label)
+    keys = [k for k in order if s[k] != 0]
+    tot = s[43] - s[0]
+    prev = s[0]
+    for k in keys[1:]:
+        print(f'  {names[k]:34s} {s[k]-prev:8d} ticks  {100*(s[k]-prev)/tot:5.1f}%')
+        prev = s[k]
+    print('  total ticks', tot, '(s_memtime ticks @100MHz => us:', tot / 100.0, ')')
