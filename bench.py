@@ -81,13 +81,16 @@ def joint_fit_secondary(ctx, iters=100):
     N = n * ss
     J = int(math.log2(N))
     bytes_per = 8 * n * n + 4 * N * N + (24 + 4 * J) * N * N / E
+    flops_per = 10.0 * (2 * N) ** 2 * math.log2((2 * N) ** 2) + 40.0 * N * N  # SURVEY.md 8(d), FFT route
     rate = E * iters / (ms * 1e-3)
     j.close()
     return {'workload': f'C4: {E} epochs x {n}x{n} ROI, {M} point sources + background, all parameters free, '
                         f'{iters} AdaBelief iterations (3 launches per iteration)',
             'cutouts_per_sec': rate, 'us_per_iteration': ms * 1e3 / iters,
             'algorithmic_bytes_per_cutout_iteration': bytes_per,
-            'hbm_roofline_frac': rate * bytes_per / 1e9 / HBM_PEAK_GBS, 'loss_finite': bool(np.all(np.isfinite(hist)))}
+            'hbm_roofline_frac': rate * bytes_per / 1e9 / HBM_PEAK_GBS,
+            'algorithmic_flop_per_cutout_iteration': flops_per, 'fp32_valu_frac_of_157': rate * flops_per / 1e12 / 157.3,
+            'loss_finite': bool(np.all(np.isfinite(hist)))}
 
 
 def sharded_joint_fit(ctx, rank, world, iters=100):
@@ -255,6 +258,14 @@ def main():
                          'fp32_valu_tflops': F * S * ITERS_PER_STEP * flops_per / launch_s / 1e12,
                          'fp32_valu_frac_of_157': F * S * ITERS_PER_STEP * flops_per / launch_s / 1e12 / 157.3},
         }
+        try:  # the box's own copy bandwidth beside the 8 TB/s specification
+            import ctypes
+            g = ctypes.c_float()
+            ctx.check(_lib.lib().lc_copy_bandwidth(ctx.h, 1 << 30, 10, ctypes.byref(g)), 'lc_copy_bandwidth')
+            out['roofline']['measured_copy_GBps'] = g.value
+            out['roofline']['frac_of_measured_copy'] = achieved / g.value
+        except Exception as e:
+            out['roofline']['measured_copy_GBps'] = None
         if world == 1 and not args.no_joint:
             try:
                 out['config']['joint_fit'] = joint_fit_secondary(ctx)

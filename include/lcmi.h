@@ -51,6 +51,28 @@ int lc_timer_stop(lc_ctx *ctx, float *elapsed_ms);
 /* device name + CU count, for reports */
 int lc_device_info(lc_ctx *ctx, char *name, int name_len, int *n_cu, int64_t *hbm_bytes);
 
+/* measured device copy bandwidth (read + write bytes / s) of a float4 grid-stride copy of `bytes` bytes, `reps`
+ * launches: the box's own HBM figure that bench.py reports beside the 8 TB/s specification */
+int lc_copy_bandwidth(lc_ctx *ctx, int64_t bytes, int reps, float *gb_per_s);
+
+/* ---- stamp pre-processing --------------------------------------------
+ * One fused pass over K stamps of npix pixels, replacing the host-side NumPy of the reference:
+ *   noise map from the background rms when `noisemap` is NULL: max(sqrt((t rms)^2 + |t data|), 1e-7) / t
+ *     (lightcurver/processes/cutout_making.py:43-51; rms[K] in e-/s, exptime[K] = t);
+ *   data, noisemap /= coefficient[K] when given (roi_file_preparation.py:162-164);
+ *   pixels that are NaN in both inputs: data = 0, noisemap = nan_noise (1.0 at psf_modelling.py:139-143,
+ *     1e7 at roi_file_preparation.py:194-196 and star_photometry.py:309-311), counted as masked;
+ *   bad[K][npix] (1 = flagged cosmic / bad pixel, may be NULL): masked; with noise_boost > 0 the noise map is
+ *     multiplied by it at the flagged pixels (roi_file_preparation.py:201) or, boost_whole_stamp != 0, once over
+ *     every stamp that holds a flagged pixel (star_photometry.py:316);
+ *   masked_count[K]: masked pixels per stamp, for the 40 % cut of psf_modelling.py:144-153.
+ * Outputs (any may be NULL): data_out, noisemap_out, weight_out = good / noisemap^2 (what lc_psf_batch_create
+ * takes), masked_count; kernel_ms = device time of the kernel alone (HIP events). */
+int lc_prepare_stamps(lc_ctx *ctx, int K, int npix, const float *data, const float *noisemap, const float *rms,
+                      const float *exptime, const float *coefficient, const uint8_t *bad, float nan_noise,
+                      float noise_boost, int boost_whole_stamp, float *data_out, float *noisemap_out,
+                      float *weight_out, int32_t *masked_count, float *kernel_ms);
+
 /* ---- optimiser settings shared by both fits ----------------------------------------------- */
 /* optax.adabelief as driven by STARRED's Optimizer(method='adabelief'):
  * lightcurver/processes/star_photometry.py:113-122, roi_modelling.py:326-334. */

@@ -41,6 +41,9 @@ SIGNATURES = {
     'lc_ctx_create': (C.c_int, [C.c_int, C.POINTER(vp)]),
     'lc_ctx_destroy': (None, [vp]),
     'lc_last_error': (C.c_char_p, [vp]),
+    'lc_copy_bandwidth': (C.c_int, [vp, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
+    'lc_prepare_stamps': (C.c_int, [vp, C.c_int, C.c_int, fp, fp, fp, fp, fp, C.POINTER(C.c_uint8), C.c_float, C.c_float,
+                                    C.c_int, fp, fp, fp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     'lc_ctx_stream': (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     'lc_ctx_synchronize': (C.c_int, [vp]),
     'lc_timer_start': (C.c_int, [vp]),

@@ -63,6 +63,41 @@ def prepare_psf_stamps(datas, noisemaps, cosmics_masks, automatic_masks=None, ma
     return datas[keep], noisemaps[keep], good[keep], keep
 
 
+def prepare_psf_stamps_batched(frames, mask_threshold_fraction=0.4):
+    """prepare_psf_stamps for every frame at once: the stamps of all frames go through one launch of the fused
+    device pass (lc_prepare_stamps: NaN clean-up, masks, masked-pixel counts), then the per-frame 40 % cut is
+    applied to the counts.  Same return convention as prepare_psf_stamps, one tuple per frame."""
+    from .preprocessing import prepare_stamps
+    sizes = [len(fr['datas']) for fr in frames]
+    if sum(sizes) == 0:
+        return [(np.zeros((0, 0, 0)), np.zeros((0, 0, 0)), np.zeros((0, 0, 0), bool), np.zeros(0, bool)) for _ in frames]
+    datas = np.concatenate([np.asarray(fr['datas'], dtype=np.float32) for fr in frames if len(fr['datas'])])
+    noise = np.concatenate([np.asarray(fr['noisemaps'], dtype=np.float32) for fr in frames if len(fr['datas'])])
+    bad = np.concatenate([_flagged(fr) for fr in frames if len(fr['datas'])])
+    out = prepare_stamps(datas, noisemap=noise, bad=bad, nan_noise=1.0, want=('data', 'noisemap', 'weight'))
+    npix = datas.shape[1] * datas.shape[2]
+    keep_all = ~(out['masked_count'] > mask_threshold_fraction * npix)
+    # usable pixel = not flagged and not NaN-in-both (psf_modelling.py:135-143); a pixel that is NaN in only one
+    # input is left to the fit's own non-finite handling, as in the reference
+    both_nan = np.isnan(datas) & np.isnan(noise)
+    good_all = ~bad & ~both_nan
+    res, o = [], 0
+    for sz in sizes:
+        sl = slice(o, o + sz)
+        keep = keep_all[sl]
+        res.append((out['data'][sl][keep].astype(np.float64), out['noisemap'][sl][keep].astype(np.float64),
+                    good_all[sl][keep], keep))
+        o += sz
+    return res
+
+
+def _flagged(fr):
+    bad = np.asarray(fr['cosmics_masks'], dtype=bool)
+    if fr.get('automatic_masks') is not None:
+        bad = bad | ~np.asarray(fr['automatic_masks'], dtype=bool)
+    return bad
+
+
 def relative_loss_differential(loss_history):
     """(max - min of the last 10 %) / (max - min of the first 90 %) of the loss curve (:205-208)."""
     lh = np.asarray(loss_history, dtype=np.float64)
@@ -79,8 +114,9 @@ def model_psfs_of_frames(frames, subsampling_factor=2, psf_n_iter_analytic=100, 
     skipped (psf_modelling.py:154-160).  Returns a list of (frame, result-or-None) with the quantities the
     reference stores: narrow_psf, full_psf, chi2, relative_loss_differential, fwhm_moffat_pixels."""
     prepared, index = [], []
+    cleaned = prepare_psf_stamps_batched(frames)
     for k, fr in enumerate(frames):
-        d, nmap, m, keep = prepare_psf_stamps(fr['datas'], fr['noisemaps'], fr['cosmics_masks'], fr.get('automatic_masks'))
+        d, nmap, m, keep = cleaned[k]
         if len(d) == 0:
             continue
         prepared.append((d, nmap, m, float(fr.get('seeing_pixels', 3.0)), keep))

@@ -186,3 +186,24 @@ def test_synthetic_datasets_are_deterministic():
     r = make_roi_dataset(E=3, M=2, n=16, ss=2, seed=1)
     assert r['data'].shape == (3, 16, 16) and r['psf'].shape == (3, 32, 32)
     assert np.allclose(r['psf'].sum((-1, -2)), 1.0, atol=1e-5)
+
+
+def test_prep_oracle_follows_reference_lines():
+    """oracle/prep.py against hand-evaluated values of the cited reference lines."""
+    from oracle import prep as op
+    data = np.array([[[4.0, -1.0], [np.nan, 0.0]]])
+    noise = op.noisemap_from_rms(data, rms=[3.0], exptime=[10.0])
+    # sqrt((10*3)^2 + |10*4|)/10, sqrt(900 + 10)/10, NaN, sqrt(900)/10
+    assert np.allclose(noise[0, 0], [np.sqrt(940.0) / 10, np.sqrt(910.0) / 10])
+    assert np.isnan(noise[0, 1, 0]) and np.isclose(noise[0, 1, 1], 3.0)
+    d, s, w, cnt = op.prepare(data, rms=[3.0], exptime=[10.0], coefficient=[2.0], bad=[[[False, True], [False, False]]],
+                              nan_noise=1e7, noise_boost=1000.0)
+    assert d[0, 1, 0] == 0.0 and s[0, 1, 0] == 1e7 and cnt.tolist() == [2]
+    assert np.isclose(d[0, 0, 0], 2.0) and np.isclose(s[0, 0, 1], 1000.0 * np.sqrt(910.0) / 20)
+    assert w[0, 0, 1] == 0.0 and w[0, 1, 0] == 0.0 and np.isclose(w[0, 1, 1], 1.0 / 1.5 ** 2)
+    # whole-epoch boost applies once, however many pixels are flagged (star_photometry.py:316)
+    bad = np.zeros((2, 2, 2), bool)
+    bad[1, 0, :] = True
+    _, s2, _, _ = op.prepare(np.ones((2, 2, 2)), noisemap=np.ones((2, 2, 2)), bad=bad, noise_boost=1000.0,
+                             boost_whole_stamp=True)
+    assert np.all(s2[0] == 1.0) and np.all(s2[1] == 1000.0)
