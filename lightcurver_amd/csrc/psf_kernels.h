@@ -314,6 +314,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
               wpre[i3][j] = ok ? wv : 0.f;
             }
           }
+          LC_STAMP(10);
           // row pass (x taps) fused with the column down-sampling: lane = high-res row
           {
             constexpr int WL = SS * (JB - 1) + NT;
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
             }
           }
           wave_lds_sync();
+          LC_STAMP(11);
           // column pass (y taps) fused with the row down-sampling, residuals, reductions: lane = (column, row strip)
           float chi = 0.f, ga = 0.f, gx = 0.f, gy = 0.f, gs = 0.f;
           {
@@ -408,6 +410,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
             r[4] = gs;
           }
           wave_lds_sync();
+          LC_STAMP(12);
           // transposed column pass: V[u][jd] = sum_id PhiY(ss*id - u) r[id][jd]: lane = (column, strip of high-res rows)
           {
             constexpr int WI = (SS * LA - 1 + NT - 1) / SS + 1;
@@ -439,8 +442,11 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
             }
           }
           wave_lds_sync();  // the scratch is rewritten by the wave's next task
+          LC_STAMP(13);
         }
+        LC_STAMP(14);
         __syncthreads();
+        LC_STAMP(15);
         if (tid < SG * 5) {
           const int sl = tid / 5, q = tid % 5;
           if (g0 + sl < S) {
@@ -635,6 +641,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       LC_STAMP(4 + 5 * (g0 / SG));
       }
       // ---- P5: transposed row pass, summed over the stars of the group into registers ------
+      LC_STAMP(16);
       {
         constexpr int WJ = (PX - 1 + NT - 1) / SS + 1;
         for (int sl = 0; sl < SG; ++sl) {
@@ -662,6 +669,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           for (int p = 0; p < PX; ++p) gB[p] = fmaf(amp, acc[p], gB[p]);
         }
       }
+      LC_STAMP(17);
     }  // groups
     }  // conv_role
     __syncthreads();
@@ -802,7 +810,8 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           const float sn = b2 * Sp_[p] + (1.f - b2) * dg * dg + eps_root;
           Mp[p] = mn;
           Sp_[p] = sn;
-          Bp[p] -= lr * (mn * bc1) / (sqrtf(sn * bc2) + eps);
+          // hardware square root and reciprocal (1 ulp each): the IEEE sequences cost ~40 instructions per pixel
+          Bp[p] -= lr * (mn * bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(sn * bc2) + eps);
         }
       }
       float4 *bp = (float4 *)(A.B + gpix);

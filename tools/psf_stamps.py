@@ -36,4 +36,9 @@ for blk, label in ((0, 'block 0 (role 0 / single form)'), (64, 'block 8 (role 1)
     for k in keys[1:]:
         print(f'  {names[k]:34s} {s[k]-prev:8d} ticks  {100*(s[k]-prev)/tot:5.1f}%')
         prev = s[k]
+    fine = {10: 'task start (prefetch issued)', 11: 'row pass', 12: 'column pass + reductions', 13: 'transposed column pass', 14: 'wave 0 done with its tasks', 15: 'barrier (other waves)', 16: 'per-star sums', 17: 'P5 transposed row pass'}
+    if s[10]:
+        print('   last group, wave 0, last task:')
+        for a in range(11, 18):
+            print(f'     {fine[a]:34s} {s[a]-s[a-1]:8d} ticks')
     print('  total ticks', tot, '(s_memtime ticks @100MHz => us:', tot / 100.0, ')')
