@@ -170,6 +170,62 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     }
   };
 
+  // Column passes: spectrum columns 0 (DC) and L/2 (Nyquist) of real rows are purely real, so the two travel
+  // as ONE complex column (real part = column 0, imaginary part = column L/2) and are separated again in the
+  // frequency domain by Hermitian symmetry.  That leaves L/2 column transforms instead of L/2 + 1: with 4 * NW
+  // transforms per sweep (a power of two) the odd one out used to cost a whole extra sweep.
+  constexpr int NCOL = L / 2;
+  auto load_column = [&](float2 (&x)[N2], int kc, bool active, int row_off) {
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) {
+      const int r = l16 + 16 * n2 - row_off;
+      float2 v = make_float2(0.f, 0.f);
+      if (active && r >= 0 && r < N) {
+        v = SPEC[r * KH + kc];
+        if (kc == 0) v.y = SPEC[r * KH + L / 2].x;
+      }
+      x[n2] = v;
+    }
+  };
+  auto store_column = [&](const float2 (&x)[N2], int kc, bool active, int row_off) {
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) {
+      const int r = l16 + 16 * n2 - row_off;
+      if (active && r >= 0 && r < N) {
+        if (kc == 0) {
+          SPEC[r * KH] = make_float2(x[n2].x, 0.f);
+          SPEC[r * KH + L / 2] = make_float2(x[n2].y, 0.f);
+        } else {
+          SPEC[r * KH + kc] = x[n2];
+        }
+      }
+    }
+  };
+  // x (block layout) *= PSF spectrum of column kc (conjugated for the adjoint); the packed column first splits
+  // into its two Hermitian parts, each multiplied by its own spectrum column, and is packed again
+  auto times_spectrum = [&](float2 (&x)[N2], const float2 (&sv)[N2], const float2 *Ste, int kc, bool conj) {
+    // sv: spectrum column kc, requested before the forward transform so that its latency hides behind it
+    if (kc == 0) {  // one quarter of one wave, once per phase
+      float2 y[N2];
+#pragma unroll
+      for (int k2 = 0; k2 < N2; ++k2) {
+        const float2 zk = x[k2];
+        const float2 zc = (k2 == 0) ? shfl2(x[0], lane_neg) : shfl2(x[(N2 - k2) % N2], lane_mirror);
+        const float2 p = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+        const float2 q = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+        const float2 sn = Ste[(size_t)(L / 2) * L + kbase + k2];
+        const float2 pp = conj ? cmul_conj(p, sv[k2]) : cmul(p, sv[k2]);
+        const float2 qq = conj ? cmul_conj(q, sn) : cmul(q, sn);
+        y[k2] = make_float2(pp.x - qq.y, pp.y + qq.x);
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < N2; ++k2) x[k2] = y[k2];
+    } else {
+#pragma unroll
+      for (int k2 = 0; k2 < N2; ++k2) x[k2] = conj ? cmul_conj(x[k2], sv[k2]) : cmul(x[k2], sv[k2]);
+    }
+  };
+
   // ---- phase A: scene rows, two real rows per complex FFT ---------------------------------------
   for (int rp0 = wid * 4; rp0 < N / 2; rp0 += C::NW * 4) {
     const int rp = rp0 + qid, u0 = 2 * rp;
@@ -204,25 +260,18 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   LC_JSTAMP(2);
   // ---- phase B: columns: FFT, multiply by the PSF spectrum, inverse FFT, keep the 'same' window ----
   const float2 *Ste = A.St + (size_t)e * KH * L;
-  for (int kc0 = wid * 4; kc0 < KH; kc0 += C::NW * 4) {
+  for (int kc0 = wid * 4; kc0 < NCOL; kc0 += C::NW * 4) {
     const int kc = kc0 + qid;
-    const bool active = kc < KH;
-    const int kcs = active ? kc : 0;
-    float2 x[N2];
+    const bool active = kc < NCOL;
+    const int kcs = active ? kc : 1;
+    float2 x[N2], sv[N2];
 #pragma unroll
-    for (int n2 = 0; n2 < N2; ++n2) {
-      const int r = l16 + 16 * n2;
-      x[n2] = (active && r < N) ? SPEC[r * KH + kcs] : make_float2(0.f, 0.f);
-    }
+    for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)kcs * L + kbase + k2];
+    load_column(x, kcs, active, 0);
     quarter_fft_fwd<L>(x, l16, TW);
-#pragma unroll
-    for (int k2 = 0; k2 < N2; ++k2) x[k2] = cmul(x[k2], Ste[(size_t)kcs * L + kbase + k2]);
+    times_spectrum(x, sv, Ste, kcs, false);
     quarter_fft_inv<L>(x, l16, TW);
-#pragma unroll
-    for (int n2 = 0; n2 < N2; ++n2) {
-      const int r = l16 + 16 * n2 - CREF;
-      if (active && r >= 0 && r < N) SPEC[r * KH + kcs] = x[n2];
-    }
+    store_column(x, kcs, active, CREF);
   }
   __syncthreads();
   LC_JSTAMP(3);
@@ -338,25 +387,18 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   __syncthreads();
   LC_JSTAMP(4);
   // ---- phase B': adjoint columns (rows sit at offset CREF), multiply by conj(spectrum) ------------
-  for (int kc0 = wid * 4; kc0 < KH; kc0 += C::NW * 4) {
+  for (int kc0 = wid * 4; kc0 < NCOL; kc0 += C::NW * 4) {
     const int kc = kc0 + qid;
-    const bool active = kc < KH;
-    const int kcs = active ? kc : 0;
-    float2 x[N2];
+    const bool active = kc < NCOL;
+    const int kcs = active ? kc : 1;
+    float2 x[N2], sv[N2];
 #pragma unroll
-    for (int n2 = 0; n2 < N2; ++n2) {
-      const int r = l16 + 16 * n2 - CREF;
-      x[n2] = (active && r >= 0 && r < N) ? SPEC[r * KH + kcs] : make_float2(0.f, 0.f);
-    }
+    for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)kcs * L + kbase + k2];
+    load_column(x, kcs, active, CREF);
     quarter_fft_fwd<L>(x, l16, TW);
-#pragma unroll
-    for (int k2 = 0; k2 < N2; ++k2) x[k2] = cmul_conj(x[k2], Ste[(size_t)kcs * L + kbase + k2]);
+    times_spectrum(x, sv, Ste, kcs, true);
     quarter_fft_inv<L>(x, l16, TW);
-#pragma unroll
-    for (int n2 = 0; n2 < N2; ++n2) {
-      const int r = l16 + 16 * n2;
-      if (active && r < N) SPEC[r * KH + kcs] = x[n2];
-    }
+    store_column(x, kcs, active, 0);
   }
   __syncthreads();
   LC_JSTAMP(5);

@@ -96,7 +96,10 @@ struct PsfCfg {
   static constexpr int SZ_T = WC_ ? N * (N + 2 * (N / 4 + 10) + 1) : N * TS;
   static constexpr int OFF_R = OFF_T + SZ_T;
   static constexpr int SZ_R2 = SG * n * TS;  // R2t / R2xt: [SG][n][TS]
-  static constexpr int SZ_V = SG * N * RS;   // V: [SG][N][RS]
+  // V: [SG][N][VS]; the WC layout keeps one zero column on either side of the n data columns so that the
+  // transposed row pass reads out-of-stamp samples as zeros through a clamped index, without selects
+  static constexpr int VS = WC_ ? n + 3 : RS, VO = WC_ ? 1 : 0;
+  static constexpr int SZ_V = SG * N * VS;
   static constexpr int JB = LR;                       // down-sampled columns per wave task (WC)
   // WC tiles carry zero aprons so that the filter windows are read without clamping or selects.  The star
   // offsets are limited to +-N/4 high-res pixels (tap_entry), which bounds every window by AP / APR.
@@ -437,7 +440,16 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
                   }
                 }
 #pragma unroll
-                for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * RS + jd0 + jl] = out[r];
+                for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * C::VS + C::VO + jd0 + jl] = out[r];
+                // the zero columns (the starlet phase reuses this region, so they are rewritten every iteration)
+                if (jd0 + jl == 0) {
+#pragma unroll
+                  for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * C::VS] = 0.f;
+                }
+                if (jd0 + jl == n - 1) {
+#pragma unroll
+                  for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * C::VS + n + 1] = 0.f;
+                }
               }
             }
           }
@@ -634,7 +646,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
             }
           }
 #pragma unroll
-          for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * RS + jd] = out[r];
+          for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * RS + jd] = out[r];  // non-WC layout: VS == RS
         }
       }
       __syncthreads();
@@ -656,9 +668,14 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
 #pragma unroll
           for (int i = 0; i < WJ; ++i) {
             const int jd = i + bq + pv / SS;
-            const int ci = min(max(jd, 0), n - 1);
-            float vv = V[(sl * N + pu) * RS + ci];
-            vv = (jd >= 0 && jd < n) ? vv : 0.f;
+            float vv;
+            if constexpr (C::WC) {
+              vv = V[(sl * N + pu) * C::VS + 1 + min(max(jd, -1), n)];
+            } else {
+              const int ci = min(max(jd, 0), n - 1);
+              vv = V[(sl * N + pu) * RS + ci];
+              vv = (jd >= 0 && jd < n) ? vv : 0.f;
+            }
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
               const int rel = SS * i - k;
