@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "psf_kernels.h"
+#include "psf_noise.h"
 
 using namespace lc;
 
@@ -20,6 +21,7 @@ struct lc_psf_batch {
   float *B = nullptr, *mB = nullptr, *sB = nullptr;
   float *stars = nullptr, *stars_m = nullptr, *stars_s = nullptr, *moffat = nullptr;
   float *hist = nullptr, *qscratch = nullptr;
+  float *ntab = nullptr;  // noise propagation: 1-D starlet tables [F][S][J][3][2][N]
   float *xch = nullptr;   // two-workgroup form: exchange slabs, flags, abort word
   int *xflags = nullptr;
   bool split_used = false;
@@ -437,10 +439,41 @@ int lc_psf_batch_set_regularization(lc_psf_batch *b, const float *W, float lam_s
   }
   return LC_OK;
 }
+namespace {
+typedef void (*noise_fn)(int, int, const float *, const float *, const float *, float *);
+noise_fn find_noise_kernel(int N, int ss) {
+  if (N == 16 && ss == 1) return psf_noise_accumulate_kernel<16, 1>;
+  if (N == 32 && ss == 2) return psf_noise_accumulate_kernel<32, 2>;
+  if (N == 48 && ss == 2) return psf_noise_accumulate_kernel<48, 2>;
+  if (N == 64 && ss == 2) return psf_noise_accumulate_kernel<64, 2>;
+  if (N == 128 && ss == 2) return psf_noise_accumulate_kernel<128, 2>;
+  return nullptr;
+}
+}  // namespace
+
 int lc_psf_batch_propagate_noise(lc_psf_batch *b) {
   if (!b) return LC_ERR_INVALID;
   const int F = b->F, S = b->S, N = b->N, n = b->n, ss = b->ss, J = b->J;
   const size_t NN = (size_t)N * N, nn = (size_t)n * n;
+  if (!std::getenv("LCMI_NOISE_HOST")) {
+    // device path (psf_noise.h): 1-D starlet tables of every star in double, then the rank-1 products in fp32
+    noise_fn fn = find_noise_kernel(N, ss);
+    if (!fn) LC_FAIL(b->ctx, LC_ERR_UNSUPPORTED, "no noise-propagation kernel for this stamp size");
+    if (!b->ntab) {
+      int rc0 = dmalloc(b, &b->ntab, (size_t)F * S * J * 6 * N);
+      if (rc0) return rc0;
+    }
+    hipLaunchKernelGGL(psf_noise_tables_kernel, dim3(F * S), dim3(((N + 63) / 64) * 64), 4 * N * sizeof(double),
+                       b->ctx->stream, S, N, ss, J, b->stars, b->ntab);
+    LC_HIP(b->ctx, hipGetLastError());
+    const int lds = (int)((nn + (size_t)n * N + 6 * N) * sizeof(float));
+    LC_HIP(b->ctx, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(fn, dim3(F * J), dim3(kNoiseThreads), lds, b->ctx->stream, S, J, b->stars, b->wgt, b->ntab, b->W);
+    LC_HIP(b->ctx, hipGetLastError());
+    b->have_W = true;
+    return LC_OK;
+  }
+  // host path (double precision FFT convolutions), kept as an independent cross-check: LCMI_NOISE_HOST=1
   std::vector<float> st((size_t)F * S * 4), w((size_t)F * S * nn);
   int rc;
   if ((rc = d2h(b, st.data(), b->stars, st.size() * sizeof(float)))) return rc;

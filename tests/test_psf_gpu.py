@@ -68,9 +68,14 @@ def test_eval_without_weights_uses_scale_norms(ctx):
     assert H.rel_err(out['grad_grid'][0], g['B'].numpy().reshape(n * ss, n * ss)) < 5e-5
 
 
-def test_noise_propagation_matches_oracle(ctx):
-    n, ss, S, F = 16, 2, 4, 2
-    ds, plist, b = _setup(n, ss, F, S, 21, ctx)
+@pytest.mark.parametrize('n,ss,S', [(16, 1, 3), (16, 2, 4), (24, 2, 5), (32, 2, 8), (64, 2, 3)])
+def test_noise_propagation_matches_oracle(ctx, n, ss, S):
+    """Device noise propagation (csrc/psf_noise.h: separable starlet tables + rank-1 products, fp32) against the
+    oracle's direct float64 formula, and against the library's independent host implementation (double-precision
+    FFT convolutions, LCMI_NOISE_HOST=1).  A ragged frame (zero-weight padding star) is included."""
+    import os
+    F = 2
+    ds, plist, b = _setup(n, ss, F, S, 21 + n, ctx)
     b.propagate_noise()
     W = b.get_weights()
     J = om.n_scales(n * ss)
@@ -78,6 +83,24 @@ def test_noise_propagation_matches_oracle(ctx):
         data, sig2, mask = H.psf_oracle_inputs(ds, f, ss)
         Wo = om.propagate_noise_psf(plist[f], sig2, mask, ss)[:J].numpy()
         assert H.rel_err(W[f], Wo) < 2e-5
+    os.environ['LCMI_NOISE_HOST'] = '1'
+    try:
+        b.propagate_noise()
+    finally:
+        os.environ.pop('LCMI_NOISE_HOST', None)
+    assert H.rel_err(W, b.get_weights()) < 2e-5
+    # padding star: amplitude 0 and weight 0 -> no contribution, same maps as the frame without it
+    from lightcurver_amd.psf_batch import PsfBatch
+    w = H.weights_from(ds)
+    stars = H.stars_array(plist)
+    w2 = np.concatenate([w, np.zeros_like(w[:, :1])], axis=1)
+    d2 = np.concatenate([ds['data'], np.zeros_like(ds['data'][:, :1])], axis=1)
+    st2 = np.concatenate([stars, np.zeros_like(stars[:, :1])], axis=1)
+    b2 = PsfBatch(d2, w2, ss, ctx)
+    b2.set_moffat(H.moffat_array(plist))
+    b2.set_stars(st2)
+    b2.propagate_noise()
+    assert H.rel_err(b2.get_weights(), W) < 1e-6
 
 
 @pytest.mark.parametrize('n,ss,S', [(16, 2, 4), (32, 2, 8)])
