@@ -7,13 +7,41 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
-#include <complex>
 #include <thread>
 #include <vector>
 
 namespace lc {
 
-typedef std::complex<double> cd;
+// plain complex pair: std::complex's operator* goes through the NaN-recovering runtime routine on the host
+// compiler, several times the cost of the four multiplications below
+struct cd {
+  double re, im;
+  cd() : re(0), im(0) {}
+  cd(double r, double i = 0.0) : re(r), im(i) {}
+  double real() const { return re; }
+  double imag() const { return im; }
+};
+inline cd operator+(cd a, cd b) { return cd(a.re + b.re, a.im + b.im); }
+inline cd operator-(cd a, cd b) { return cd(a.re - b.re, a.im - b.im); }
+inline cd operator*(cd a, cd b) { return cd(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+inline cd &operator+=(cd &a, cd b) {
+  a.re += b.re;
+  a.im += b.im;
+  return a;
+}
+inline cd conj(cd a) { return cd(a.re, -a.im); }
+
+// twiddles exp(-2 pi i k / L), k < L / 2, computed once per length and thread
+inline const std::vector<cd> &host_twiddles(int L) {
+  thread_local std::vector<cd> tw;
+  thread_local int twL = 0;
+  if (twL != L) {
+    tw.resize(L / 2);
+    for (int k = 0; k < L / 2; ++k) tw[k] = cd(std::cos(-2.0 * M_PI * k / L), std::sin(-2.0 * M_PI * k / L));
+    twL = L;
+  }
+  return tw;
+}
 
 inline void host_fft1d(cd *x, int L, bool inv) {
   for (int i = 1, j = 0; i < L; ++i) {
@@ -22,16 +50,16 @@ inline void host_fft1d(cd *x, int L, bool inv) {
     j ^= bit;
     if (i < j) std::swap(x[i], x[j]);
   }
+  const std::vector<cd> &tw = host_twiddles(L);
   for (int len = 2; len <= L; len <<= 1) {
-    const double ang = 2.0 * M_PI / len * (inv ? 1.0 : -1.0);
-    const cd wl(std::cos(ang), std::sin(ang));
+    const int step = L / len, half = len / 2;
     for (int i = 0; i < L; i += len) {
-      cd w(1.0, 0.0);
-      for (int k = 0; k < len / 2; ++k) {
-        const cd u = x[i + k], v = x[i + k + len / 2] * w;
+      for (int k = 0; k < half; ++k) {
+        cd w = tw[k * step];
+        if (inv) w.im = -w.im;
+        const cd u = x[i + k], v = x[i + k + half] * w;
         x[i + k] = u + v;
-        x[i + k + len / 2] = u - v;
-        w *= wl;
+        x[i + k + half] = u - v;
       }
     }
   }
@@ -40,11 +68,16 @@ inline void host_fft1d(cd *x, int L, bool inv) {
 inline void host_fft2d(std::vector<cd> &a, int L, int r0, int nr, bool inv) {
   if (!inv)
     for (int r = r0; r < r0 + nr; ++r) host_fft1d(&a[(size_t)r * L], L, false);
-  std::vector<cd> col(L);
-  for (int c = 0; c < L; ++c) {
-    for (int r = 0; r < L; ++r) col[r] = a[(size_t)r * L + c];
-    host_fft1d(col.data(), L, inv);
-    for (int r = 0; r < L; ++r) a[(size_t)r * L + c] = col[r];
+  // columns, eight at a time through a transposed tile so that the strided accesses stay in cache lines
+  constexpr int TB = 8;
+  std::vector<cd> col((size_t)TB * L);
+  for (int c0 = 0; c0 < L; c0 += TB) {
+    const int nb = std::min(TB, L - c0);
+    for (int r = 0; r < L; ++r)
+      for (int b = 0; b < nb; ++b) col[(size_t)b * L + r] = a[(size_t)r * L + c0 + b];
+    for (int b = 0; b < nb; ++b) host_fft1d(&col[(size_t)b * L], L, inv);
+    for (int r = 0; r < L; ++r)
+      for (int b = 0; b < nb; ++b) a[(size_t)r * L + c0 + b] = col[(size_t)b * L + r];
   }
   if (inv)
     for (int r = 0; r < L; ++r) host_fft1d(&a[(size_t)r * L], L, true);
@@ -103,17 +136,30 @@ struct NoiseAccumulator {
         A[(size_t)(ss * i) * L + ss * jx] = (std::isfinite(wv) && wv > 0.f) ? (double)wv : 0.0;
       }
     host_fft2d(A, L, 0, N, false);
-    for (int j = 0; j <= J; ++j) {
+    // two real images per complex transform: Z = FFT(k_j^2 + i k_{j+1}^2);  by Hermitian symmetry
+    //   FFT(k_j^2)[q] = (Z[q] + conj Z[-q]) / 2,   FFT(k_{j+1}^2)[q] = (Z[q] - conj Z[-q]) / (2 i)
+    for (int j = 0; j <= J; j += 2) {
+      const bool two = (j + 1 <= J);
       std::fill(B.begin(), B.end(), cd(0, 0));
       for (int u = 0; u < N; ++u)
         for (int v = 0; v < N; ++v) {
           const int su = u + shift, sv = v + shift;
           if (su < 0 || su >= N || sv < 0 || sv >= N) continue;
-          const double k = kap[j][(size_t)su * N + sv];
-          B[(size_t)u * L + v] = k * k;
+          const double k0 = kap[j][(size_t)su * N + sv];
+          const double k1 = two ? kap[j + 1][(size_t)su * N + sv] : 0.0;
+          B[(size_t)u * L + v] = cd(k0 * k0, k1 * k1);
         }
       host_fft2d(B, L, 0, N, false);
-      for (size_t i = 0; i < A.size(); ++i) acc[j][i] += A[i] * B[i];
+      for (int r = 0; r < L; ++r) {
+        const int rm = (L - r) & (L - 1);
+        for (int q = 0; q < L; ++q) {
+          const int qm = (L - q) & (L - 1);
+          const cd z = B[(size_t)r * L + q], zc = conj(B[(size_t)rm * L + qm]);
+          const cd a = A[(size_t)r * L + q];
+          acc[j][(size_t)r * L + q] += a * cd(0.5 * (z.re + zc.re), 0.5 * (z.im + zc.im));
+          if (two) acc[j + 1][(size_t)r * L + q] += a * cd(0.5 * (z.im - zc.im), -0.5 * (z.re - zc.re));
+        }
+      }
     }
   }
   void merge(const NoiseAccumulator &o) {
@@ -123,11 +169,19 @@ struct NoiseAccumulator {
   // W: [(J+1)][N*N]
   void finalize(float *W) {
     const double sc = 1.0 / ((double)L * L);
-    for (int j = 0; j <= J; ++j) {
-      host_fft2d(acc[j], L, 0, L, true);
+    // the results are real, so two scales share one inverse transform (real part / imaginary part)
+    for (int j = 0; j <= J; j += 2) {
+      const bool two = (j + 1 <= J);
+      std::vector<cd> &z = acc[j];
+      if (two)
+        for (size_t i = 0; i < z.size(); ++i) z[i] = cd(z[i].re - acc[j + 1][i].im, z[i].im + acc[j + 1][i].re);
+      host_fft2d(z, L, 0, L, true);
       for (int u = 0; u < N; ++u)
-        for (int v = 0; v < N; ++v)
-          W[((size_t)j * N + u) * N + v] = (float)std::sqrt(std::max(acc[j][(size_t)(u + c) * L + (v + c)].real() * sc, 0.0));
+        for (int v = 0; v < N; ++v) {
+          const cd val = z[(size_t)(u + c) * L + (v + c)];
+          W[((size_t)j * N + u) * N + v] = (float)std::sqrt(std::max(val.re * sc, 0.0));
+          if (two) W[((size_t)(j + 1) * N + u) * N + v] = (float)std::sqrt(std::max(val.im * sc, 0.0));
+        }
     }
   }
 };
