@@ -93,6 +93,41 @@ def joint_fit_secondary(ctx, iters=100):
             'loss_finite': bool(np.all(np.isfinite(hist)))}
 
 
+def c3_shard_secondary(ctx, iters=50):
+    """Secondary figure: one GPU's share of BASELINE.json configs[2] (C3: 500 frames x 8 stars x 64x64 over 8
+    GPUs = 63 frames per GPU), pixel-grid stage of the PSF fit."""
+    from lightcurver_amd.psf_batch import PsfBatch
+    from lightcurver_amd.synthetic import make_psf_dataset
+    F, S, n, ss = 63, 8, 64, 2
+    ds = make_psf_dataset(F=F, S=S, n=n, ss=ss, seed=103)
+    weight = (ds['masks'] / ds['noisemap'].astype(np.float64) ** 2).astype(np.float32)
+    b = PsfBatch(ds['data'], weight, ss, ctx)
+    g = ds['fwhm_guess']
+    f0 = np.sqrt(np.maximum(g * g - (2.0 / ss) ** 2, 1.0))
+    b.set_moffat(np.stack([f0, f0, np.zeros(F), np.full(F, 2.5)], axis=-1))
+    stars = np.zeros((F, S, 4), np.float32)
+    stars[..., 0] = (ds['data'] * ds['masks']).sum(axis=(-1, -2))
+    b.set_stars(stars)
+    b.set_grid(None)
+    b.fit_moffat(30)
+    b.propagate_noise()
+    b.set_regularization(None, 1.0, 1.0)
+    ab = dict(init_learning_rate=1e-4, schedule_learning_rate=True)
+    b.run_adabelief(5, **ab)
+    ctx.synchronize()
+    ctx.timer_start()
+    b.run_adabelief(iters, **ab)
+    ms = ctx.timer_stop()
+    hist = b.loss_history()
+    bytes_per = algorithmic_bytes_per_cutout_iteration(n, ss, S)
+    rate = F * S * iters / (ms * 1e-3)
+    b.close()
+    return {'workload': f'C3 shard: {F} frames x {S} stars, {n}x{n} stamps (1/8 of C3), {iters} AdaBelief iterations',
+            'cutouts_per_sec': rate, 'us_per_iteration': ms * 1e3 / iters,
+            'algorithmic_bytes_per_cutout_iteration': bytes_per,
+            'hbm_roofline_frac': rate * bytes_per / 1e9 / HBM_PEAK_GBS, 'loss_finite': bool(np.all(np.isfinite(hist)))}
+
+
 def sharded_joint_fit(ctx, rank, world, iters=100):
     """Opt-in (--sharded-joint): C4's 200 epochs sharded over the ranks, shared block all-reduced in place by
     RCCL every iteration (lightcurver_amd/distributed.py).  Strong scaling: the total work is fixed."""
@@ -271,6 +306,10 @@ def main():
                 out['config']['joint_fit'] = joint_fit_secondary(ctx)
             except Exception as e:
                 out['config']['joint_fit'] = {'error': repr(e)}
+            try:
+                out['config']['c3_shard'] = c3_shard_secondary(ctx)
+            except Exception as e:
+                out['config']['c3_shard'] = {'error': repr(e)}
         if sharded is not None:
             out['config']['sharded_joint_fit'] = sharded
         if not args.no_cpu_baseline and world == 1:

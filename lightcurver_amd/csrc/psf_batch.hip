@@ -22,6 +22,7 @@ struct lc_psf_batch {
   float *stars = nullptr, *stars_m = nullptr, *stars_s = nullptr, *moffat = nullptr;
   float *hist = nullptr, *qscratch = nullptr;
   float *ntab = nullptr;  // noise propagation: 1-D starlet tables [F][S][J][3][2][N]
+  float *B1 = nullptr, *mB1 = nullptr, *sB1 = nullptr;  // role 1's copy of the pixel state (n = 64)
   float *xch = nullptr;   // two-workgroup form: exchange slabs, flags, abort word
   int *xflags = nullptr;
   bool split_used = false;
@@ -200,7 +201,7 @@ const PsfVariant *find_variant(int n, int ss) {
       make_variant<PsfCfg<32, 2, 4, 8, true>, true>(),    // n = 16, ss = 2
       make_variant<PsfCfg<48, 2, 4, 8, true>, true>(),    // n = 24 (lightcurver default stamp_size_stars)
       make_variant<PsfCfg<64, 2, 8, 4, true>, true>(),    // n = 32 (C1, C2)
-      make_variant<PsfCfg<128, 2, 16, 1>>(),  // n = 64 (C3)
+      make_variant<PsfCfg<128, 2, 16, 1>, true>(),  // n = 64 (C3)
   };
   for (const auto &v : table)
     if (v.n == n && v.ss == ss) return &v;
@@ -253,11 +254,16 @@ int launch_psf(lc_psf_batch *b, int mode, int n_iter, const lc_adabelief_cfg *cf
       int rc = dmalloc(b, &b->xch, (size_t)b->F * 4 * ((size_t)b->N * b->N + 64));
       if (rc) return rc;
       if ((rc = dmalloc(b, &b->xflags, (size_t)b->F * 2 + 16))) return rc;
+      const size_t FNN = (size_t)b->F * b->N * b->N;
+      if ((rc = dmalloc(b, &b->B1, FNN)) || (rc = dmalloc(b, &b->mB1, FNN)) || (rc = dmalloc(b, &b->sB1, FNN))) return rc;
     }
     LC_HIP(b->ctx, hipMemsetAsync(b->xflags, 0, ((size_t)b->F * 2 + 16) * sizeof(int), b->ctx->stream));
     A.xch = b->xch;
     A.xflags = b->xflags;
     A.xabort = b->xflags + (size_t)b->F * 2;
+    A.B1 = b->B1;
+    A.mB1 = b->mB1;
+    A.sB1 = b->sB1;
     b->split_used = true;
     LC_HIP(b->ctx, hipFuncSetAttribute((const void *)v->fn_split, hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes));
     hipLaunchKernelGGL(v->fn_split, dim3(split_grid), dim3(v->nthr), v->lds_bytes, b->ctx->stream, A);

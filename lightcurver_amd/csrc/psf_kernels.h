@@ -46,6 +46,7 @@ struct PsfArgs {
   // per-(frame, role) iteration flags [F][2], one abort word
   float *xch;
   int *xflags, *xabort;
+  float *B1, *mB1, *sB1;  // [F][N*N]: role 1's own copy of the pixel state when it does not fit in registers
 };
 
 // Write-through (sc1) stores and L1-bypassing (sc1) loads for data handed from one workgroup to another
@@ -211,7 +212,23 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
   // Pixel state of this thread.  With <= 8 pixels per thread it stays in registers for the whole launch
   // (B, both AdaBelief moments and the Moffat): HBM then sees it once per launch instead of per iteration.
   constexpr bool STATE_REGS = (PX <= 8);
-  static_assert(!SPLIT || STATE_REGS, "the two-workgroup form keeps B in registers");
+  // pixel state in global memory (PX > 8): in the two-workgroup form role 1 works on its own copy, taken here
+  // (every thread only ever touches its own pixels of it, so no barrier is needed)
+  float *Bg = A.B, *mBg = A.mB, *sBg = A.sB;
+  if constexpr (SPLIT && !STATE_REGS) {
+    if (role == 1) {
+      const size_t g0pix = (size_t)f * N * N + (size_t)(tid0 / (N / PX)) * N + (tid0 % (N / PX)) * PX;
+#pragma unroll
+      for (int q = 0; q < PX / 4; ++q) {
+        ((float4 *)(A.B1 + g0pix))[q] = ((const float4 *)(A.B + g0pix))[q];
+        ((float4 *)(A.mB1 + g0pix))[q] = ((const float4 *)(A.mB + g0pix))[q];
+        ((float4 *)(A.sB1 + g0pix))[q] = ((const float4 *)(A.sB + g0pix))[q];
+      }
+      Bg = A.B1;
+      mBg = A.mB1;
+      sBg = A.sB1;
+    }
+  }
   float Bp[PX], Mp[PX], Sp_[PX], Tp[PX];
   {
     const size_t g0pix = (size_t)f * N * N + (size_t)(tid0 / (N / PX)) * N + (tid0 % (N / PX)) * PX;
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
 #pragma unroll
       for (int p = 0; p < PX; ++p) T[pu * TS + pv + p] = Bp[p] + Tp[p];
     } else {
-      const float4 *bp = (const float4 *)(A.B + gpix);
+      const float4 *bp = (const float4 *)(Bg + gpix);
       const float4 *tp = (const float4 *)(A.Tm + gpix);
 #pragma unroll
       for (int q = 0; q < PX / 4; ++q) {
@@ -708,7 +725,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
 #pragma unroll
         for (int p = 0; p < PX; ++p) bpix[p] = Bp[p];
       } else {
-        const float4 *bp = (const float4 *)(A.B + gpix);
+        const float4 *bp = (const float4 *)(Bg + gpix);
 #pragma unroll
         for (int q = 0; q < PX / 4; ++q) {
           const float4 b = bp[q];
@@ -831,9 +848,9 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           Bp[p] -= lr * (mn * bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(sn * bc2) + eps);
         }
       }
-      float4 *bp = (float4 *)(A.B + gpix);
-      float4 *mp = (float4 *)(A.mB + gpix);
-      float4 *sp = (float4 *)(A.sB + gpix);
+      float4 *bp = (float4 *)(Bg + gpix);
+      float4 *mp = (float4 *)(mBg + gpix);
+      float4 *sp = (float4 *)(sBg + gpix);
 #pragma unroll
       for (int q = 0; q < (STATE_REGS ? 0 : PX / 4); ++q) {
         float4 b = bp[q], m = mp[q], s = sp[q];

@@ -169,14 +169,14 @@ def test_moffat_stage_reaches_oracle_optimum(ctx):
         assert abs(fw_gpu - fw_or) / fw_or < 2e-2
 
 
-@pytest.mark.parametrize('n,S,F', [(16, 4, 5), (24, 5, 3), (32, 8, 100)])
+@pytest.mark.parametrize('n,S,F', [(16, 4, 5), (24, 5, 3), (32, 8, 100), (64, 8, 63)])
 def test_two_workgroup_form_is_bit_identical(ctx, n, S, F):
     """Small batches run the optimisation loop with two workgroups per frame (chi2 gradient / starlet term,
     swapped through L2 every iteration, psf_kernels.h SPLIT).  Both forms apply the same operations in the
     same order, so loss history, grid and star parameters must agree bit for bit with the one-workgroup form
     (LCMI_PSF_SINGLE_WG=1); F = 100 loads 200 CUs at once, the uneven-load case for the hand-off."""
     import os
-    ss, T = 2, 60
+    ss, T = 2, (60 if n < 64 else 20)   # n = 64 (one GPU's share of C3): pixel state in HBM, role 1 on its own copy
     out = []
     for single in (False, True):
         if single:
