@@ -124,15 +124,30 @@ __device__ __forceinline__ void adjoint_line_dpp(const float own[PX], int x0, in
       out[p] = acc;
     }
   }
-  float s1 = 0.f, s2 = 0.f, e1 = 0.f, e2 = 0.f;  // head sums x <= D, x <= 2D; tail sums x >= N-1-D, x >= N-1-2D
+  // head sums over x <= D and x <= 2D, tail sums over x >= N-1-D and x >= N-1-2D (the samples that clamp onto the
+  // two ends).  x = lil * PX + p, so for a threshold T a lane contributes all of its samples (lil < T / PX), a
+  // compile-time prefix of them (lil == T / PX) or nothing: one shared full sum, four short partial sums, selects
+  // per lane instead of per sample.
+  float full = own[0];
 #pragma unroll
-  for (int p = 0; p < PX; ++p) {
-    const int x = x0 + p;
-    s1 += (x <= D) ? own[p] : 0.f;
-    s2 += (x <= 2 * D) ? own[p] : 0.f;
-    e1 += (x >= N - 1 - D) ? own[p] : 0.f;
-    e2 += (x >= N - 1 - 2 * D) ? own[p] : 0.f;
-  }
+  for (int p = 1; p < PX; ++p) full += own[p];
+  auto head = [&](auto tc) {
+    constexpr int T = decltype(tc)::value, Q = T / PX, R = T % PX;
+    float part = own[0];
+#pragma unroll
+    for (int p = 1; p <= R; ++p) part += own[p];
+    return (lil < Q) ? full : ((lil == Q) ? part : 0.f);
+  };
+  auto tail = [&](auto tc) {
+    constexpr int T = decltype(tc)::value, Q = T / PX, R = T % PX;
+    float part = own[PX - 1];
+#pragma unroll
+    for (int p = 1; p <= R; ++p) part += own[PX - 1 - p];
+    const int lir = LPR - 1 - lil;
+    return (lir < Q) ? full : ((lir == Q) ? part : 0.f);
+  };
+  float s1 = head(std::integral_constant<int, D>{}), s2 = head(std::integral_constant<int, 2 * D>{});
+  float e1 = tail(std::integral_constant<int, D>{}), e2 = tail(std::integral_constant<int, 2 * D>{});
   s1 = line_sum<LPR>(s1);
   s2 = line_sum<LPR>(s2);
   e1 = line_sum<LPR>(e1);
