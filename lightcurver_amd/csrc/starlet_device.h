@@ -205,7 +205,9 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F 
 // LDS needed by starlet_l1_grad (floats): two ping-pong images at the 16-byte aligned row stride.
 template <int N>
 struct StarletLds {
-  static constexpr int TS = N + 1, TSS = N + 4;
+  // forward sweep rows: [4 x first sample][N samples][4 x last sample], 16-byte aligned, so that a neighbour quad
+  // that falls off either end is read as the replicated edge through a clamped address, without selects
+  static constexpr int TS = N + 1, TSS = N + 8;
   static constexpr int FLOATS = 2 * N * TSS;
 };
 
@@ -237,8 +239,17 @@ __device__ __forceinline__ void starlet_l1_grad(const float img[PX], const float
     c[4 * q + 1] = img[4 * q + 1];
     c[4 * q + 2] = img[4 * q + 2];
     c[4 * q + 3] = img[4 * q + 3];
-    *(float4 *)&fA[pu * TSS + pv + 4 * q] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
   }
+  // one row of the forward buffers: own samples, plus the replicated edge quads from the two end threads
+  auto put_row = [&](float *buf, int pu, int pv, const float (&v)[PX]) {
+    float *row = buf + pu * TSS + 4;
+#pragma unroll
+    for (int q = 0; q < PX / 4; ++q)
+      *(float4 *)&row[pv + 4 * q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    if (pv == 0) *(float4 *)&row[-4] = make_float4(v[0], v[0], v[0], v[0]);
+    if (pv + PX == N) *(float4 *)&row[N] = make_float4(v[PX - 1], v[PX - 1], v[PX - 1], v[PX - 1]);
+  };
+  put_row(fA, pu, pv, c);
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < J; ++j) {
@@ -267,22 +278,21 @@ __device__ __forceinline__ void starlet_l1_grad(const float img[PX], const float
     }
     // row pass: r = Row_j c (edge replicating), own samples from registers, neighbours by 128-bit reads
     float r[PX];
-    const float *row = fA + pu * TSS;
+    const float *row = fA + pu * TSS + 4;
     if (d < 4) {
       float w[PX + 8];
-      const float4 Lc = ld4(row + max(pv - 4, 0));
-      const float4 Rc = ld4(row + min(pv + PX, N - 4));
-      const bool hl = pv > 0, hr = pv + PX < N;
-      w[0] = hl ? Lc.x : c[0];
-      w[1] = hl ? Lc.y : c[0];
-      w[2] = hl ? Lc.z : c[0];
-      w[3] = hl ? Lc.w : c[0];
+      const float4 Lc = ld4(row + pv - 4);
+      const float4 Rc = ld4(row + pv + PX);
+      w[0] = Lc.x;
+      w[1] = Lc.y;
+      w[2] = Lc.z;
+      w[3] = Lc.w;
 #pragma unroll
       for (int p = 0; p < PX; ++p) w[4 + p] = c[p];
-      w[PX + 4] = hr ? Rc.x : c[PX - 1];
-      w[PX + 5] = hr ? Rc.y : c[PX - 1];
-      w[PX + 6] = hr ? Rc.z : c[PX - 1];
-      w[PX + 7] = hr ? Rc.w : c[PX - 1];
+      w[PX + 4] = Rc.x;
+      w[PX + 5] = Rc.y;
+      w[PX + 6] = Rc.z;
+      w[PX + 7] = Rc.w;
 #pragma unroll
       for (int p = 0; p < PX; ++p) {
         float acc = 0.375f * w[4 + p];
@@ -291,21 +301,20 @@ __device__ __forceinline__ void starlet_l1_grad(const float img[PX], const float
         r[p] = acc;
       }
     } else {
-      const float e0 = row[0], eN = row[N - 1];
 #pragma unroll
       for (int q = 0; q < PX / 4; ++q) {
         float a4[4] = {0.375f * c[4 * q], 0.375f * c[4 * q + 1], 0.375f * c[4 * q + 2], 0.375f * c[4 * q + 3]};
 #pragma unroll
         for (int t = -2; t <= 2; ++t) {
           if (t == 0) continue;
-          const int idx = pv + 4 * q + t * d;
-          const float4 v4 = ld4(row + min(max(idx, 0), N - 4));
+          // d is a multiple of 4 here: a neighbour quad lies entirely inside the row or entirely beyond one end
+          const int idx = min(max(pv + 4 * q + t * d, -4), N);
+          const float4 v4 = ld4(row + idx);
           const float bt = b3tap(t);
-          const bool lo = idx < 0, hi = idx > N - 4;
-          a4[0] = fmaf(bt, lo ? e0 : (hi ? eN : v4.x), a4[0]);
-          a4[1] = fmaf(bt, lo ? e0 : (hi ? eN : v4.y), a4[1]);
-          a4[2] = fmaf(bt, lo ? e0 : (hi ? eN : v4.z), a4[2]);
-          a4[3] = fmaf(bt, lo ? e0 : (hi ? eN : v4.w), a4[3]);
+          a4[0] = fmaf(bt, v4.x, a4[0]);
+          a4[1] = fmaf(bt, v4.y, a4[1]);
+          a4[2] = fmaf(bt, v4.z, a4[2]);
+          a4[3] = fmaf(bt, v4.w, a4[3]);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[4 * q + e] = a4[e];
@@ -313,7 +322,7 @@ __device__ __forceinline__ void starlet_l1_grad(const float img[PX], const float
     }
 #pragma unroll
     for (int q = 0; q < PX / 4; ++q)
-      *(float4 *)&fB[pu * TSS + pv + 4 * q] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+      *(float4 *)&fB[pu * TSS + 4 + pv + 4 * q] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
     __syncthreads();
     // column pass: c_{j+1} = Col_j r; detail coefficients, l1 value and sub-gradient
     const float lam = (j == 0) ? lam_hf : lam_sc;
@@ -325,7 +334,7 @@ __device__ __forceinline__ void starlet_l1_grad(const float img[PX], const float
       for (int t = -2; t <= 2; ++t) {
         if (t == 0) continue;
         const int uu = min(max(pu + t * d, 0), N - 1);
-        const float4 v4 = ld4(fB + uu * TSS + pv + 4 * qq);
+        const float4 v4 = ld4(fB + uu * TSS + 4 + pv + 4 * qq);
         const float bt = b3tap(t);
         a4[0] = fmaf(bt, v4.x, a4[0]);
         a4[1] = fmaf(bt, v4.y, a4[1]);
@@ -350,11 +359,7 @@ __device__ __forceinline__ void starlet_l1_grad(const float img[PX], const float
 #pragma unroll
       for (int qq = 0; qq < PX / 4; ++qq) qp[qq] = make_float4(q[4 * qq], q[4 * qq + 1], q[4 * qq + 2], q[4 * qq + 3]);
     }
-    if (j + 1 < J) {
-#pragma unroll
-      for (int qq = 0; qq < PX / 4; ++qq)
-        *(float4 *)&fA[pu * TSS + pv + 4 * qq] = make_float4(c[4 * qq], c[4 * qq + 1], c[4 * qq + 2], c[4 * qq + 3]);
-    }
+    if (j + 1 < J) put_row(fA, pu, pv, c);
     __syncthreads();
   }
   // backward: z_J = 0; z_j = q_j + H_j^T (z_{j+1} - q_j), H_j^T = Row^T Col^T (edge-replicating adjoint).
