@@ -863,7 +863,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           const float sn = b2 * ss_[e] + (1.f - b2) * dg * dg + eps_root;
           mm[e] = mn;
           ss_[e] = sn;
-          bb[e] -= lr * (mn * bc1) / (sqrtf(sn * bc2) + eps);
+          bb[e] -= lr * (mn * bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(sn * bc2) + eps);
         }
         bp[q] = b;
         mp[q] = m;
