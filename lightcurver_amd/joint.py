@@ -58,6 +58,7 @@ class JointFit:
     def set_loss(self, W=None, lam_scales=0.0, lam_hf=0.0, lam_positivity=0.0, lam_positivity_ps=0.0,
                  lam_pts_source=0.0, lam_flux_uniformity=0.0, prior=None):
         """prior: dict with c_x_mean, c_x_sigma, c_y_mean, c_y_sigma (length M) or None."""
+        self._configured_by = None  # see starred/deconvolution/loss.py Loss.configure
         cfg = _lib.JointLossCfg(float(lam_scales), float(lam_hf), float(lam_positivity), float(lam_positivity_ps),
                                 float(lam_pts_source), float(lam_flux_uniformity), 0, None, None, None, None)
         keep = []

@@ -63,7 +63,11 @@ class Loss:
 
     def configure(self):
         """Push the loss settings to the device object (called by the optimiser before it runs)."""
-        self._fit.set_loss(**self._settings)
+        # several Loss objects may share one device fit; the settings (with the weight cube) are uploaded only when
+        # another Loss, or a direct set_loss call, configured it last
+        if getattr(self._fit, '_configured_by', None) is not self:
+            self._fit.set_loss(**self._settings)
+            self._fit._configured_by = self
         return self._fit
 
     def value_and_grad(self, args):
