@@ -28,7 +28,10 @@ for r in rows(trace_dir, '*kernel_trace.csv'):
     us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     k = name(r)
     if k == 'psf_fit_kernel':
-        k += ' [timed launch, 100 iterations]' if us > LONG_US else ' [1-iteration evaluation, untimed setup]'
+        if int(r.get('Workgroup_Size_X', 512)) == 1024:
+            k += ' [64x64 stamps: C3-shard secondary figure]'
+        else:
+            k += ' [timed launch, 100 iterations]' if us > LONG_US else ' [1-iteration evaluation, untimed setup]'
     dur[k].append(us)
 total = sum(sum(v) for v in dur.values())
 ktab = [dict(kernel=k, calls=len(v), total_us=round(sum(v), 1), avg_us=round(sum(v) / len(v), 2), min_us=round(min(v), 2),
@@ -43,7 +46,7 @@ def counter(d, cname):
             continue
         us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         k = name(r)
-        if k == 'psf_fit_kernel' and us > LONG_US:
+        if k == 'psf_fit_kernel' and us > LONG_US and int(r.get('Workgroup_Size', r.get('Workgroup_Size_X', 512))) != 1024:
             vals['psf_fit_kernel'].append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in vals.items()}, {k: len(v) for k, v in vals.items()}
 
