@@ -583,28 +583,40 @@ int lc_psf_batch_fit_moffat(lc_psf_batch *b, int n_iter, float *final_loss) {
       h[4 + S + s] = h[4 + 2 * S + s] = b->n / 4.0;
     }
   }
-  std::vector<float> loss(F), gm((size_t)F * 4), gs((size_t)F * S * 4);
   const bool had_W = b->have_W;
+  // pinned staging: parameters up, loss + gradients down, one synchronisation per evaluation
+  const size_t n_in = (size_t)F * 4 + (size_t)F * S * 4, n_out = (size_t)F + (size_t)F * 4 + (size_t)F * S * 4;
+  float *pin = nullptr;
+  LC_HIP(b->ctx, hipHostMalloc((void **)&pin, (n_in + n_out) * sizeof(float), hipHostMallocDefault));
+  struct PinGuard {
+    float *p;
+    ~PinGuard() { (void)hipHostFree(p); }
+  } guard{pin};
+  float *pmof = pin, *pst = pin + (size_t)F * 4, *loss = pin + n_in, *gm = loss + F, *gs = gm + (size_t)F * 4;
+  std::memcpy(pst, st.data(), st.size() * sizeof(float));  // sky (column 3) stays as it is
+  hipStream_t q = b->ctx->stream;
   auto eval = [&](const std::vector<double> &X, std::vector<double> &Fv, std::vector<double> &G) -> int {
     for (int f = 0; f < F; ++f) {
       const double *xf = &X[(size_t)f * D];
-      for (int k = 0; k < 4; ++k) mof[f * 4 + k] = (float)xf[k];
+      for (int k = 0; k < 4; ++k) pmof[f * 4 + k] = (float)xf[k];
       for (int s = 0; s < S; ++s) {
-        st[((size_t)f * S + s) * 4 + 0] = (float)xf[4 + s];
-        st[((size_t)f * S + s) * 4 + 1] = (float)xf[4 + S + s];
-        st[((size_t)f * S + s) * 4 + 2] = (float)xf[4 + 2 * S + s];
+        pst[((size_t)f * S + s) * 4 + 0] = (float)xf[4 + s];
+        pst[((size_t)f * S + s) * 4 + 1] = (float)xf[4 + S + s];
+        pst[((size_t)f * S + s) * 4 + 2] = (float)xf[4 + 2 * S + s];
       }
     }
     int r;
-    if ((r = lc_psf_batch_set_moffat(b, mof.data()))) return r;
-    if ((r = lc_psf_batch_set_stars(b, st.data()))) return r;
+    LC_HIP(b->ctx, hipMemcpyAsync(b->moffat, pmof, (size_t)F * 4 * sizeof(float), hipMemcpyHostToDevice, q));
+    LC_HIP(b->ctx, hipMemcpyAsync(b->stars, pst, (size_t)F * S * 4 * sizeof(float), hipMemcpyHostToDevice, q));
+    hipLaunchKernelGGL(moffat_raster_kernel, dim3(F), dim3(256), 0, q, b->N, b->ss, b->moffat, b->Tm);
     if ((r = ensure_hist(b, b->iters_done + 1))) return r;
     if ((r = launch_psf(b, 0, 1, nullptr, true, false))) return r;  // stage A: no regularisation (B fixed)
-    hipLaunchKernelGGL(moffat_grad_kernel, dim3(F), dim3(256), 0, b->ctx->stream, b->N, b->ss, b->moffat, b->o_gT,
-                       b->o_gmoffat);
-    if ((r = d2h(b, loss.data(), b->o_loss, F * sizeof(float)))) return r;
-    if ((r = d2h(b, gm.data(), b->o_gmoffat, gm.size() * sizeof(float)))) return r;
-    if ((r = d2h(b, gs.data(), b->o_gstars, gs.size() * sizeof(float)))) return r;
+    hipLaunchKernelGGL(moffat_grad_kernel, dim3(F), dim3(256), 0, q, b->N, b->ss, b->moffat, b->o_gT, b->o_gmoffat);
+    LC_HIP(b->ctx, hipGetLastError());
+    LC_HIP(b->ctx, hipMemcpyAsync(loss, b->o_loss, (size_t)F * sizeof(float), hipMemcpyDeviceToHost, q));
+    LC_HIP(b->ctx, hipMemcpyAsync(gm, b->o_gmoffat, (size_t)F * 4 * sizeof(float), hipMemcpyDeviceToHost, q));
+    LC_HIP(b->ctx, hipMemcpyAsync(gs, b->o_gstars, (size_t)F * S * 4 * sizeof(float), hipMemcpyDeviceToHost, q));
+    LC_HIP(b->ctx, hipStreamSynchronize(q));
     for (int f = 0; f < F; ++f) {
       Fv[f] = loss[f];
       double *g = &G[(size_t)f * D];
