@@ -206,20 +206,26 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   auto times_spectrum = [&](float2 (&x)[N2], const float2 (&sv)[N2], const float2 *Ste, int kc, bool conj) {
     // sv: spectrum column kc, requested before the forward transform so that its latency hides behind it
     if (kc == 0) {  // one quarter of one wave, once per phase
-      float2 y[N2];
-#pragma unroll
-      for (int k2 = 0; k2 < N2; ++k2) {
-        const float2 zk = x[k2];
-        const float2 zc = (k2 == 0) ? shfl2(x[0], lane_neg) : shfl2(x[(N2 - k2) % N2], lane_mirror);
+      // bin k2 of this lane and bin N2 - k2 of its mirror lane are each other's conjugate partners: the two
+      // registers of such a pair are read (own value + partner's value by shuffle) before either is overwritten,
+      // so the split / multiply / re-pack runs in place
+      auto one = [&](float2 zk, float2 zc, int k2) {
         const float2 p = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
         const float2 q = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
         const float2 sn = Ste[(size_t)(L / 2) * L + kbase + k2];
         const float2 pp = conj ? cmul_conj(p, sv[k2]) : cmul(p, sv[k2]);
         const float2 qq = conj ? cmul_conj(q, sn) : cmul(q, sn);
-        y[k2] = make_float2(pp.x - qq.y, pp.y + qq.x);
-      }
+        return make_float2(pp.x - qq.y, pp.y + qq.x);
+      };
+      x[0] = one(x[0], shfl2(x[0], lane_neg), 0);
 #pragma unroll
-      for (int k2 = 0; k2 < N2; ++k2) x[k2] = y[k2];
+      for (int k2 = 1; k2 < N2 / 2; ++k2) {
+        const float2 za = x[k2], zb = x[N2 - k2];
+        const float2 ca = shfl2(zb, lane_mirror), cb = shfl2(za, lane_mirror);  // partners of za and of zb
+        x[k2] = one(za, ca, k2);
+        x[N2 - k2] = one(zb, cb, N2 - k2);
+      }
+      x[N2 / 2] = one(x[N2 / 2], shfl2(x[N2 / 2], lane_mirror), N2 / 2);
     } else {
 #pragma unroll
       for (int k2 = 0; k2 < N2; ++k2) x[k2] = conj ? cmul_conj(x[k2], sv[k2]) : cmul(x[k2], sv[k2]);

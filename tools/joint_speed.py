@@ -6,6 +6,7 @@ from lightcurver_amd import _lib
 from lightcurver_amd.joint import JointFit
 from lightcurver_amd.synthetic import make_roi_dataset
 E, n, M, iters = [int(x) for x in sys.argv[1:5]]
+if os.environ.get("LCMI_DEBUG_GLOBAL"): _lib.lib().lc_joint_set_debug_global(1)
 with_h = (len(sys.argv) < 6 or sys.argv[5] != 'noh')
 t0 = time.time(); ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=104); print('synth', time.time() - t0)
 ctx = _lib.Context(0)
