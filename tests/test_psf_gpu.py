@@ -193,3 +193,50 @@ def test_two_workgroup_form_is_bit_identical(ctx, n, S, F):
     for a, c in zip(out[0], out[1]):
         np.testing.assert_array_equal(a, c)
     assert np.all(np.isfinite(out[0][0]))
+
+
+def test_two_workgroup_hand_off_under_streaming_load(ctx):
+    """The in-launch hand-off of the two-workgroup form must stay exact while other work streams through the
+    memory system of every CU: a second context copies 1 GiB buffers in a loop on its own stream (its workgroups
+    share the CUs with the partner workgroups, warm their L1/L2 and delay them unevenly) while C2-sized batches are
+    fitted; every loss, grid pixel and star parameter must equal the unloaded one-workgroup result bit for bit."""
+    import ctypes as C
+    import os
+    import threading
+    from lightcurver_amd import _lib
+    n, S, F, ss, T = 32, 8, 100, 2, 150
+    os.environ['LCMI_PSF_SINGLE_WG'] = '1'
+    try:
+        ds, plist, b = _setup(n, ss, F, S, 4321, ctx, jitter=0.1)
+        b.propagate_noise()
+        b.set_regularization(None, 1.0, 1.0)
+        b.run_adabelief(T, init_learning_rate=1e-4)
+        ref = (b.loss_history(), b.get_grid(), b.get_stars())
+    finally:
+        os.environ.pop('LCMI_PSF_SINGLE_WG', None)
+    ctx2 = _lib.Context(0)
+    stop = threading.Event()
+    rates = []
+
+    def stream():
+        g = C.c_float()
+        while not stop.is_set():
+            ctx2.check(_lib.lib().lc_copy_bandwidth(ctx2.h, 1 << 30, 4, C.byref(g)), 'lc_copy_bandwidth')
+            rates.append(g.value)
+
+    th = threading.Thread(target=stream)
+    th.start()
+    try:
+        for rep in range(3):
+            ds, plist, b = _setup(n, ss, F, S, 4321, ctx, jitter=0.1)
+            b.propagate_noise()
+            b.set_regularization(None, 1.0, 1.0)
+            b.run_adabelief(T, init_learning_rate=1e-4)
+            got = (b.loss_history(), b.get_grid(), b.get_stars())
+            for a, c in zip(got, ref):
+                np.testing.assert_array_equal(a, c)
+    finally:
+        stop.set()
+        th.join()
+        ctx2.close()
+    assert len(rates) >= 1
