@@ -46,6 +46,7 @@ struct lc_joint {
   hipStream_t streamB = nullptr;      // the h regulariser runs here, concurrently with the epoch kernel
   hipEvent_t evReg = nullptr, evUpd = nullptr;
   bool reg_pending = false;
+  bool in_device_loop = false, fuse_pending = false;  // lc_joint_run_adabelief: scalar reduction fused into the update
   std::vector<float> h_sigma2, h_psf;  // host copies for the one-time noise propagation
   std::vector<void *> allocs;
 };
@@ -301,7 +302,16 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   // N^2 / 256 blocks finish the AdaBelief sweep of h in a fraction of the single-workgroup latency
   if (!v->uk || (A.lam_pts == 0.f && (reg_mode == 2 || !rh))) {
     const int NN = j->N * j->N;
-    hipLaunchKernelGGL(joint_update_gm_kernel, dim3((NN + kGmThreads - 1) / kGmThreads), dim3(kGmThreads), 0, stream, A, j->N);
+    int nblk = (NN + kGmThreads - 1) / kGmThreads;
+    if (j->fuse_pending && mode == 1) {
+      A.fuse_scalar_reduce = 1;
+      A.g_cx_e = j->g_cx_e;
+      A.g_cy_e = j->g_cy_e;
+      A.chi2_e = j->chi2_e;
+      A.shared_w = j->shared;
+      nblk = 1;
+    }
+    hipLaunchKernelGGL(joint_update_gm_kernel, dim3(nblk), dim3(kGmThreads), 0, stream, A, j->N);
     LC_HIP(j->ctx, hipGetLastError());
     return LC_OK;
   }
@@ -586,6 +596,11 @@ int lc_joint_step_local(lc_joint *j) {
   }
   int need = launch_epochs(j, 0, 0, false, nullptr);
   if (need < 0) return need;
+  // inside lc_joint_run_adabelief, with the background fixed, only scalars are reduced: the multi-block update
+  // kernel does that itself (one launch less per iteration)
+  j->fuse_pending = j->in_device_loop && need == 0 && !j->free_mask[LC_P_H] &&
+                    (!j->v->uk || (j->cfg.lam_pts_source == 0.f && (j->reg_pending || !reg_h_on(j))));
+  if (j->fuse_pending) return LC_OK;
   return launch_reduce(j, need);
 }
 int lc_joint_shared_buffer_dev(lc_joint *j, void **dev_ptr, int *count) {
@@ -611,6 +626,7 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   if (rc) return rc;
   LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
   j->reg_pending = false;
+  j->fuse_pending = false;
   j->iters_done += 1;
   return LC_OK;
 }
@@ -659,11 +675,13 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
   if (!j || n_iter <= 0) return LC_ERR_INVALID;
   int rc = ensure_hist(j, j->iters_done + n_iter + 2);
   if (rc) return rc;
-  for (int it = 0; it < n_iter; ++it) {
-    if ((rc = lc_joint_step_local(j))) return rc;
-    if ((rc = lc_joint_step_update(j, cfg))) return rc;
+  j->in_device_loop = true;
+  for (int it = 0; it < n_iter && !rc; ++it) {
+    if ((rc = lc_joint_step_local(j))) break;
+    rc = lc_joint_step_update(j, cfg);
   }
-  return LC_OK;
+  j->in_device_loop = false;
+  return rc;
 }
 int lc_joint_iterations_done(lc_joint *j) { return j ? j->iters_done : LC_ERR_INVALID; }
 

@@ -129,8 +129,14 @@ __global__ void gm_regs_kernel(int nparts_l1, int nblocks, const float *l1_part,
 __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArgs A, int N) {
   __shared__ float sc[8];
   __shared__ float red[kGmThreads / 64];
+  __shared__ double lanes[kGmThreads];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int E = A.E, M = A.M, NN = N * N;
+  if (A.fuse_scalar_reduce) {  // grid of one block (the background is not updated)
+    reduce_scalars(E, M, NN, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.shared_w, lanes, tid);
+    __threadfence_block();
+    __syncthreads();
+  }
   const float Etot = A.shared[NN + 4 * M + 1];
   const bool use_reg = (A.reg_mode == 2);
   if (tid == 0) {

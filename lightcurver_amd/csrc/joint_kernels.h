@@ -581,6 +581,36 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 // (coalesced 128-byte rows, 4 independent loads in flight per lane), then the 8 partials are added in a fixed
 // order, so the result does not depend on scheduling.  Scalars: last block, one thread each, in double.
 constexpr int kRedPix = 32, kRedParts = 8;
+// Scalars of the shared block: quantity q in [0, 4M] (dc_x, dc_y, sum a, sum a^2 per source, then chi2), one wave per
+// quantity at a time; lanes stride over the epochs in double, partials combined in lane order.  256 threads.
+__device__ __forceinline__ void reduce_scalars(int E, int M, int NN, const float *g_cx_e, const float *g_cy_e,
+                                               const float *chi2_e, const float *a, float *shared, double *lanes,
+                                               int tid) {
+  const int lane = tid & 63, wid = tid >> 6, nw = (kRedPix * kRedParts) / 64;
+  for (int q = wid; q <= 4 * M; q += nw) {
+    double acc = 0.0;
+    for (int e = lane; e < E; e += 64) {
+      if (q == 4 * M) {
+        acc += chi2_e[e];
+      } else {
+        const int kind = q / M, i = q % M;
+        const float ai = a[e * M + i];
+        acc += (kind == 0) ? (double)g_cx_e[e * M + i] : (kind == 1) ? (double)g_cy_e[e * M + i] : (kind == 2) ? (double)ai : (double)ai * ai;
+      }
+    }
+    lanes[tid] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {
+      double t = 0.0;
+      for (int l = 0; l < 64; ++l) t += lanes[wid * 64 + l];
+      shared[NN + q] = (float)t;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (tid == 0) shared[NN + 4 * M + 1] = (float)E;
+}
 __global__ __launch_bounds__(kRedPix *kRedParts) void joint_reduce_kernel(int E, int M, int NN, int need_h, const float *HG,
                                                                            const float *g_cx_e, const float *g_cy_e,
                                                                            const float *chi2_e, const float *a,
@@ -614,33 +644,8 @@ __global__ __launch_bounds__(kRedPix *kRedParts) void joint_reduce_kernel(int E,
     }
     return;
   }
-  // scalar block: quantity q in [0, 4M] (dc_x, dc_y, sum a, sum a^2 per source, then chi2), one wave per
-  // quantity at a time; lanes stride over the epochs in double, partials combined in lane order
   __shared__ double lanes[kRedPix * kRedParts];
-  const int lane = tid & 63, wid = tid >> 6, nw = (kRedPix * kRedParts) / 64;
-  for (int q = wid; q <= 4 * M; q += nw) {
-    double acc = 0.0;
-    for (int e = lane; e < E; e += 64) {
-      if (q == 4 * M) {
-        acc += chi2_e[e];
-      } else {
-        const int kind = q / M, i = q % M;
-        const float ai = a[e * M + i];
-        acc += (kind == 0) ? (double)g_cx_e[e * M + i] : (kind == 1) ? (double)g_cy_e[e * M + i] : (kind == 2) ? (double)ai : (double)ai * ai;
-      }
-    }
-    lanes[tid] = acc;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane == 0) {
-      double t = 0.0;
-      for (int l = 0; l < 64; ++l) t += lanes[wid * 64 + l];
-      shared[NN + q] = (float)t;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (tid == 0) shared[NN + 4 * M + 1] = (float)E;
+  reduce_scalars(E, M, NN, g_cx_e, g_cy_e, chi2_e, a, shared, lanes, tid);
 }
 
 // ---- kernel 3: regularisers, loss, AdaBelief -------------------------------------------------------
@@ -655,6 +660,11 @@ struct JointUpdArgs {
   float *qscr;                     // [J][N*N]
   float *par[LC_P_COUNT], *pm[LC_P_COUNT], *ps[LC_P_COUNT];  // device parameter blocks and moments (P_H unused here)
   const float *g_a, *g_dx, *g_dy, *g_mean;                    // per-epoch gradients of kernel 1
+  // fused scalar reduction (multi-block update kernel, background fixed): block 0 first sums the per-epoch scalars
+  // into shared_w, sparing the separate reduction launch
+  int fuse_scalar_reduce;
+  const float *g_cx_e, *g_cy_e, *chi2_e;
+  float *shared_w;
   float *gout[LC_P_COUNT];         // gradient outputs (mode 0), nullable
   float *hist, *out_loss;
   float lam_sc, lam_hf, lam_pos, lam_pos_ps, lam_pts, lam_fu;
