@@ -473,14 +473,17 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       vals[5 + 3 * i] = pX[i];
       vals[6 + 3 * i] = pY[i];
     }
+    const int nq = 4 + 3 * M;  // quantities in use (wave-uniform): the unused sources are not reduced
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const float s = wave_sum(vals[q]);
-      if (lane == 0) RED[wid * NQ + q] = s;
+      if (q < nq) {
+        const float s = wave_sum(vals[q]);
+        if (lane == 0) RED[wid * NQ + q] = s;
+      }
     }
     __syncthreads();
     float *TOT = RED + C::NW * NQ;
-    if (tid < NQ) {
+    if (tid < nq) {
       float acc = 0.f;
       for (int w = 0; w < C::NW; ++w) acc += RED[w * NQ + tid];
       TOT[tid] = acc;
