@@ -7,7 +7,7 @@
 #include "joint_kernels.h"
 #include "joint_gm.h"
 #include "noise_host.h"
-#include "noise_kernels.h"
+#include "starlet_norms.h"
 
 using namespace lc;
 
@@ -33,7 +33,7 @@ struct lc_joint {
   float *tabs = nullptr, *HG = nullptr;
   float *chi2_e = nullptr, *g_a = nullptr, *g_cx_e = nullptr, *g_cy_e = nullptr, *g_dx = nullptr, *g_dy = nullptr,
         *g_mean = nullptr;
-  float *model = nullptr, *fisher = nullptr, *shared = nullptr, *W = nullptr, *norms = nullptr, *atoms = nullptr,
+  float *model = nullptr, *fisher = nullptr, *shared = nullptr, *W = nullptr, *norms = nullptr,
         *qscr = nullptr, *out_loss = nullptr, *hist = nullptr, *scene2 = nullptr;
   float *prior = nullptr;  // [4][M]
   int shared_count = 0, hist_cap = 0, iters_done = 0, n_prior = 0;
@@ -387,7 +387,6 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   TRY(dmalloc(j, &j->shared, j->shared_count));
   TRY(dmalloc(j, &j->W, (size_t)(j->J + 1) * NN));
   TRY(dmalloc(j, &j->norms, j->J + 1));
-  TRY(dmalloc(j, &j->atoms, (size_t)(j->J + 1) * 3 * N));
   TRY(dmalloc(j, &j->qscr, (size_t)(j->J + 1) * NN));
   TRY(dmalloc(j, &j->out_loss, 4));
   TRY(dmalloc(j, &j->greg, NN));
@@ -428,10 +427,9 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
     std::vector<float2> tw(L);
     for (int k = 0; k < L; ++k) tw[k] = make_float2((float)std::cos(-2.0 * M_PI * k / L), (float)std::sin(-2.0 * M_PI * k / L));
     TRY(h2d(j, j->twid, tw.data(), tw.size() * sizeof(float2)));
-    std::vector<float> norms, atoms;
-    starlet_noise_tables(N, j->J, norms, atoms);
+    std::vector<float> norms;
+    starlet_scale_norms(N, j->J, norms);
     TRY(h2d(j, j->norms, norms.data(), norms.size() * sizeof(float)));
-    TRY(h2d(j, j->atoms, atoms.data(), atoms.size() * sizeof(float)));
   }
   {
     // PSF spectra: FFT2 of the zero-padded narrow PSF, stored transposed and pre-divided by L^2

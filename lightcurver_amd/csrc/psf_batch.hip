@@ -6,7 +6,7 @@
 #include <thread>
 
 #include "noise_host.h"
-#include "noise_kernels.h"
+#include "starlet_norms.h"
 #include <cstdlib>
 
 #include "psf_kernels.h"
@@ -379,10 +379,10 @@ int lc_psf_batch_create(lc_ctx *ctx, int F, int S_max, int n, int ss, const floa
     TRY(h2d(b, b->data, d.data(), d.size() * sizeof(float)));
     TRY(h2d(b, b->wgt, w.data(), w.size() * sizeof(float)));
   }
-  // starlet scale norms and the separable factors of psi_j^2
+  // starlet scale norms (the l1 weights used when no weight map is set)
   {
-    std::vector<float> norms, atoms;
-    starlet_noise_tables(b->N, b->J, norms, atoms);
+    std::vector<float> norms;
+    starlet_scale_norms(b->N, b->J, norms);
     TRY(h2d(b, b->norms, norms.data(), norms.size() * sizeof(float)));
   }
 #undef TRY

@@ -26,12 +26,11 @@ static inline void starlet_atoms_1d(int N, int J, std::vector<std::vector<double
 }
 
 
-// norms[j] = ||psi_j||_2 (j <= J, last = coarse atom), atoms[j][3][N] = p_j^2, p_j p_{j+1}, p_{j+1}^2.
-static inline void starlet_noise_tables(int N, int J, std::vector<float> &norms, std::vector<float> &atoms) {
+// norms[j] = ||psi_j||_2 (j <= J, last = the coarse atom)
+static inline void starlet_scale_norms(int N, int J, std::vector<float> &norms) {
   std::vector<std::vector<double>> p;
   starlet_atoms_1d(N, J, p);
   norms.assign(J + 1, 0.f);
-  atoms.assign((size_t)(J + 1) * 3 * N, 0.f);
   for (int j = 0; j <= J; ++j) {
     double s_pp = 0, s_qq = 0, s_pq = 0;
     for (int i = 0; i < N; ++i) {
@@ -39,9 +38,6 @@ static inline void starlet_noise_tables(int N, int J, std::vector<float> &norms,
       s_pp += pj * pj;
       s_qq += qj * qj;
       s_pq += pj * qj;
-      atoms[((size_t)j * 3 + 0) * N + i] = (float)(pj * pj);
-      atoms[((size_t)j * 3 + 1) * N + i] = (float)(pj * qj);
-      atoms[((size_t)j * 3 + 2) * N + i] = (float)(qj * qj);
     }
     norms[j] = (float)std::sqrt(std::max(s_pp * s_pp - 2.0 * s_pq * s_pq + s_qq * s_qq, 0.0));
   }
