@@ -1,11 +1,13 @@
 // Joint multi-epoch forward-model object behind the C ABI (include/lcmi.h, "joint" section).
 #include <cmath>
+#include <cstdlib>
 #include <complex>
 #include <thread>
 #include <cstring>
 
 #include "joint_kernels.h"
 #include "joint_gm.h"
+#include "joint_ps.h"
 #include "noise_host.h"
 #include "starlet_norms.h"
 
@@ -42,6 +44,7 @@ struct lc_joint {
   lc_joint_loss_cfg cfg{};
   float *greg = nullptr, *regs = nullptr;
   float2 *spec = nullptr;             // [E][N][KH] spectrum scratch of the large-grid epoch kernel
+  float *psf_dev = nullptr, *psF = nullptr;  // point-source-only path: narrow PSFs [E][N*N], filter outputs [E][M][3][n*n]
   float *gm_c = nullptr, *gm_t = nullptr, *gm_n = nullptr, *gm_y = nullptr, *gm_l1 = nullptr, *gm_pos = nullptr;
   hipStream_t streamB = nullptr;      // the h regulariser runs here, concurrently with the epoch kernel
   hipEvent_t evReg = nullptr, evUpd = nullptr;
@@ -159,6 +162,22 @@ bool reg_h_on(const lc_joint *j) {
   return lam && (j->free_mask[LC_P_H] || j->h_nonzero);
 }
 
+typedef void (*ps_fn)(JointPsArgs);
+void find_ps_kernel(int N, int ss, ps_fn *fn, int *lds) {
+  *fn = nullptr;
+#define LC_PS(NN_, SS_)                          \
+  if (N == NN_ && ss == SS_) {                   \
+    *fn = joint_ps_kernel<NN_, SS_>;             \
+    *lds = joint_ps_lds_bytes<NN_, SS_>();       \
+  }
+  LC_PS(16, 1)
+  LC_PS(32, 2)
+  LC_PS(48, 2)
+  LC_PS(64, 2)
+  LC_PS(128, 2)
+#undef LC_PS
+}
+
 int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model_out) {
   const JointVariant *v = j->v;
   JointArgs A;
@@ -193,6 +212,26 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   A.g_mean = j->g_mean;
   A.model_out = model_out;
   A.fisher_out = j->fisher;
+  // no background in the scene: separable Gaussian filtering of the epoch PSFs instead of the FFT pipeline
+  if (!A.h_active && j->M > 0 && j->psf_dev && !std::getenv("LCMI_JOINT_FFT_ONLY")) {
+    ps_fn pk = nullptr;
+    int plds = 0;
+    find_ps_kernel(j->N, j->ss, &pk, &plds);
+    if (pk) {
+      if (!j->psF) {
+        int rc = dmalloc(j, &j->psF, (size_t)j->E * j->M * 3 * j->n * j->n);
+        if (rc) return rc;
+      }
+      JointPsArgs P;
+      P.J = A;
+      P.psf = j->psf_dev;
+      P.F = j->psF;
+      LC_HIP(j->ctx, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
+      hipLaunchKernelGGL(pk, dim3(j->E), dim3(kPsThreads), plds, j->ctx->stream, P);
+      LC_HIP(j->ctx, hipGetLastError());
+      return 0;
+    }
+  }
   LC_HIP(j->ctx, hipFuncSetAttribute((const void *)v->ek, hipFuncAttributeMaxDynamicSharedMemorySize, v->e_lds));
   hipLaunchKernelGGL(v->ek, dim3(j->E), dim3(v->e_thr), v->e_lds, j->ctx->stream, A);
   LC_HIP(j->ctx, hipGetLastError());
@@ -434,6 +473,10 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   {
     // PSF spectra: FFT2 of the zero-padded narrow PSF, stored transposed and pre-divided by L^2
     j->h_psf.assign(psf, psf + E * NN);
+    if (N <= 128) {
+      TRY(dmalloc(j, &j->psf_dev, (size_t)E * NN));
+      TRY(h2d(j, j->psf_dev, psf, (size_t)E * NN * sizeof(float)));
+    }
     std::vector<float2> st((size_t)E * KH * L);
     const double sc = 1.0 / ((double)L * L);
     const int T = noise_threads(E);

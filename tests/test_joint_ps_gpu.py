@@ -1,0 +1,84 @@
+"""GPU parity of the point-source-only joint path (csrc/joint_ps.h: separable Gaussian filtering of the epoch PSFs,
+taken whenever the background is zero and fixed -- the reference's default star photometry,
+lightcurver/processes/star_photometry.py:74-87) against the float64 oracle and against the library's own FFT
+pipeline (LCMI_JOINT_FFT_ONLY=1).  Tolerances as in test_joint_gpu.py: 3e-5 on models / losses, 1e-4 on gradients."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import model as om, optim as oo
+from lightcurver_amd.synthetic import make_roi_dataset
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ctx, E, M, n, ss, seed, alpha_sigma=0.0, edge=False):
+    from lightcurver_amd.joint import JointFit
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=seed, alpha_sigma=alpha_sigma, with_background=False)
+    rng = np.random.default_rng(seed + 1)
+    p = {k: np.array(v, dtype=np.float64) for k, v in ds['truth'].items()}
+    p['a'] = p['a'] * rng.uniform(0.9, 1.1, p['a'].shape)
+    p['c_x'] = p['c_x'] + rng.normal(0, 0.1, M)
+    p['c_y'] = p['c_y'] + rng.normal(0, 0.1, M)
+    p['dx'] = p['dx'] + rng.normal(0, 0.05, E)
+    p['dy'] = p['dy'] + rng.normal(0, 0.05, E)
+    p['mean'] = rng.normal(0, 1e-3, E)
+    p['h'] = np.zeros_like(p['h'])
+    if edge:  # a source 1.5 data pixels from the stamp edge: its Gaussian is cut by the scene grid
+        p['c_x'][0] = n / 2.0 - 1.5
+        p['c_y'][0] = -(n / 2.0 - 2.2)
+    j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
+    j.set_params(**p)
+    po = {k: om.T(v) for k, v in p.items()}
+    return ds, j, p, po, om.T(ds['data']), om.T(ds['noisemap']) ** 2, om.T(ds['psf'])
+
+
+@pytest.mark.parametrize('E,M,n,ss,alpha,edge', [(3, 1, 16, 1, 0.0, False), (4, 2, 16, 2, 0.0, False), (3, 2, 16, 2, 3.0, False),
+                                                 (3, 3, 24, 2, 0.5, False), (3, 1, 32, 2, 0.0, True), (2, 2, 64, 2, 0.3, False)])
+def test_point_sources_only_matches_oracle_and_fft_path(ctx, E, M, n, ss, alpha, edge):
+    ds, j, p, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 500 + n + M, alpha_sigma=alpha, edge=edge)
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'mean']
+    j.set_loss(lam_positivity_ps=5.0, lam_flux_uniformity=0.4)
+    j.set_free(free)
+    model, chi2_e = j.model()
+    mo = om.deconv_model(po, psf, ss, n)
+    assert H.rel_err(model, mo.numpy()) < 3e-5
+    assert H.rel_err(chi2_e, (((data - mo) ** 2) / sig2).sum((-1, -2)).numpy()) < 3e-5
+    L, g = oo.value_and_grad(lambda q: om.deconv_loss(q, data, sig2, psf, ss, lam_pos_ps=5.0, lam_fu=0.4), po, free)
+    loss, grads = j.loss_grad(free)
+    assert abs(loss - float(L)) / abs(float(L)) < 3e-5
+    for k in free:
+        assert H.rel_err(grads[k], g[k].numpy()) < 1e-4, k
+    sig = j.fisher_flux_sigma()
+    assert H.rel_err(sig, om.fisher_flux_sigma(po, sig2, psf, ss).numpy()) < 3e-5
+    # the library's FFT pipeline on the same object
+    os.environ['LCMI_JOINT_FFT_ONLY'] = '1'
+    try:
+        model_f, _ = j.model()
+        loss_f, grads_f = j.loss_grad(free)
+        sig_f = j.fisher_flux_sigma()
+    finally:
+        os.environ.pop('LCMI_JOINT_FFT_ONLY', None)
+    assert H.rel_err(model, model_f) < 2e-5 and abs(loss - loss_f) < 2e-5 * abs(loss_f)
+    assert H.rel_err(sig, sig_f) < 2e-5
+    for k in free:
+        assert H.rel_err(grads[k], grads_f[k]) < 1e-4, k
+
+
+def test_point_sources_only_trajectory(ctx):
+    E, M, n, ss, T = 6, 1, 32, 2, 30
+    ds, j, p, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 77)
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'mean']
+    j.set_loss()
+    j.set_free(free)
+    j.run_adabelief(T, init_learning_rate=1e-3, schedule_learning_rate=True)
+    hist = j.loss_history()
+    pf, lh, l0 = oo.adabelief(lambda q: om.deconv_loss(q, data, sig2, psf, ss), po, free, 1e-3, T, schedule=True)
+    ref = np.array([l0] + lh)
+    assert np.abs(hist - ref).max() / np.abs(ref).max() < 2e-4
+    got = j.get_params()
+    assert H.rel_err(got['a'], pf['a'].numpy()) < 2e-4
+    assert np.abs(got['c_x'] - pf['c_x'].numpy()).max() < 5e-4
+    assert np.abs(got['dy'] - pf['dy'].numpy()).max() < 5e-4
