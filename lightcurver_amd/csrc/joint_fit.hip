@@ -336,6 +336,7 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   A.prior_cy_mean = j->prior + 2 * j->M;
   A.prior_cy_sigma = j->prior + 3 * j->M;
   if (cfg) A.ab = *cfg; else lc_adabelief_defaults(&A.ab);
+  adabelief_schedule(A.ab, t, A.lr, A.bc1, A.bc2);
   // the multi-block update serves the large grids always, and the LDS variants whenever nothing is left for one
   // workgroup to do alone (h regulariser already evaluated on the second stream, no point-source starlet term):
   // N^2 / 256 blocks finish the AdaBelief sweep of h in a fraction of the single-workgroup latency

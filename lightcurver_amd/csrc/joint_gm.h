@@ -140,12 +140,9 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
   const float Etot = A.shared[NN + 4 * M + 1];
   const bool use_reg = (A.reg_mode == 2);
   if (tid == 0) {
-    const double t1 = (double)(A.t + 1);
-    double lr = A.ab.init_learning_rate;
-    if (A.ab.schedule_learning_rate) lr *= pow((double)A.ab.decay_rate, (double)A.t / (double)A.ab.transition_steps);
-    sc[0] = (float)lr;
-    sc[1] = (float)(1.0 / (1.0 - pow((double)A.ab.b1, t1)));
-    sc[2] = (float)(1.0 / (1.0 - pow((double)A.ab.b2, t1)));
+    sc[0] = A.lr;
+    sc[1] = A.bc1;
+    sc[2] = A.bc2;
   }
   __syncthreads();
   const float lr = sc[0], bc1 = sc[1], bc2 = sc[2];

@@ -674,6 +674,7 @@ struct JointUpdArgs {
   int n_prior;
   const float *prior_cx_mean, *prior_cx_sigma, *prior_cy_mean, *prior_cy_sigma;
   lc_adabelief_cfg ab;
+  float lr, bc1, bc2;  // learning rate and bias corrections of iteration t, evaluated on the host (adabelief_schedule)
 };
 
 __device__ __forceinline__ float adabelief_step(float &p, float &m, float &s, float g, float lr, float bc1, float bc2,
@@ -824,12 +825,9 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
   // scalars: learning rate, bias corrections, flux statistics, loss
   float *sc = red + NWV * 2;  // [0] lr [1] bc1 [2] bc2
   if (tid == 0) {
-    const double t1 = (double)(A.t + 1);
-    double lr = A.ab.init_learning_rate;
-    if (A.ab.schedule_learning_rate) lr *= pow((double)A.ab.decay_rate, (double)A.t / (double)A.ab.transition_steps);
-    sc[0] = (float)lr;
-    sc[1] = (float)(1.0 / (1.0 - pow((double)A.ab.b1, t1)));
-    sc[2] = (float)(1.0 / (1.0 - pow((double)A.ab.b2, t1)));
+    sc[0] = A.lr;
+    sc[1] = A.bc1;
+    sc[2] = A.bc2;
     float tl1 = 0.f, tpos = 0.f;
     for (int w = 0; w < NWV; ++w) {
       tl1 += red[w * 2];

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,16 @@ struct lc_ctx {
   std::string err;
   int n_cu = 0;
 };
+
+// learning rate and bias corrections of AdaBelief iteration t (0-based), in double on the host: the kernels take
+// them as numbers instead of evaluating three double-precision pow() in one lane per iteration
+inline void adabelief_schedule(const lc_adabelief_cfg &ab, int t, float &lr, float &bc1, float &bc2) {
+  double l = ab.init_learning_rate;
+  if (ab.schedule_learning_rate) l *= std::pow((double)ab.decay_rate, (double)t / (double)ab.transition_steps);
+  lr = (float)l;
+  bc1 = (float)(1.0 / (1.0 - std::pow((double)ab.b1, (double)(t + 1))));
+  bc2 = (float)(1.0 / (1.0 - std::pow((double)ab.b2, (double)(t + 1))));
+}
 
 #define LC_HIP(ctx, call)                                                                  \
   do {                                                                                     \

@@ -21,6 +21,9 @@ struct lc_psf_batch {
   float *B = nullptr, *mB = nullptr, *sB = nullptr;
   float *stars = nullptr, *stars_m = nullptr, *stars_s = nullptr, *moffat = nullptr;
   float *hist = nullptr, *qscratch = nullptr;
+  float *sched = nullptr;  // AdaBelief schedule table of the current launch [cap][3]
+  int sched_cap = 0;
+  lc_adabelief_cfg sched_cfg{};
   float *ntab = nullptr;  // noise propagation: 1-D starlet tables [F][S][J][3][2][N]
   float *B1 = nullptr, *mB1 = nullptr, *sB1 = nullptr;  // role 1's copy of the pixel state (n = 64)
   float *xch = nullptr;   // two-workgroup form: exchange slabs, flags, abort word
@@ -244,6 +247,26 @@ int launch_psf(lc_psf_batch *b, int mode, int n_iter, const lc_adabelief_cfg *cf
   A.lam_sc = reg ? b->lam_sc : 0.f;
   A.lam_hf = reg ? b->lam_hf : 0.f;
   if (cfg) A.ab = *cfg; else lc_adabelief_defaults(&A.ab);
+  if (mode == 1) {
+    // learning rate and bias corrections by absolute iteration, evaluated here in double; the table is rebuilt only
+    // when the optimiser settings change or the iteration count outgrows it, so back-to-back launches stay asynchronous
+    const int need = A.t0 + n_iter;
+    if (need > b->sched_cap || std::memcmp(&A.ab, &b->sched_cfg, sizeof(A.ab)) != 0) {
+      const int cap = std::max(need * 2, 4096);
+      if (cap > b->sched_cap) {
+        b->sched = nullptr;  // the old table stays in the allocation list until the object goes
+        int rc = dmalloc(b, &b->sched, (size_t)3 * cap);
+        if (rc) return rc;
+        b->sched_cap = cap;
+      }
+      std::vector<float> tab((size_t)3 * b->sched_cap);
+      for (int t = 0; t < b->sched_cap; ++t) adabelief_schedule(A.ab, t, tab[3 * t], tab[3 * t + 1], tab[3 * t + 2]);
+      LC_HIP(b->ctx, hipMemcpyAsync(b->sched, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, b->ctx->stream));
+      LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));  // `tab` is pageable and goes out of scope
+      b->sched_cfg = A.ab;
+    }
+    A.sched = b->sched;
+  }
   // Two workgroups per frame when the optimisation loop would otherwise leave more than half of the CUs idle.
   // Every workgroup of that grid must be resident at once (partners wait for each other): one per CU.
   const int split_grid = ((b->F + 7) / 8) * 16;

@@ -46,6 +46,7 @@ struct PsfArgs {
   // per-(frame, role) iteration flags [F][2], one abort word
   float *xch;
   int *xflags, *xabort;
+  const float *sched;     // [>= t0 + n_iter][3]: learning rate and bias corrections by absolute iteration (host-made)
   float *B1, *mB1, *sB1;  // [F][N*N]: role 1's own copy of the pixel state when it does not fit in registers
 };
 
@@ -253,15 +254,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     const int pu = tid / (N / PX);         // owned row
     const int pv = (tid % (N / PX)) * PX;  // first owned column
     const size_t gpix = (size_t)f * N * N + (size_t)pu * N + pv;
-    if (tid == 0 && A.mode == 1) {
-      const double t1 = (double)(tglob + 1);
-      double lr = A.ab.init_learning_rate;
-      if (A.ab.schedule_learning_rate)
-        lr *= pow((double)A.ab.decay_rate, (double)tglob / (double)A.ab.transition_steps);
-      SCAL[0] = (float)lr;
-      SCAL[1] = (float)(1.0 / (1.0 - pow((double)A.ab.b1, t1)));
-      SCAL[2] = (float)(1.0 / (1.0 - pow((double)A.ab.b2, t1)));
-    }
+    if (tid < 3 && A.mode == 1) SCAL[tid] = A.sched[3 * tglob + tid];  // lr, bc1, bc2
     LC_STAMP(0);
     float gB[PX];
 #pragma unroll
