@@ -8,6 +8,7 @@
 #include "joint_kernels.h"
 #include "joint_gm.h"
 #include "joint_ps.h"
+#include "joint_noise.h"
 #include "noise_host.h"
 #include "starlet_norms.h"
 
@@ -22,6 +23,7 @@ struct JointVariant {
   update_fn uk;  // null: regulariser + update run as global-memory kernels (joint_gm.h)
   int u_thr, u_lds;
   bool gspec;
+  epoch_fn ek_aux;  // plain convolution / spectrum modes of the same pipeline (noise propagation)
 };
 
 struct lc_joint {
@@ -44,6 +46,8 @@ struct lc_joint {
   lc_joint_loss_cfg cfg{};
   float *greg = nullptr, *regs = nullptr;
   float2 *spec = nullptr;             // [E][N][KH] spectrum scratch of the large-grid epoch kernel
+  float *nz_a = nullptr, *nz_b = nullptr, *nz_c = nullptr, *nz_up = nullptr, *nz_scene = nullptr;  // noise propagation [E][N*N]
+  float2 *St_alt = nullptr;                                                                        // [E][KH][L]
   float *psf_dev = nullptr, *psF = nullptr;  // point-source-only path: narrow PSFs [E][N*N], filter outputs [E][M][3][n*n]
   float *gm_c = nullptr, *gm_t = nullptr, *gm_n = nullptr, *gm_y = nullptr, *gm_l1 = nullptr, *gm_pos = nullptr;
   hipStream_t streamB = nullptr;      // the h regulariser runs here, concurrently with the epoch kernel
@@ -78,13 +82,13 @@ template <int N, int SS, int L, int PX, int NW>
 JointVariant make_jv() {
   typedef JointCfg<N, SS, L, NW> C;
   return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, joint_update_kernel<N, PX>, N * N / PX,
-                      (int)(StarletLds<N>::FLOATS * sizeof(float)), false};
+                      (int)(StarletLds<N>::FLOATS * sizeof(float)), false, joint_epoch_kernel<C, true>};
 }
 // large grids: spectrum scratch in HBM, starlet / update as multi-block kernels
 template <int N, int SS, int L, int NW>
 JointVariant make_jv_gm() {
   typedef JointCfg<N, SS, L, NW, true> C;
-  return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, nullptr, 0, 0, true};
+  return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, nullptr, 0, 0, true, joint_epoch_kernel<C, true>};
 }
 int g_debug_global = 0;  // lc_joint_set_debug_global: small stamps through the large-grid kernels (parity tests)
 const JointVariant *find_jv(int n, int ss) {
@@ -474,10 +478,8 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   {
     // PSF spectra: FFT2 of the zero-padded narrow PSF, stored transposed and pre-divided by L^2
     j->h_psf.assign(psf, psf + E * NN);
-    if (N <= 128) {
-      TRY(dmalloc(j, &j->psf_dev, (size_t)E * NN));
-      TRY(h2d(j, j->psf_dev, psf, (size_t)E * NN * sizeof(float)));
-    }
+    TRY(dmalloc(j, &j->psf_dev, (size_t)E * NN));
+    TRY(h2d(j, j->psf_dev, psf, (size_t)E * NN * sizeof(float)));
     std::vector<float2> st((size_t)E * KH * L);
     const double sc = 1.0 / ((double)L * L);
     const int T = noise_threads(E);
@@ -580,10 +582,82 @@ int lc_joint_set_loss(lc_joint *j, const lc_joint_loss_cfg *cfg, const float *W)
   return LC_OK;
 }
 
+namespace {
+// one launch of the auxiliary epoch kernel: mode 4 (scene -> spectrum) or mode 3 (scene (*) spectrum -> image)
+int launch_aux(lc_joint *j, int mode, const float *scene, const float2 *St_in, float2 *St_out, float *conv_out) {
+  const JointVariant *v = j->v;
+  JointArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.E = j->E;
+  A.M = 0;
+  A.mode = mode;
+  A.St = St_in;
+  A.spec = j->spec;
+  A.twid = j->twid;
+  A.a = j->par[LC_P_A];
+  A.cx = j->par[LC_P_CX];
+  A.cy = j->par[LC_P_CY];
+  A.dx = j->par[LC_P_DX];
+  A.dy = j->par[LC_P_DY];
+  A.alpha = j->par[LC_P_ALPHA];
+  A.h = j->par[LC_P_H];
+  A.mean = j->par[LC_P_MEAN];
+  A.tabs = j->tabs;
+  A.scene_in = scene;
+  A.St_out = St_out;
+  A.conv_out = conv_out;
+  LC_HIP(j->ctx, hipFuncSetAttribute((const void *)v->ek_aux, hipFuncAttributeMaxDynamicSharedMemorySize, v->e_lds));
+  hipLaunchKernelGGL(v->ek_aux, dim3(j->E), dim3(v->e_thr), v->e_lds, j->ctx->stream, A);
+  LC_HIP(j->ctx, hipGetLastError());
+  return LC_OK;
+}
+
+int propagate_noise_device(lc_joint *j) {
+  const int N = j->N, ss = j->ss, E = j->E, J = j->J, c = (N - 1) / 2, shift = ss * (j->n / 2) - c;
+  const size_t NN = (size_t)N * N, ENN = (size_t)E * NN;
+  int rc;
+  if (!j->nz_a) {
+    if ((rc = dmalloc(j, &j->nz_a, ENN)) || (rc = dmalloc(j, &j->nz_b, ENN)) || (rc = dmalloc(j, &j->nz_c, ENN)) ||
+        (rc = dmalloc(j, &j->nz_up, ENN)) || (rc = dmalloc(j, &j->nz_scene, ENN)) ||
+        (rc = dmalloc(j, &j->St_alt, (size_t)E * j->KH * j->L)))
+      return rc;
+  }
+  hipStream_t q = j->ctx->stream;
+  const dim3 grid((unsigned)((NN + kNzThreads - 1) / kNzThreads), (unsigned)E), block(kNzThreads);
+  hipLaunchKernelGGL(nz_up0_kernel, grid, block, 0, q, N, ss, j->wgt, j->nz_up);
+  hipLaunchKernelGGL(nz_response_kernel, grid, block, 0, q, N, ss, j->psf_dev, j->nz_a);
+  float *cur = j->nz_a, *nxt = j->nz_c;
+  for (int s = 0; s <= J; ++s) {
+    if (s < J) {
+      hipLaunchKernelGGL(nz_pass_kernel, grid, block, 0, q, N, 1 << s, 1, cur, j->nz_b);
+      hipLaunchKernelGGL(nz_pass_kernel, grid, block, 0, q, N, 1 << s, 0, j->nz_b, nxt);
+    }
+    hipLaunchKernelGGL(nz_kappa2_kernel, grid, block, 0, q, N, shift, cur, s < J ? nxt : (const float *)nullptr, j->nz_scene);
+    LC_HIP(j->ctx, hipGetLastError());
+    if ((rc = launch_aux(j, 4, j->nz_scene, nullptr, j->St_alt, nullptr))) return rc;       // spectra of kappa^2
+    if ((rc = launch_aux(j, 3, j->nz_up, j->St_alt, nullptr, j->HG))) return rc;            // up0(w_e) (*) kappa_e^2
+    if ((rc = launch_reduce(j, 1))) return rc;                                              // sum over the epochs
+    hipLaunchKernelGGL(nz_sqrt_kernel, dim3((unsigned)((NN + kNzThreads - 1) / kNzThreads)), block, 0, q, (int)NN, j->shared,
+                       j->W + (size_t)s * NN);
+    LC_HIP(j->ctx, hipGetLastError());
+    std::swap(cur, nxt);
+  }
+  return LC_OK;
+}
+}  // namespace
+
 int lc_joint_propagate_noise(lc_joint *j, float *W_out) {
   if (!j) return LC_ERR_INVALID;
   const int N = j->N, n = j->n, ss = j->ss, E = j->E, c = (N - 1) / 2;
   const size_t NN = (size_t)N * N, nn = (size_t)n * n;
+  if (!std::getenv("LCMI_NOISE_HOST")) {
+    int rc = propagate_noise_device(j);
+    if (rc) return rc;
+    j->have_W = true;
+    if (W_out && (rc = d2h(j, W_out, j->W, (size_t)(j->J + 1) * NN * sizeof(float)))) return rc;
+    return LC_OK;
+  }
+  // host path (double-precision FFT convolutions, threaded), kept as an independent cross-check: LCMI_NOISE_HOST=1
   // contributor = epoch; response of dL/dh to a unit of whitened noise in data pixel p* = (n/2, n/2):
   //   r_e[u'][v'] = sum_{(u,v) in block(p*)} s_e[u - u' + c][v - v' + c]      (adjoint of D_ss . conv_same(., s_e))
   std::vector<float> w((size_t)E * nn);

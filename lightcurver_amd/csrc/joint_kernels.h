@@ -39,6 +39,12 @@ struct JointArgs {
   float *chi2_e, *g_a, *g_cx_e, *g_cy_e, *g_dx, *g_dy, *g_mean;
   float *model_out;           // [E][n][n] or null
   float *fisher_out;          // [E][M]
+  // auxiliary instantiation (AUX = true; noise propagation on the device, csrc/joint_noise.h):
+  //   mode 3: conv_same(scene_in[e], image whose spectrum is St[e]) -> conv_out[e] at full resolution
+  //   mode 4: spectrum of scene_in[e] in the layout of St -> St_out[e]
+  const float *scene_in;      // [E][N][N]
+  float2 *St_out;             // [E][L/2+1][L]
+  float *conv_out;            // [E][N][N]
 };
 
 __device__ __forceinline__ void sample_coords(int u, int v, float c0, float ca, float sa, float sdx, float sdy,
@@ -88,7 +94,7 @@ struct JointCfg {
   static_assert(LDS_BYTES <= 163840, "LDS");
 };
 
-template <class C>
+template <class C, bool AUX = false>
 __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   constexpr int N = C::N, SS = C::SS, L = C::L, n = C::n, KH = C::KH, CREF = C::CREF;
   extern __shared__ __align__(16) float2 lds2[];
@@ -241,7 +247,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     for (int n2 = 0; n2 < N2; ++n2) {
       const int v = l16 + 16 * n2;
       float2 z = make_float2(0.f, 0.f);
-      if (active && v < N) {
+      if constexpr (AUX) {
+        if (active && v < N) {
+          const float *si = A.scene_in + (size_t)e * N * N;
+          z = make_float2(si[u0 * N + v], si[(u0 + 1) * N + v]);
+        }
+      } else if (active && v < N) {
         float s0 = 0.f, s1 = 0.f;
         for (int i = 0; i < M; ++i) {
           const float gx = tab[(0 * M + i) * N + v];
@@ -264,6 +275,33 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   }
   __syncthreads();
   LC_JSTAMP(2);
+  if constexpr (AUX) {
+    if (A.mode == 4) {  // forward column transforms only: the spectrum of scene_in[e], transposed, divided by L^2
+      float2 *So = A.St_out + (size_t)e * KH * L;
+      const float sc = 1.0f / ((float)L * (float)L);
+      for (int kc0 = wid * 4; kc0 < NCOL; kc0 += C::NW * 4) {
+        const int kc = kc0 + qid;
+        const bool active = kc < NCOL;
+        const int kcs = active ? kc : 1;
+        float2 x[N2];
+        load_column(x, kcs, active, 0);
+        quarter_fft_fwd<L>(x, l16, TW);
+        if (kcs == 0) {  // packed pair: column 0 = Hermitian part, column L/2 = anti-Hermitian part / i
+#pragma unroll
+          for (int k2 = 0; k2 < N2; ++k2) {
+            const float2 zk = x[k2];
+            const float2 zc = (k2 == 0) ? shfl2(x[0], lane_neg) : shfl2(x[(N2 - k2) % N2], lane_mirror);
+            So[kbase + k2] = make_float2(0.5f * sc * (zk.x + zc.x), 0.5f * sc * (zk.y - zc.y));
+            So[(size_t)(L / 2) * L + kbase + k2] = make_float2(0.5f * sc * (zk.y + zc.y), -0.5f * sc * (zk.x - zc.x));
+          }
+        } else if (active) {
+#pragma unroll
+          for (int k2 = 0; k2 < N2; ++k2) So[(size_t)kcs * L + kbase + k2] = make_float2(sc * x[k2].x, sc * x[k2].y);
+        }
+      }
+      return;
+    }
+  }
   // ---- phase B: columns: FFT, multiply by the PSF spectrum, inverse FFT, keep the 'same' window ----
   const float2 *Ste = A.St + (size_t)e * KH * L;
   for (int kc0 = wid * 4; kc0 < NCOL; kc0 += C::NW * 4) {
@@ -281,6 +319,25 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   }
   __syncthreads();
   LC_JSTAMP(3);
+  if constexpr (AUX) {  // mode 3: inverse rows, 'same' window of the convolution at full resolution
+    float *co = A.conv_out + (size_t)e * N * N;
+    for (int rp0 = wid * 4; rp0 < N / 2; rp0 += C::NW * 4) {
+      const int rp = rp0 + qid, u0 = 2 * rp;
+      const bool active = rp < N / 2;
+      float2 x[N2];
+      pack_rows(x, u0, active);
+      quarter_fft_inv<L>(x, l16, TW);
+#pragma unroll
+      for (int n2 = 0; n2 < N2; ++n2) {
+        const int v = l16 + 16 * n2 - CREF;
+        if (active && v >= 0 && v < N) {
+          co[u0 * N + v] = x[n2].x;
+          co[(u0 + 1) * N + v] = x[n2].y;
+        }
+      }
+    }
+    return;
+  }
   // ---- phase C: inverse rows -> model, residuals; forward rows of the up-sampled weighted residual ----
   float acc_chi = 0.f, acc_mean = 0.f, acc_fis = 0.f;
   const float *de = A.data + (size_t)e * n * n, *we = A.wgt + (size_t)e * n * n;

@@ -106,3 +106,26 @@ def test_n128_loss_gradients_and_steps(ctx):
     ref = np.array([l0] + lh)
     assert np.abs(hist - ref).max() / np.abs(ref).max() < 2e-4
     assert H.rel_err(j.get_params()['a'], pf['a'].numpy()) < 2e-4
+
+
+def test_n128_noise_propagation_device_vs_host(ctx):
+    """Noise propagation at the configs[4] stamp size: the device path (FFT pipeline of the large-grid epoch kernel)
+    against the library's double-precision host implementation."""
+    import os
+    ds, j, po, data, sig2, psf = _setup(ctx, 2, 2, 128, 2, 778)
+    W = j.propagate_noise()
+    os.environ['LCMI_NOISE_HOST'] = '1'
+    try:
+        Wh = j.propagate_noise()
+    finally:
+        os.environ.pop('LCMI_NOISE_HOST', None)
+    assert W.shape == Wh.shape == (9, 256, 256)
+    for s in range(W.shape[0]):
+        assert H.rel_err(W[s], Wh[s]) < 2e-4, s
+
+
+def test_forced_global_noise_propagation(ctx, global_kernels):
+    ds, j, po, data, sig2, psf = _setup(ctx, 3, 2, 32, 2, 31)
+    W = j.propagate_noise()
+    Wo = om.propagate_noise_deconv(sig2, psf, 2).numpy()
+    assert H.rel_err(W, Wo) < 1e-4
