@@ -365,6 +365,35 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   return LC_OK;
 }
 
+// one launch of the auxiliary epoch kernel: mode 4 (scene -> spectrum) or mode 3 (scene (*) spectrum -> image)
+int launch_aux(lc_joint *j, int mode, const float *scene, const float2 *St_in, float2 *St_out, float *conv_out) {
+  const JointVariant *v = j->v;
+  JointArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.E = j->E;
+  A.M = 0;
+  A.mode = mode;
+  A.St = St_in;
+  A.spec = j->spec;
+  A.twid = j->twid;
+  A.a = j->par[LC_P_A];
+  A.cx = j->par[LC_P_CX];
+  A.cy = j->par[LC_P_CY];
+  A.dx = j->par[LC_P_DX];
+  A.dy = j->par[LC_P_DY];
+  A.alpha = j->par[LC_P_ALPHA];
+  A.h = j->par[LC_P_H];
+  A.mean = j->par[LC_P_MEAN];
+  A.tabs = j->tabs;
+  A.scene_in = scene;
+  A.St_out = St_out;
+  A.conv_out = conv_out;
+  LC_HIP(j->ctx, hipFuncSetAttribute((const void *)v->ek_aux, hipFuncAttributeMaxDynamicSharedMemorySize, v->e_lds));
+  hipLaunchKernelGGL(v->ek_aux, dim3(j->E), dim3(v->e_thr), v->e_lds, j->ctx->stream, A);
+  LC_HIP(j->ctx, hipGetLastError());
+  return LC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -480,26 +509,32 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
     j->h_psf.assign(psf, psf + E * NN);
     TRY(dmalloc(j, &j->psf_dev, (size_t)E * NN));
     TRY(h2d(j, j->psf_dev, psf, (size_t)E * NN * sizeof(float)));
-    std::vector<float2> st((size_t)E * KH * L);
-    const double sc = 1.0 / ((double)L * L);
-    const int T = noise_threads(E);
-    std::vector<std::thread> pool;
-    for (int t = 0; t < T; ++t)
-      pool.emplace_back([&, t]() {
-        std::vector<cd> a((size_t)L * L);
-        for (int e = t; e < E; e += T) {
-          std::fill(a.begin(), a.end(), cd(0, 0));
-          for (int r = 0; r < N; ++r)
-            for (int c = 0; c < N; ++c) a[(size_t)r * L + c] = psf[(size_t)e * NN + (size_t)r * N + c];
-          host_fft2d(a, L, 0, N, false);
-          float2 *se = st.data() + (size_t)e * KH * L;
-          for (int k = 0; k < KH; ++k)
-            for (int r = 0; r < L; ++r)
-              se[(size_t)k * L + r] = make_float2((float)(a[(size_t)r * L + k].real() * sc), (float)(a[(size_t)r * L + k].imag() * sc));
-        }
-      });
-    for (auto &th : pool) th.join();
-    TRY(h2d(j, j->St, st.data(), st.size() * sizeof(float2)));
+    if (!std::getenv("LCMI_SPECTRA_HOST")) {
+      // on the device: the row / column FFT passes of the epoch kernel in its spectrum mode
+      TRY(launch_aux(j, 4, j->psf_dev, nullptr, j->St, nullptr));
+    } else {
+      // host (double precision, threaded): independent cross-check
+      std::vector<float2> st((size_t)E * KH * L);
+      const double sc = 1.0 / ((double)L * L);
+      const int T = noise_threads(E);
+      std::vector<std::thread> pool;
+      for (int t = 0; t < T; ++t)
+        pool.emplace_back([&, t]() {
+          std::vector<cd> a((size_t)L * L);
+          for (int e = t; e < E; e += T) {
+            std::fill(a.begin(), a.end(), cd(0, 0));
+            for (int r = 0; r < N; ++r)
+              for (int c = 0; c < N; ++c) a[(size_t)r * L + c] = psf[(size_t)e * NN + (size_t)r * N + c];
+            host_fft2d(a, L, 0, N, false);
+            float2 *se = st.data() + (size_t)e * KH * L;
+            for (int k = 0; k < KH; ++k)
+              for (int r = 0; r < L; ++r)
+                se[(size_t)k * L + r] = make_float2((float)(a[(size_t)r * L + k].real() * sc), (float)(a[(size_t)r * L + k].imag() * sc));
+          }
+        });
+      for (auto &th : pool) th.join();
+      TRY(h2d(j, j->St, st.data(), st.size() * sizeof(float2)));
+    }
   }
   for (int k = 0; k < LC_P_COUNT; ++k) j->free_mask[k] = 0;
 #undef TRY
@@ -583,35 +618,6 @@ int lc_joint_set_loss(lc_joint *j, const lc_joint_loss_cfg *cfg, const float *W)
 }
 
 namespace {
-// one launch of the auxiliary epoch kernel: mode 4 (scene -> spectrum) or mode 3 (scene (*) spectrum -> image)
-int launch_aux(lc_joint *j, int mode, const float *scene, const float2 *St_in, float2 *St_out, float *conv_out) {
-  const JointVariant *v = j->v;
-  JointArgs A;
-  std::memset(&A, 0, sizeof(A));
-  A.E = j->E;
-  A.M = 0;
-  A.mode = mode;
-  A.St = St_in;
-  A.spec = j->spec;
-  A.twid = j->twid;
-  A.a = j->par[LC_P_A];
-  A.cx = j->par[LC_P_CX];
-  A.cy = j->par[LC_P_CY];
-  A.dx = j->par[LC_P_DX];
-  A.dy = j->par[LC_P_DY];
-  A.alpha = j->par[LC_P_ALPHA];
-  A.h = j->par[LC_P_H];
-  A.mean = j->par[LC_P_MEAN];
-  A.tabs = j->tabs;
-  A.scene_in = scene;
-  A.St_out = St_out;
-  A.conv_out = conv_out;
-  LC_HIP(j->ctx, hipFuncSetAttribute((const void *)v->ek_aux, hipFuncAttributeMaxDynamicSharedMemorySize, v->e_lds));
-  hipLaunchKernelGGL(v->ek_aux, dim3(j->E), dim3(v->e_thr), v->e_lds, j->ctx->stream, A);
-  LC_HIP(j->ctx, hipGetLastError());
-  return LC_OK;
-}
-
 int propagate_noise_device(lc_joint *j) {
   const int N = j->N, ss = j->ss, E = j->E, J = j->J, c = (N - 1) / 2, shift = ss * (j->n / 2) - c;
   const size_t NN = (size_t)N * N, ENN = (size_t)E * NN;
