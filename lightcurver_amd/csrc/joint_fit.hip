@@ -53,7 +53,8 @@ struct lc_joint {
   hipStream_t streamB = nullptr;      // the h regulariser runs here, concurrently with the epoch kernel
   hipEvent_t evReg = nullptr, evUpd = nullptr;
   bool reg_pending = false;
-  bool in_device_loop = false, fuse_pending = false;  // lc_joint_run_adabelief: scalar reduction fused into the update
+  bool in_device_loop = false, fuse_pending = false;
+  bool pts_pending = false;  // the point-source starlet term of this iteration was evaluated by the stream-B launch  // lc_joint_run_adabelief: scalar reduction fused into the update
   std::vector<float> h_sigma2, h_psf;  // host copies for the one-time noise propagation
   std::vector<void *> allocs;
 };
@@ -344,7 +345,8 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   // the multi-block update serves the large grids always, and the LDS variants whenever nothing is left for one
   // workgroup to do alone (h regulariser already evaluated on the second stream, no point-source starlet term):
   // N^2 / 256 blocks finish the AdaBelief sweep of h in a fraction of the single-workgroup latency
-  if (!v->uk || (A.lam_pts == 0.f && (reg_mode == 2 || !rh))) {
+  A.pts_early = (reg_mode == 1) ? (j->pts_pending ? 1 : 0) : ((j->pts_pending && mode == 1) ? 2 : 0);
+  if (!v->uk || ((A.lam_pts == 0.f || A.pts_early == 2) && (reg_mode == 2 || !rh))) {
     const int NN = j->N * j->N;
     int nblk = (NN + kGmThreads - 1) / kGmThreads;
     if (j->fuse_pending && mode == 1) {
@@ -463,7 +465,7 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   TRY(dmalloc(j, &j->qscr, (size_t)(j->J + 1) * NN));
   TRY(dmalloc(j, &j->out_loss, 4));
   TRY(dmalloc(j, &j->greg, NN));
-  TRY(dmalloc(j, &j->regs, 4));
+  TRY(dmalloc(j, &j->regs, 4 + 3 * kMaxSources + 4));
   if (v->gspec) TRY(dmalloc(j, &j->spec, (size_t)E * N * KH));
   if (!v->uk) {
     const size_t nb = (NN + kGmThreads - 1) / kGmThreads;
@@ -707,7 +709,10 @@ int lc_joint_propagate_noise(lc_joint *j, float *W_out) {
 int lc_joint_step_local(lc_joint *j) {
   if (!j) return LC_ERR_INVALID;
   j->reg_pending = false;
-  if (reg_h_on(j)) {
+  // inside lc_joint_run_adabelief (one GPU: the mean fluxes are all local) the point-source starlet term, which depends
+  // on the current a, c_x, c_y only, is evaluated with the background regulariser on the second stream
+  j->pts_pending = j->in_device_loop && j->v->uk && j->cfg.lam_pts_source != 0.f && j->M > 0;
+  if (reg_h_on(j) || j->pts_pending) {
     // starlet l1 + positivity of h depend on h alone: evaluate them on a second stream while the epoch
     // kernel (which leaves CUs idle whenever E < 256) runs; the update kernel joins the two
     LC_HIP(j->ctx, hipStreamWaitEvent(j->streamB, j->evUpd, 0));
@@ -721,7 +726,7 @@ int lc_joint_step_local(lc_joint *j) {
   // inside lc_joint_run_adabelief, with the background fixed, only scalars are reduced: the multi-block update
   // kernel does that itself (one launch less per iteration)
   j->fuse_pending = j->in_device_loop && need == 0 && !j->free_mask[LC_P_H] &&
-                    (!j->v->uk || (j->cfg.lam_pts_source == 0.f && (j->reg_pending || !reg_h_on(j))));
+                    (!j->v->uk || ((j->cfg.lam_pts_source == 0.f || j->pts_pending) && (j->reg_pending || !reg_h_on(j))));
   if (j->fuse_pending) return LC_OK;
   return launch_reduce(j, need);
 }
@@ -749,6 +754,7 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
   j->reg_pending = false;
   j->fuse_pending = false;
+  j->pts_pending = false;
   j->iters_done += 1;
   return LC_OK;
 }

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
   }
   const float Etot = A.shared[NN + 4 * M + 1];
   const bool use_reg = (A.reg_mode == 2);
+  const bool pts = (A.lam_pts != 0.f && A.pts_early == 2);  // point-source starlet term evaluated by the reg launch
   if (tid == 0) {
     sc[0] = A.lr;
     sc[1] = A.bc1;
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
       const float sd = sqrtf(var);
       if (sd > 0.f) ga += A.lam_fu * (av - mean) / (Etot * sd);
     }
+    if (pts) ga += A.regs[4 + i * 3] / Etot;
     if (A.mode == 0) {
       if (A.gout[LC_P_A]) A.gout[LC_P_A][idx] = ga;
     } else if (A.free_mask[LC_P_A]) {
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
     const int which = (tid < M) ? LC_P_CX : LC_P_CY, i = tid % M;
     float gv = A.shared[NN + (which == LC_P_CX ? 0 : M) + i];
     float cv = A.par[which][i];
+    if (pts) gv += (A.shared[NN + 2 * M + i] / Etot) * A.ss * A.regs[4 + i * 3 + (which == LC_P_CX ? 1 : 2)];
     if (A.n_prior > 0) {
       const float mu = (which == LC_P_CX) ? A.prior_cx_mean[i] : A.prior_cy_mean[i];
       const float sg = (which == LC_P_CX) ? A.prior_cx_sigma[i] : A.prior_cy_sigma[i];
@@ -221,6 +224,7 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
     double loss = 0.5 * (double)A.shared[NN + 4 * M];
     for (int w = 0; w < kGmThreads / 64; ++w) loss += red[w];
     if (use_reg) loss += (double)A.regs[0] + (double)A.regs[1];
+    if (pts) loss += (double)A.regs[2];
     if (A.lam_fu != 0.f && Etot > 1.f)
       for (int i = 0; i < M; ++i) {
         const double mean = A.shared[NN + 2 * M + i] / Etot;

@@ -732,6 +732,11 @@ struct JointUpdArgs {
   const float *prior_cx_mean, *prior_cx_sigma, *prior_cy_mean, *prior_cy_sigma;
   lc_adabelief_cfg ab;
   float lr, bc1, bc2;  // learning rate and bias corrections of iteration t, evaluated on the host (adabelief_schedule)
+  // point-source starlet term evaluated ahead of the update, next to the background regulariser (it depends on the
+  // current a, c_x, c_y only): pts_early = 1 in the reg_mode 1 launch computes it (mean fluxes from par[A] itself) and
+  // leaves regs[2] = value, regs[4 + 3 i ..] = d/d abar_i, d/dX_i / abar_i, d/dY_i / abar_i;  pts_early = 2 in the
+  // update launch consumes them instead of evaluating the term
+  int pts_early;
 };
 
 __device__ __forceinline__ float adabelief_step(float &p, float &m, float &s, float g, float lr, float bc1, float bc2,
@@ -798,37 +803,29 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
       greg_own[p] += (hp[p] < 0.f) ? -A.lam_pos : 0.f;
     }
   }
-  if (A.reg_mode == 1) {  // regulariser-only launch: publish and leave
-#pragma unroll
-    for (int q = 0; q < PX / 4; ++q)
-      *(float4 *)(A.greg + pix + 4 * q) = make_float4(greg_own[4 * q], greg_own[4 * q + 1], greg_own[4 * q + 2], greg_own[4 * q + 3]);
-    const float s1 = wave_sum(l1), s2 = wave_sum(pos);
-    if (lane == 0) {
-      red[wid * 2] = s1;
-      red[wid * 2 + 1] = s2;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      float t1 = 0.f, t2 = 0.f;
-      for (int w = 0; w < NWV; ++w) {
-        t1 += red[w * 2];
-        t2 += red[w * 2 + 1];
-      }
-      A.regs[0] = t1;
-      A.regs[1] = t2;
-    }
-    return;
-  }
   // ---- regularization_strength_pts_source: lam * sum W_0 |starlet_0(Pbar)|, Pbar = sum_i mean_e(a_i) G(c_i)
   //      (the point-source channel at the target resolution in the reference frame, DESIGN.md SPEC) ----
   __shared__ float pts_red[NWV * 3 * kMaxSources + 3 * kMaxSources];
-  if (A.lam_pts != 0.f) {
+  __shared__ float pts_abar[kMaxSources];
+  __shared__ float pts_red3[NWV];
+  float pts_l1_own = 0.f;
+  const bool pts_here = A.lam_pts != 0.f && A.pts_early != 2 && (A.reg_mode != 1 || A.pts_early == 1);
+  if (pts_here && A.reg_mode == 1) {  // mean fluxes straight from the parameters: one wave per source
+    for (int i = wid; i < M; i += NWV) {
+      float acc = 0.f;
+      for (int e2 = lane; e2 < E; e2 += 64) acc += A.par[LC_P_A][e2 * M + i];
+      acc = wave_sum(acc);
+      if (lane == 0) pts_abar[i] = acc / (float)E;
+    }
+    __syncthreads();
+  }
+  if (pts_here) {
     const float c0 = (N - 1) * 0.5f, inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm2 = 0.15915494309189535f * inv_s2;
     float pb[PX];
 #pragma unroll
     for (int p = 0; p < PX; ++p) pb[p] = 0.f;
     for (int i = 0; i < M; ++i) {
-      const float abar = A.shared[NN + 2 * M + i] / Etot;
+      const float abar = (A.reg_mode == 1) ? pts_abar[i] : A.shared[NN + 2 * M + i] / Etot;
       const float X = c0 + A.ss * A.par[LC_P_CX][i], Y = c0 + A.ss * A.par[LC_P_CY][i];
       const float ty = (float)pu - Y;
 #pragma unroll
@@ -840,7 +837,8 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
     float zp[PX], l1p = 0.f;
     __syncthreads();  // the background starlet above is done with the LDS buffers
     starlet_l1_grad<N, PX, 1>(pb, A.W, A.norms, A.qscr, 0.f, A.lam_pts, lds, tid, l1p, zp);
-    pos += l1p;  // joins the loss through the same reduction
+    if (A.reg_mode != 1) pos += l1p;  // joins the loss through the same reduction
+    pts_l1_own = l1p;
     for (int i = 0; i < M; ++i) {
       const float X = c0 + A.ss * A.par[LC_P_CX][i], Y = c0 + A.ss * A.par[LC_P_CY][i];
       const float ty = (float)pu - Y;
@@ -870,7 +868,34 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
       pts_red[NWV * 3 * kMaxSources + i * 3 + q] = acc;  // d/d abar_i, d/dX_i / abar_i, d/dY_i / abar_i
     }
   }
-  const float *ptsg = pts_red + NWV * 3 * kMaxSources;
+  if (A.reg_mode == 1) {  // regulariser-only launch: publish and leave
+#pragma unroll
+    for (int q = 0; q < PX / 4; ++q)
+      *(float4 *)(A.greg + pix + 4 * q) = make_float4(greg_own[4 * q], greg_own[4 * q + 1], greg_own[4 * q + 2], greg_own[4 * q + 3]);
+    const float s1 = wave_sum(l1), s2 = wave_sum(pos), s3 = wave_sum(pts_l1_own);
+    if (lane == 0) {
+      red[wid * 2] = s1;
+      red[wid * 2 + 1] = s2;
+      pts_red3[wid] = s3;
+    }
+    __syncthreads();
+    float pts_l1_total = 0.f;
+    if (tid == 0) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int w = 0; w < NWV; ++w) {
+        t1 += red[w * 2];
+        t2 += red[w * 2 + 1];
+        pts_l1_total += pts_red3[w];
+      }
+      A.regs[0] = t1;
+      A.regs[1] = t2;
+      A.regs[2] = pts_l1_total;
+    }
+    if (pts_here && tid < 3 * M) A.regs[4 + tid] = pts_red[NWV * 3 * kMaxSources + tid];
+    return;
+  }
+  const float *ptsg = (A.pts_early == 2) ? (A.regs + 4) : (pts_red + NWV * 3 * kMaxSources);
+  if (A.pts_early == 2 && tid == 0) pos += A.regs[2];
   {
     const float s1 = wave_sum(l1), s2 = wave_sum(pos);
     if (lane == 0) {

@@ -134,3 +134,38 @@ def test_adabelief_trajectory(ctx, n, ss, with_h):
     if with_h:
         dh = np.abs(got['h'] - pf['h'].numpy())
         assert dh.max() < 0.05 * T * 1e-3 and np.median(dh) < 1e-5
+
+
+@pytest.mark.parametrize('n,with_h', [(16, True), (32, True), (16, False)])
+def test_adabelief_trajectory_with_point_source_starlet_term(ctx, n, with_h):
+    """regularization_strength_pts_source is on by default in the reference's ROI fit (roi_modelling.py:311).  Inside
+    lc_joint_run_adabelief the term is evaluated ahead of the update, on the second stream with the background
+    regulariser; the trajectory must still follow the oracle, and a step-by-step drive of the same object (the
+    sharded-fit entry points, where the term is evaluated inside the update) must give the same parameters."""
+    E, M, T, ss = 4, 2, 20, 2
+    ds, j, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 140 + n, with_h=with_h)
+    W = om.propagate_noise_deconv(sig2, psf, ss)
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'mean'] + (['h'] if with_h else [])
+    kw = dict(W=W.numpy(), lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_pts_source=0.3, lam_flux_uniformity=0.2)
+    j.set_loss(**kw)
+    j.set_free(free)
+    p0 = j.get_params()
+    j.run_adabelief(T, init_learning_rate=1e-3, schedule_learning_rate=True)
+    hist = j.loss_history()
+    fn = lambda q: om.deconv_loss(q, data, sig2, psf, ss, W=W, lam_scales=1.0, lam_hf=1.0, lam_pos=10.0, lam_pts=0.3,
+                                  lam_fu=0.2)
+    pf, lh, l0 = oo.adabelief(fn, po, free, 1e-3, T, schedule=True)
+    ref = np.array([l0] + lh)
+    assert np.abs(hist - ref).max() / np.abs(ref).max() < 2e-4
+    got = j.get_params()
+    assert H.rel_err(got['a'], pf['a'].numpy()) < 2e-4
+    assert np.abs(got['c_x'] - pf['c_x'].numpy()).max() < 5e-4
+    # same object, driven step by step
+    j.set_params(**p0)
+    j.set_free(free)
+    for _ in range(T):
+        j.step_local()
+        j.step_update(init_learning_rate=1e-3, schedule_learning_rate=True)
+    got2 = j.get_params()
+    assert H.rel_err(got2['a'], got['a']) < 1e-5
+    assert np.abs(got2['c_x'] - got['c_x']).max() < 1e-5 and np.abs(got2['c_y'] - got['c_y']).max() < 1e-5

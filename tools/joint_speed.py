@@ -15,7 +15,7 @@ p = dict(ds['truth']); p['a'] = p['a'] * 0.9
 if not with_h: p['h'] = np.zeros_like(p['h'])
 j.set_params(**p)
 t0 = time.time(); W = j.propagate_noise(); print('propagate_noise', time.time() - t0)
-j.set_loss(W=W, lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0)
+j.set_loss(W=W, lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=float(os.environ.get('LCMI_PTS', '0')), lam_flux_uniformity=float(os.environ.get('LCMI_FU', '0')))
 free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'mean'] + (['h'] if with_h else [])
 j.set_free(free)
 j.run_adabelief(5, init_learning_rate=1e-4, schedule_learning_rate=False); ctx.synchronize()
