@@ -69,7 +69,8 @@ def joint_fit_secondary(ctx, iters=100):
     p['a'] = p['a'] * 0.9
     j.set_params(**p)
     W = j.propagate_noise()
-    j.set_loss(W=W, lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0)
+    # the reference's code fall-backs of the main ROI optimisation (roi_modelling.py:308-312)
+    j.set_loss(W=W, lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
     j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
     ab = dict(init_learning_rate=1e-4, schedule_learning_rate=False)
     j.run_adabelief(5, **ab)
@@ -84,7 +85,7 @@ def joint_fit_secondary(ctx, iters=100):
     flops_per = 10.0 * (2 * N) ** 2 * math.log2((2 * N) ** 2) + 40.0 * N * N  # SURVEY.md 8(d), FFT route
     rate = E * iters / (ms * 1e-3)
     j.close()
-    return {'workload': f'C4: {E} epochs x {n}x{n} ROI, {M} point sources + background, all parameters free, '
+    return {'workload': f'C4: {E} epochs x {n}x{n} ROI, {M} point sources + background, all parameters free, reference-default regularisation strengths, '
                         f'{iters} AdaBelief iterations (3 launches per iteration)',
             'cutouts_per_sec': rate, 'us_per_iteration': ms * 1e3 / iters,
             'algorithmic_bytes_per_cutout_iteration': bytes_per,
