@@ -50,6 +50,7 @@ struct lc_joint {
   float2 *St_alt = nullptr;                                                                        // [E][KH][L]
   float *psf_dev = nullptr, *psF = nullptr;  // point-source-only path: narrow PSFs [E][N*N], filter outputs [E][M][3][n*n]
   float *gm_c = nullptr, *gm_t = nullptr, *gm_n = nullptr, *gm_y = nullptr, *gm_l1 = nullptr, *gm_pos = nullptr;
+  float *gm_pts = nullptr;  // [8] mean fluxes + [blocks][8][3] partial inner products of the point-source term
   hipStream_t streamB = nullptr;      // the h regulariser runs here, concurrently with the epoch kernel
   hipEvent_t evReg = nullptr, evUpd = nullptr;
   bool reg_pending = false;
@@ -253,7 +254,7 @@ int launch_reduce(lc_joint *j, int need_h) {
 }
 
 // starlet l1 + positivity of h as multi-block kernels: -> greg, regs (same contract as reg_mode 1 of joint_update_kernel)
-int launch_reg_gm(lc_joint *j, hipStream_t stream) {
+int launch_reg_gm(lc_joint *j, hipStream_t stream, bool with_pts, bool abar_from_shared) {
   const int N = j->N, NN = N * N, J = j->J, nb = (NN + kGmThreads - 1) / kGmThreads;
   const dim3 grid(nb), block(kGmThreads);
   const float *W = j->have_W ? j->W : nullptr;
@@ -282,6 +283,20 @@ int launch_reg_gm(lc_joint *j, hipStream_t stream) {
   }
   hipLaunchKernelGGL(gm_positivity_kernel, grid, block, 0, stream, NN, j->par[LC_P_H], j->cfg.lam_positivity, j->greg, j->gm_pos);
   hipLaunchKernelGGL(gm_regs_kernel, dim3(1), dim3(64), 0, stream, l1_on ? J * nb : 0, nb, j->gm_l1, j->gm_pos, j->regs);
+  if (with_pts) {
+    // point-source starlet term: scale 0 only, on Pbar (the work buffers of the chain above are free again)
+    float *abar = j->gm_pts, *part = j->gm_pts + 8, *qp = j->qscr + (size_t)J * NN, *l1p = j->gm_l1 + (size_t)J * nb;
+    hipLaunchKernelGGL(gm_abar_kernel, dim3(1), dim3(256), 0, stream, j->E, j->M, NN, j->par[LC_P_A], j->shared,
+                       abar_from_shared ? 1 : 0, abar);
+    hipLaunchKernelGGL(gm_pbar_kernel, grid, block, 0, stream, N, j->ss, j->M, abar, j->par[LC_P_CX], j->par[LC_P_CY], j->gm_c);
+    hipLaunchKernelGGL(gm_pass_kernel, grid, block, 0, stream, N, 1, 1, j->gm_c, j->gm_t);
+    hipLaunchKernelGGL(gm_pass_kernel, grid, block, 0, stream, N, 1, 0, j->gm_t, j->gm_n);
+    hipLaunchKernelGGL(gm_coef_kernel, grid, block, 0, stream, N, j->gm_n, j->gm_c, W, j->norms, j->cfg.lam_pts_source, qp, l1p);
+    hipLaunchKernelGGL(gm_pass_adjoint_kernel, grid, block, 0, stream, N, 1, 0, qp, (const float *)nullptr, j->gm_t);
+    hipLaunchKernelGGL(gm_pass_adjoint_kernel, grid, block, 0, stream, N, 1, 1, j->gm_t, (const float *)nullptr, j->gm_y);
+    hipLaunchKernelGGL(gm_pts_inner_kernel, grid, block, 0, stream, N, j->ss, j->M, qp, j->gm_y, j->par[LC_P_CX], j->par[LC_P_CY], part);
+    hipLaunchKernelGGL(gm_pts_final_kernel, dim3(1), dim3(64), 0, stream, nb, j->M, part, l1p, j->regs);
+  }
   LC_HIP(j->ctx, hipGetLastError());
   return LC_OK;
 }
@@ -290,12 +305,17 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
                   int reg_mode = 0, hipStream_t stream = nullptr) {
   if (!stream) stream = j->ctx->stream;
   const JointVariant *v = j->v;
+  bool gm_pts_done = false;
   if (!v->uk) {
-    if (reg_mode == 1) return launch_reg_gm(j, stream);
-    if (reg_mode == 0 && reg_h_on(j)) {
-      int rc = launch_reg_gm(j, stream);
+    const bool want_pts = j->cfg.lam_pts_source != 0.f && j->M > 0;
+    if (reg_mode == 1) return launch_reg_gm(j, stream, j->pts_pending, false);
+    if (reg_mode == 2) gm_pts_done = j->pts_pending;  // evaluated by the stream-B chain of this iteration
+    if ((reg_mode == 0 && (reg_h_on(j) || want_pts)) || (reg_mode == 2 && want_pts && !gm_pts_done)) {
+      // inline (gradient evaluations, step-by-step / sharded drive): the mean fluxes come from the reduced block
+      int rc = launch_reg_gm(j, stream, want_pts, true);
       if (rc) return rc;
       reg_mode = 2;
+      gm_pts_done = want_pts;
     }
   }
   JointUpdArgs A;
@@ -345,7 +365,7 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   // the multi-block update serves the large grids always, and the LDS variants whenever nothing is left for one
   // workgroup to do alone (h regulariser already evaluated on the second stream, no point-source starlet term):
   // N^2 / 256 blocks finish the AdaBelief sweep of h in a fraction of the single-workgroup latency
-  A.pts_early = (reg_mode == 1) ? (j->pts_pending ? 1 : 0) : ((j->pts_pending && mode == 1) ? 2 : 0);
+  A.pts_early = (reg_mode == 1) ? (j->pts_pending ? 1 : 0) : (((j->pts_pending && mode == 1) || gm_pts_done) ? 2 : 0);
   if (!v->uk || ((A.lam_pts == 0.f || A.pts_early == 2) && (reg_mode == 2 || !rh))) {
     const int NN = j->N * j->N;
     int nblk = (NN + kGmThreads - 1) / kGmThreads;
@@ -475,6 +495,7 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
     TRY(dmalloc(j, &j->gm_y, NN));
     TRY(dmalloc(j, &j->gm_l1, (size_t)(j->J + 1) * nb));
     TRY(dmalloc(j, &j->gm_pos, nb));
+    TRY(dmalloc(j, &j->gm_pts, 8 + nb * 3 * kMaxSources));
   }
   LC_HIP(ctx, hipStreamCreate(&j->streamB));
   LC_HIP(ctx, hipEventCreateWithFlags(&j->evReg, hipEventDisableTiming));
@@ -590,8 +611,6 @@ int lc_joint_set_free(lc_joint *j, const int32_t *free_mask) {
 }
 int lc_joint_set_loss(lc_joint *j, const lc_joint_loss_cfg *cfg, const float *W) {
   if (!j || !cfg) return LC_ERR_INVALID;
-  if (!j->v->uk && cfg->lam_pts_source != 0.f)
-    LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "regularization_strength_pts_source is not available for this stamp size");
   j->cfg = *cfg;
   j->n_prior = 0;
   if (cfg->n_prior > 0) {
@@ -711,7 +730,7 @@ int lc_joint_step_local(lc_joint *j) {
   j->reg_pending = false;
   // inside lc_joint_run_adabelief (one GPU: the mean fluxes are all local) the point-source starlet term, which depends
   // on the current a, c_x, c_y only, is evaluated with the background regulariser on the second stream
-  j->pts_pending = j->in_device_loop && j->v->uk && j->cfg.lam_pts_source != 0.f && j->M > 0;
+  j->pts_pending = j->in_device_loop && j->cfg.lam_pts_source != 0.f && j->M > 0;
   if (reg_h_on(j) || j->pts_pending) {
     // starlet l1 + positivity of h depend on h alone: evaluate them on a second stream while the epoch
     // kernel (which leaves CUs idle whenever E < 256) runs; the update kernel joins the two

@@ -125,6 +125,75 @@ __global__ void gm_regs_kernel(int nparts_l1, int nblocks, const float *l1_part,
   }
 }
 
+// ---- regularization_strength_pts_source for the large grids: lam * sum W_0 |starlet_0(Pbar)|, Pbar = sum_i abar_i G(c_i) ----
+// abar[i] = mean over the epochs of a[e][i]: from the parameters themselves (one GPU) or from the reduced block
+__global__ void gm_abar_kernel(int E, int M, int NN, const float *a, const float *shared, int from_shared, float *abar) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int i = wid; i < M; i += nw) {
+    if (from_shared) {
+      if (lane == 0) abar[i] = shared[NN + 2 * M + i] / shared[NN + 4 * M + 1];
+    } else {
+      float acc = 0.f;
+      for (int e = lane; e < E; e += 64) acc += a[e * M + i];
+      acc = wave_sum_shfl(acc);
+      if (lane == 0) abar[i] = acc / (float)E;
+    }
+  }
+}
+__global__ void gm_pbar_kernel(int N, int ss, int M, const float *abar, const float *cx, const float *cy, float *pbar) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N * N) return;
+  const float c0 = (N - 1) * 0.5f, inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm2 = 0.15915494309189535f * inv_s2;
+  const int u = k / N, v = k % N;
+  float acc = 0.f;
+  for (int i = 0; i < M; ++i) {
+    const float tx = (float)v - (c0 + ss * cx[i]), ty = (float)u - (c0 + ss * cy[i]);
+    acc = fmaf(abar[i] * nrm2, expf(-0.5f * (tx * tx + ty * ty) * inv_s2), acc);
+  }
+  pbar[k] = acc;
+}
+// z = q - adj (adjoint of the scale-0 smoothing applied to q); per-block partial inner products with G_i and its
+// position derivatives: part[block][i][3] = sum z G_i, sum z G_i tx / sigma^2, sum z G_i ty / sigma^2
+__global__ void gm_pts_inner_kernel(int N, int ss, int M, const float *q, const float *adj, const float *cx, const float *cy,
+                                    float *part) {
+  __shared__ float red[kGmThreads / 64][kMaxSources * 3];
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const float c0 = (N - 1) * 0.5f, inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm2 = 0.15915494309189535f * inv_s2;
+  const bool in = k < N * N;
+  const float z = in ? q[k] - adj[k] : 0.f;
+  const int u = in ? k / N : 0, v = in ? k % N : 0;
+  for (int i = 0; i < M; ++i) {
+    const float tx = (float)v - (c0 + ss * cx[i]), ty = (float)u - (c0 + ss * cy[i]);
+    const float gq = z * nrm2 * expf(-0.5f * (tx * tx + ty * ty) * inv_s2);
+    const float sa = wave_sum_shfl(gq), sx = wave_sum_shfl(gq * tx * inv_s2), sy = wave_sum_shfl(gq * ty * inv_s2);
+    if (lane == 0) {
+      red[wid][i * 3] = sa;
+      red[wid][i * 3 + 1] = sx;
+      red[wid][i * 3 + 2] = sy;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 3 * M) {
+    float acc = 0.f;
+    for (int w = 0; w < kGmThreads / 64; ++w) acc += red[w][threadIdx.x];
+    part[(size_t)blockIdx.x * 3 * kMaxSources + threadIdx.x] = acc;
+  }
+}
+// ordered final sums -> regs[2] = value of the term, regs[4 + 3 i + q] = the three inner products of source i
+__global__ void gm_pts_final_kernel(int nblocks, int M, const float *part, const float *l1_part, float *regs) {
+  const int t = threadIdx.x;
+  if (t < 3 * M) {
+    float acc = 0.f;
+    for (int b = 0; b < nblocks; ++b) acc += part[(size_t)b * 3 * kMaxSources + t];
+    regs[4 + t] = acc;
+  }
+  if (t == 63) {
+    float acc = 0.f;
+    for (int b = 0; b < nblocks; ++b) acc += l1_part[b];
+    regs[2] = acc;
+  }
+}
+
 // AdaBelief on h (every block) and on the small blocks + loss (block 0).  A.greg / A.regs hold the h regulariser.
 __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArgs A, int N) {
   __shared__ float sc[8];

@@ -54,10 +54,31 @@ def test_forced_global_loss_and_gradients(ctx, global_kernels, E, M, n, alpha):
     assert H.rel_err(grads2['h'], g2['h'].numpy()) < 1e-4
 
 
-def test_forced_global_pts_source_is_refused(ctx, global_kernels):
-    ds, j, po, data, sig2, psf = _setup(ctx, 2, 1, 16, 2, 9)
-    with pytest.raises(RuntimeError):
-        j.set_loss(lam_pts_source=0.5)
+@pytest.mark.parametrize('n', [16, 32])
+def test_forced_global_point_source_starlet_term(ctx, global_kernels, n):
+    """regularization_strength_pts_source through the multi-block kernels (what 128 x 128 ROIs use; the reference's
+    default ROI fit has the term on, roi_modelling.py:311): loss and gradients, then a trajectory, against the oracle."""
+    E, M, ss, T = 3, 2, 2, 15
+    ds, j, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 600 + n)
+    W = om.propagate_noise_deconv(sig2, psf, ss)
+    kw = dict(lam_scales=1.0, lam_hf=1.0, lam_pos=10.0, lam_pts=0.3, lam_fu=0.2)
+    j.set_loss(W=W.numpy(), lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_pts_source=0.3, lam_flux_uniformity=0.2)
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean']
+    j.set_free(free)
+    fn = lambda q: om.deconv_loss(q, data, sig2, psf, ss, W=W, **kw)
+    L, g = oo.value_and_grad(fn, po, free)
+    loss, grads = j.loss_grad(free)
+    assert abs(loss - float(L)) / abs(float(L)) < 3e-5
+    for k in free:
+        assert H.rel_err(grads[k], g[k].numpy()) < 1e-4, k
+    j.run_adabelief(T, init_learning_rate=1e-3, schedule_learning_rate=True)
+    hist = j.loss_history()
+    pf, lh, l0 = oo.adabelief(fn, po, free, 1e-3, T, schedule=True)
+    ref = np.array([l0] + lh)
+    assert np.abs(hist - ref).max() / np.abs(ref).max() < 2e-4
+    got = j.get_params()
+    assert H.rel_err(got['a'], pf['a'].numpy()) < 2e-4
+    assert np.abs(got['c_x'] - pf['c_x'].numpy()).max() < 5e-4
 
 
 @pytest.mark.parametrize('n', [16, 32])
@@ -86,8 +107,8 @@ def test_n128_loss_gradients_and_steps(ctx):
     AdaBelief iterations against the oracle."""
     E, M, n, ss, T = 2, 2, 128, 2, 3
     ds, j, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 777, alpha_sigma=0.2)
-    lam = dict(lam_scales=1.0, lam_hf=1.0, lam_pos=10.0, lam_pos_ps=5.0)
-    j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_positivity_ps=5.0)
+    lam = dict(lam_scales=1.0, lam_hf=1.0, lam_pos=10.0, lam_pos_ps=5.0, lam_pts=0.05)
+    j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_positivity_ps=5.0, lam_pts_source=0.05)
     free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean']
     j.set_free(free)
     model, chi2_e = j.model()
