@@ -84,3 +84,34 @@ def test_psf_fit_end_results(ctx):
         assert H.rel_err(stars[f][:, 0], pf['a'].numpy()) < 1e-4                   # north-star level
         assert np.abs(stars[f][:, 1] - pf['x0'].numpy()).max() < 1e-3 and np.abs(stars[f][:, 2] - pf['y0'].numpy()).max() < 1e-3
         assert abs(res['chi2'][f] - chi2_o) / chi2_o < 5e-3
+
+
+def test_star_photometry_end_results_meet_the_north_star_tolerances(ctx):
+    """The reference's default star photometry (point source only, star_photometry.py:74-122: learning rate 1e-3 with
+    the schedule): a smooth problem in a handful of parameters per epoch.  After 1000 iterations fluxes and shifts agree
+    with the oracle within 1e-4 relative and chi2 within 1e-5."""
+    from lightcurver_amd.joint import JointFit
+    E, M, n, ss, T = 6, 1, 16, 2, 1000
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=2026, with_background=False)
+    p = {k: np.array(v, dtype=np.float64) for k, v in ds['truth'].items()}
+    rng = np.random.default_rng(3)
+    p['a'] = p['a'] * rng.uniform(0.8, 1.2, p['a'].shape)
+    p['h'] = np.zeros_like(p['h'])
+    data, sig2, psf = om.T(ds['data']), om.T(ds['noisemap']) ** 2, om.T(ds['psf'])
+    j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
+    j.set_params(**p)
+    j.set_loss()
+    free = ['a', 'dx', 'dy', 'mean']
+    j.set_free(free)
+    j.run_adabelief(T, init_learning_rate=1e-3, schedule_learning_rate=True)
+    got = j.get_params()
+    model, chi2_e = j.model()
+    po = {k: om.T(v) for k, v in p.items()}
+    pf, lh, l0 = oo.adabelief(lambda q: om.deconv_loss(q, data, sig2, psf, ss), po, free, 1e-3, T, schedule=True)
+    mo = om.deconv_model(pf, psf, ss, n)
+    chi2_o = (((data - mo) ** 2) / sig2).sum().item()
+    print('star: flux', H.rel_err(got['a'], pf['a'].numpy()), 'dx', np.abs(got['dx'] - pf['dx'].numpy()).max(), 'dy',
+          np.abs(got['dy'] - pf['dy'].numpy()).max(), 'chi2', abs(chi2_e.sum() - chi2_o) / chi2_o)
+    assert H.rel_err(got['a'], pf['a'].numpy()) < 1e-4
+    assert np.abs(got['dx'] - pf['dx'].numpy()).max() < 1e-4 and np.abs(got['dy'] - pf['dy'].numpy()).max() < 1e-4
+    assert abs(chi2_e.sum() - chi2_o) / chi2_o < 1e-5
