@@ -15,6 +15,8 @@ __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) {  // a * conj(b
 
 // ---- quarter-wave register FFT ------------------------------------------------------------------------
 // One length-L transform per group of 16 lanes (four per wave, side by side), data in registers:
+// (L = 16 * N2 with N2 = 2^m or 3 * 2^m: 32, 48, 96, 192, 384 ... -- the smallest alias-free length of an N-point 'same'
+//  convolution is 3N/2, so the factor 3 saves a quarter of the work of the next power of two)
 //   "stride" layout : lane n1 (0..15), register n2 (0..L/16-1) holds sample  n = n1 + 16 n2
 //   "block"  layout : lane l,          register k2              holds bin     k = k2 + (L/16) * bitrev4(l)
 // forward  = in-lane FFT over n2, twiddle W_L^(n1 k2), 16-point decimation-in-frequency FFT across the lanes
@@ -60,6 +62,58 @@ __device__ __forceinline__ void inlane_fft(float2 (&x)[N2]) {
         x[i] = make_float2(a.x + b.x, a.y + b.y);
         x[i + h] = make_float2(a.x - b.x, a.y - b.y);
       }
+    }
+  }
+}
+// exp(-2 pi i m / 24), m in [0, 24): the twiddles of the radix-3 level for lengths 3, 6, 12, 24 (literals for compile-time m)
+__device__ __forceinline__ float2 w24(int m) {
+  constexpr float c[7] = {1.f, 0.9659258262890683f, 0.8660254037844387f, 0.7071067811865476f, 0.5f, 0.25881904510252074f, 0.f};
+  // cos(pi m / 12) and sin(pi m / 12) from the first quadrant
+  const int q = m / 6, r = m % 6;  // quadrant, position inside it
+  const float cr = c[r], sr = c[6 - r];
+  float co, si;
+  if (q == 0) { co = cr; si = sr; }
+  else if (q == 1) { co = -sr; si = cr; }
+  else if (q == 2) { co = -cr; si = -sr; }
+  else { co = sr; si = -cr; }
+  return make_float2(co, -si);
+}
+// In-lane FFT of N2 = 2^m or 3 * 2^m points (natural order in and out).  The factor 3 is taken by one decimation-in-time
+// level on top of three power-of-two transforms: X[k + P q] = sum_r W3^(r q) W_N2^(r k) FFT_P(x[3 m + r])[k].
+template <int N2, bool INV>
+__device__ __forceinline__ void inlane_fft_any(float2 (&x)[N2]) {
+  if constexpr ((N2 & (N2 - 1)) == 0) {
+    inlane_fft<N2, INV>(x);
+  } else {
+    static_assert(N2 % 3 == 0 && ((N2 / 3) & (N2 / 3 - 1)) == 0 && 24 % N2 == 0, "length 3, 6, 12 or 24");
+    constexpr int P = N2 / 3;
+    float2 y0[P], y1[P], y2[P];
+#pragma unroll
+    for (int m = 0; m < P; ++m) {
+      y0[m] = x[3 * m];
+      y1[m] = x[3 * m + 1];
+      y2[m] = x[3 * m + 2];
+    }
+    inlane_fft<P, INV>(y0);
+    inlane_fft<P, INV>(y1);
+    inlane_fft<P, INV>(y2);
+    constexpr float kS3 = 0.8660254037844386f;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      float2 w1 = w24(k * (24 / N2)), w2 = w24(2 * k * (24 / N2));
+      if (INV) {
+        w1.y = -w1.y;
+        w2.y = -w2.y;
+      }
+      const float2 t1 = cmul(y1[k], w1), t2 = cmul(y2[k], w2);
+      const float2 sm = make_float2(t1.x + t2.x, t1.y + t2.y), df = make_float2(t1.x - t2.x, t1.y - t2.y);
+      const float2 a0 = y0[k];
+      const float2 mid = make_float2(fmaf(-0.5f, sm.x, a0.x), fmaf(-0.5f, sm.y, a0.y));
+      // forward: X1 = mid - i c df, X2 = mid + i c df;  inverse: the conjugate roots
+      const float2 rot = INV ? make_float2(-kS3 * df.y, kS3 * df.x) : make_float2(kS3 * df.y, -kS3 * df.x);
+      x[k] = make_float2(a0.x + sm.x, a0.y + sm.y);
+      x[k + P] = make_float2(mid.x + rot.x, mid.y + rot.y);
+      x[k + 2 * P] = make_float2(mid.x - rot.x, mid.y - rot.y);
     }
   }
 }
@@ -121,8 +175,8 @@ __device__ __forceinline__ void dit_stage_inv(float2 (&x)[L / 16], int l16, cons
 template <int L>
 __device__ __forceinline__ void quarter_fft_fwd(float2 (&x)[L / 16], int l16, const float2 *tw) {
   constexpr int N2 = L / 16;
-  if constexpr (L >= 512) LC_LAUNDER(l16);  // keep the 2 * N2 twiddle registers from being hoisted out of the caller's loops
-  inlane_fft<N2, false>(x);
+  if constexpr (N2 >= 24) LC_LAUNDER(l16);  // keep the 2 * N2 twiddle registers from being hoisted out of the caller's loops
+  inlane_fft_any<N2, false>(x);
 #pragma unroll
   for (int k2 = 1; k2 < N2; ++k2) x[k2] = cmul(x[k2], tw[l16 * k2]);
   dif_stage<L, 8>(x, l16, tw);
@@ -133,7 +187,7 @@ __device__ __forceinline__ void quarter_fft_fwd(float2 (&x)[L / 16], int l16, co
 template <int L>
 __device__ __forceinline__ void quarter_fft_inv(float2 (&x)[L / 16], int l16, const float2 *tw) {
   constexpr int N2 = L / 16;
-  if constexpr (L >= 512) LC_LAUNDER(l16);
+  if constexpr (N2 >= 24) LC_LAUNDER(l16);
   dit_stage_inv<L, 1>(x, l16, tw);
   dit_stage_inv<L, 2>(x, l16, tw);
   dit_stage_inv<L, 4>(x, l16, tw);
@@ -144,7 +198,7 @@ __device__ __forceinline__ void quarter_fft_inv(float2 (&x)[L / 16], int l16, co
     w.y = -w.y;
     x[k2] = cmul(x[k2], w);
   }
-  inlane_fft<N2, true>(x);
+  inlane_fft_any<N2, true>(x);
 }
 
 }  // namespace lc

@@ -81,7 +81,7 @@ struct JointCfg {
   static constexpr int OFF_WS = OFF_SPEC + SZ_SPEC;
   // linear row buffer(s) for the data-space step: one per quarter-wave when LDS allows (N <= 64), else one per
   // wave that the four quarters use in turn
-  static constexpr bool WSQ = (N <= 64);
+  static constexpr bool WSQ = (N <= 128);
   static constexpr int SZ_WS = NW * (WSQ ? 4 : 1) * L;
   static constexpr int OFF_TW = OFF_WS + SZ_WS;
   static constexpr int SZ_TW = L;
@@ -225,13 +225,13 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       };
       x[0] = one(x[0], shfl2(x[0], lane_neg), 0);
 #pragma unroll
-      for (int k2 = 1; k2 < N2 / 2; ++k2) {
+      for (int k2 = 1; 2 * k2 < N2; ++k2) {
         const float2 za = x[k2], zb = x[N2 - k2];
         const float2 ca = shfl2(zb, lane_mirror), cb = shfl2(za, lane_mirror);  // partners of za and of zb
         x[k2] = one(za, ca, k2);
         x[N2 - k2] = one(zb, cb, N2 - k2);
       }
-      x[N2 / 2] = one(x[N2 / 2], shfl2(x[N2 / 2], lane_mirror), N2 / 2);
+      if constexpr (N2 % 2 == 0) x[N2 / 2] = one(x[N2 / 2], shfl2(x[N2 / 2], lane_mirror), N2 / 2);
     } else {
 #pragma unroll
       for (int k2 = 0; k2 < N2; ++k2) x[k2] = conj ? cmul_conj(x[k2], sv[k2]) : cmul(x[k2], sv[k2]);

@@ -44,6 +44,19 @@ inline const std::vector<cd> &host_twiddles(int L) {
 }
 
 inline void host_fft1d(cd *x, int L, bool inv) {
+  if (L & (L - 1)) {  // not a power of two (the device uses 3 * 2^m lengths too): plain DFT, cross-check paths only
+    std::vector<cd> y(L);
+    for (int k = 0; k < L; ++k) {
+      cd acc(0, 0);
+      for (int n = 0; n < L; ++n) {
+        const double ang = (inv ? 2.0 : -2.0) * M_PI * (double)(((long long)k * n) % L) / L;
+        acc += x[n] * cd(std::cos(ang), std::sin(ang));
+      }
+      y[k] = acc;
+    }
+    for (int k = 0; k < L; ++k) x[k] = y[k];
+    return;
+  }
   for (int i = 1, j = 0; i < L; ++i) {
     int bit = L >> 1;
     for (; j & bit; bit >>= 1) j ^= bit;
