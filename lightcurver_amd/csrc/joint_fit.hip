@@ -106,7 +106,7 @@ const JointVariant *find_jv(int n, int ss) {
       // FFT length L = 16 * N2, the smallest of 2^m and 3 * 2^m that keeps the 'same' window alias free (>= 3N/2)
       make_jv<16, 1, 32, 4, 8>(),     // n = 16, ss = 1 (reference test fixture)
       make_jv<32, 2, 48, 4, 16>(),    // n = 16, ss = 2
-      make_jv<48, 2, 96, 4, 16>(),    // n = 24 (default stamp_size_stars)
+      make_jv<48, 2, 96, 4, 8>(),     // n = 24 (default stamp_size_stars)
       make_jv<64, 2, 96, 8, 16>(),    // n = 32 (default stamp_size_ROI)
       make_jv<128, 2, 192, 16, 8>(),  // n = 64 (C4)
       make_jv_gm<256, 2, 384, 8>(),   // n = 128 (C5)
