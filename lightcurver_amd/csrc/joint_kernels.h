@@ -580,12 +580,18 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     const float ixf = floorf(nsx), iyf = floorf(nsy);
     const float fxc = nsx - ixf, fyc = nsy - iyf;
     const int ixc = (int)ixf, iyc = (int)iyf;
-    const int marg = (sa == 0.f) ? min((int)ceilf(fmaxf(fabsf(sdx), fabsf(sdy))) + 2, N / 2) : N / 2;
+    // Only the outermost ring of h collects clamped (edge-replicated) samples; every other pixel of a translated
+    // epoch is served by the four-tap stencil, whose taps simply drop out where they leave the scene grid.
+    const int marg = (sa == 0.f) ? 1 : N / 2;
     const int NI = N - 2 * marg;
     for (int q = tid; q < NI * NI; q += C::NTHR) {
       const int ky = marg + q / NI, kx = marg + q % NI;
-      const float *g0 = GSl + (ky - iyc) * GST + (kx - ixc);
-      HGe[ky * N + kx] = (1.f - fyc) * ((1.f - fxc) * g0[0] + fxc * g0[-1]) + fyc * ((1.f - fxc) * g0[-GST] + fxc * g0[-GST - 1]);
+      const int r0 = ky - iyc, q0 = kx - ixc;
+      const bool ra = (r0 >= 0 && r0 < N), rb = (r0 >= 1 && r0 <= N), qa = (q0 >= 0 && q0 < N), qb = (q0 >= 1 && q0 <= N);
+      const float *g0 = GSl + r0 * GST + q0;
+      const float g00 = (ra && qa) ? g0[0] : 0.f, g01 = (ra && qb) ? g0[-1] : 0.f;
+      const float g10 = (rb && qa) ? g0[-GST] : 0.f, g11 = (rb && qb) ? g0[-GST - 1] : 0.f;
+      HGe[ky * N + kx] = (1.f - fyc) * ((1.f - fxc) * g00 + fxc * g01) + fyc * ((1.f - fxc) * g10 + fxc * g11);
     }
     const int n_rows = 2 * marg * N, n_cols = 2 * marg * NI;
     for (int q = tid; q < n_rows + n_cols; q += C::NTHR) {
