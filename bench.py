@@ -201,7 +201,8 @@ def main():
     ds = make_psf_dataset(**cfg)
     F, S, n, ss = cfg['F'], cfg['S'], cfg['n'], cfg['ss']
 
-    ctx = _lib.Context(local_rank)
+    # rehearsal of the multi-rank path on a one-GPU box: LCMI_BENCH_DEVICE=0 puts every rank on that device
+    ctx = _lib.Context(int(os.environ.get('LCMI_BENCH_DEVICE', local_rank)))
     weight = (ds['masks'] / ds['noisemap'].astype(np.float64) ** 2).astype(np.float32)
     b = PsfBatch(ds['data'], weight, ss, ctx)
     # setup (not timed): Moffat stage from the seeing guess, then noise propagation for the l1 weights
