@@ -88,10 +88,10 @@ def test_psf_fit_end_results(ctx):
 
 def test_star_photometry_end_results_meet_the_north_star_tolerances(ctx):
     """The reference's default star photometry (point source only, star_photometry.py:74-122: learning rate 1e-3 with
-    the schedule): a smooth problem in a handful of parameters per epoch.  After 1000 iterations fluxes and shifts agree
+    the schedule): a smooth problem in a handful of parameters per epoch.  After 600 iterations fluxes and shifts agree
     with the oracle within 1e-4 relative and chi2 within 1e-5."""
     from lightcurver_amd.joint import JointFit
-    E, M, n, ss, T = 6, 1, 16, 2, 1000
+    E, M, n, ss, T = 6, 1, 16, 2, 600
     ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=2026, with_background=False)
     p = {k: np.array(v, dtype=np.float64) for k, v in ds['truth'].items()}
     rng = np.random.default_rng(3)
