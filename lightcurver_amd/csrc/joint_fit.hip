@@ -50,6 +50,7 @@ struct lc_joint {
   float2 *St_alt = nullptr;                                                                        // [E][KH][L]
   float *psf_dev = nullptr, *psF = nullptr;  // point-source-only path: narrow PSFs [E][N*N], filter outputs [E][M][3][n*n]
   float *gm_c = nullptr, *gm_t = nullptr, *gm_n = nullptr, *gm_y = nullptr, *gm_l1 = nullptr, *gm_pos = nullptr;
+  float *gm_edge = nullptr;  // [N][4] end sums of the adjoint passes
   float *gm_pts = nullptr;  // [8] mean fluxes + [blocks][8][3] partial inner products of the point-source term
   hipStream_t streamB = nullptr;      // the h regulariser runs here, concurrently with the epoch kernel
   hipEvent_t evReg = nullptr, evUpd = nullptr;
@@ -276,8 +277,10 @@ int launch_reg_gm(lc_joint *j, hipStream_t stream, bool with_pts, bool abar_from
       const int d = 1 << s;
       const float *q = j->qscr + (size_t)s * NN;
       hipLaunchKernelGGL(gm_sub_kernel, grid, block, 0, stream, NN, j->greg, q, j->gm_y);
-      hipLaunchKernelGGL(gm_pass_adjoint_kernel, grid, block, 0, stream, N, d, 0, j->gm_y, (const float *)nullptr, j->gm_t);
-      hipLaunchKernelGGL(gm_pass_adjoint_kernel, grid, block, 0, stream, N, d, 1, j->gm_t, q, j->greg);
+      hipLaunchKernelGGL(gm_edge_kernel, dim3(N), dim3(64), 0, stream, N, d, 0, j->gm_y, j->gm_edge);
+      hipLaunchKernelGGL(gm_pass_adjoint_kernel, grid, block, 0, stream, N, d, 0, j->gm_y, j->gm_edge, (const float *)nullptr, j->gm_t);
+      hipLaunchKernelGGL(gm_edge_kernel, dim3(N), dim3(64), 0, stream, N, d, 1, j->gm_t, j->gm_edge);
+      hipLaunchKernelGGL(gm_pass_adjoint_kernel, grid, block, 0, stream, N, d, 1, j->gm_t, j->gm_edge, q, j->greg);
     }
   } else {
     LC_HIP(j->ctx, hipMemsetAsync(j->greg, 0, (size_t)NN * sizeof(float), stream));
@@ -293,8 +296,10 @@ int launch_reg_gm(lc_joint *j, hipStream_t stream, bool with_pts, bool abar_from
     hipLaunchKernelGGL(gm_pass_kernel, grid, block, 0, stream, N, 1, 1, j->gm_c, j->gm_t);
     hipLaunchKernelGGL(gm_pass_kernel, grid, block, 0, stream, N, 1, 0, j->gm_t, j->gm_n);
     hipLaunchKernelGGL(gm_coef_kernel, grid, block, 0, stream, N, j->gm_n, j->gm_c, W, j->norms, j->cfg.lam_pts_source, qp, l1p);
-    hipLaunchKernelGGL(gm_pass_adjoint_kernel, grid, block, 0, stream, N, 1, 0, qp, (const float *)nullptr, j->gm_t);
-    hipLaunchKernelGGL(gm_pass_adjoint_kernel, grid, block, 0, stream, N, 1, 1, j->gm_t, (const float *)nullptr, j->gm_y);
+    hipLaunchKernelGGL(gm_edge_kernel, dim3(N), dim3(64), 0, stream, N, 1, 0, qp, j->gm_edge);
+    hipLaunchKernelGGL(gm_pass_adjoint_kernel, grid, block, 0, stream, N, 1, 0, qp, j->gm_edge, (const float *)nullptr, j->gm_t);
+    hipLaunchKernelGGL(gm_edge_kernel, dim3(N), dim3(64), 0, stream, N, 1, 1, j->gm_t, j->gm_edge);
+    hipLaunchKernelGGL(gm_pass_adjoint_kernel, grid, block, 0, stream, N, 1, 1, j->gm_t, j->gm_edge, (const float *)nullptr, j->gm_y);
     hipLaunchKernelGGL(gm_pts_inner_kernel, grid, block, 0, stream, N, j->ss, j->M, qp, j->gm_y, j->par[LC_P_CX], j->par[LC_P_CY], part);
     hipLaunchKernelGGL(gm_pts_final_kernel, dim3(1), dim3(64), 0, stream, nb, j->M, part, l1p, j->regs);
   }
@@ -497,6 +502,7 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
     TRY(dmalloc(j, &j->gm_l1, (size_t)(j->J + 1) * nb));
     TRY(dmalloc(j, &j->gm_pos, nb));
     TRY(dmalloc(j, &j->gm_pts, 8 + nb * 3 * kMaxSources));
+    TRY(dmalloc(j, &j->gm_edge, (size_t)N * 4));
   }
   LC_HIP(ctx, hipStreamCreate(&j->streamB));
   LC_HIP(ctx, hipEventCreateWithFlags(&j->evReg, hipEventDisableTiming));

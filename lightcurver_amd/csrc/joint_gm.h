@@ -57,12 +57,38 @@ __global__ void gm_sub_kernel(int NN, const float *z, const float *q, float *y) 
   if (k < NN) y[k] = z[k] - q[k];
 }
 
-// adjoint of gm_pass_kernel along `axis`; when q != null the result is q + adjoint (the recursion step)
-__global__ void gm_pass_adjoint_kernel(int N, int d, int axis, const float *in, const float *q, float *out) {
+// sums of the samples that clamp onto the two ends of every line (x <= d, x <= 2d, x >= N-1-d, x >= N-1-2d): one wave
+// per line, lanes stride over the line.  edge[line][4]
+__global__ void gm_edge_kernel(int N, int d, int axis, const float *in, float *edge) {
+  const int line_id = blockIdx.x, lane = threadIdx.x;
+  const int stride = axis == 0 ? N : 1;
+  const float *line = in + (axis == 0 ? line_id : line_id * N);
+  float s1 = 0.f, s2 = 0.f, e1 = 0.f, e2 = 0.f;
+  for (int x = lane; x < N; x += 64) {
+    const float g = line[x * stride];
+    s1 += (x <= d) ? g : 0.f;
+    s2 += (x <= 2 * d) ? g : 0.f;
+    e1 += (x >= N - 1 - d) ? g : 0.f;
+    e2 += (x >= N - 1 - 2 * d) ? g : 0.f;
+  }
+  s1 = wave_sum_shfl(s1);
+  s2 = wave_sum_shfl(s2);
+  e1 = wave_sum_shfl(e1);
+  e2 = wave_sum_shfl(e2);
+  if (lane == 0) {
+    edge[line_id * 4 + 0] = s1;
+    edge[line_id * 4 + 1] = s2;
+    edge[line_id * 4 + 2] = e1;
+    edge[line_id * 4 + 3] = e2;
+  }
+}
+// adjoint of gm_pass_kernel along `axis` (end sums from gm_edge_kernel); when q != null the result is q + adjoint
+__global__ void gm_pass_adjoint_kernel(int N, int d, int axis, const float *in, const float *edge, const float *q, float *out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= N * N) return;
   const int u = k / N, v = k % N;
   const int x = axis == 0 ? u : v;               // position along the line
+  const int line_id = axis == 0 ? v : u;
   const int stride = axis == 0 ? N : 1;
   const float *line = in + (axis == 0 ? v : u * N);
   float acc;
@@ -74,23 +100,9 @@ __global__ void gm_pass_adjoint_kernel(int N, int d, int axis, const float *in, 
       if (xx >= 0 && xx <= N - 1) acc = fmaf(gm_b3(t), line[xx * stride], acc);
     }
   } else if (x == 0) {
-    float s1 = 0.f, s2 = 0.f;
-    const int m1 = min(d, N - 1), m2 = min(2 * d, N - 1);
-    for (int xx = 0; xx <= m2; ++xx) {
-      const float g = line[xx * stride];
-      if (xx <= m1) s1 += g;
-      s2 += g;
-    }
-    acc = 0.375f * line[0] + 0.25f * s1 + 0.0625f * s2;
+    acc = 0.375f * line[0] + 0.25f * edge[line_id * 4 + 0] + 0.0625f * edge[line_id * 4 + 1];
   } else {
-    float s1 = 0.f, s2 = 0.f;
-    const int m1 = max(N - 1 - d, 0), m2 = max(N - 1 - 2 * d, 0);
-    for (int xx = m2; xx <= N - 1; ++xx) {
-      const float g = line[xx * stride];
-      if (xx >= m1) s1 += g;
-      s2 += g;
-    }
-    acc = 0.375f * line[(N - 1) * stride] + 0.25f * s1 + 0.0625f * s2;
+    acc = 0.375f * line[(N - 1) * stride] + 0.25f * edge[line_id * 4 + 2] + 0.0625f * edge[line_id * 4 + 3];
   }
   out[k] = (q ? q[k] : 0.f) + acc;
 }
@@ -114,12 +126,15 @@ __global__ void gm_positivity_kernel(int NN, const float *h, float lam_pos, floa
   }
 }
 
-// ordered sums of the partials -> regs[0] = l1, regs[1] = positivity
+// sums of the partials -> regs[0] = l1, regs[1] = positivity: one wave, lanes stride over the partials, fixed combine order
 __global__ void gm_regs_kernel(int nparts_l1, int nblocks, const float *l1_part, const float *pos_part, float *regs) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float a = 0.f, b = 0.f;
-    for (int i = 0; i < nparts_l1; ++i) a += l1_part[i];
-    for (int i = 0; i < nblocks; ++i) b += pos_part[i];
+  const int lane = threadIdx.x;
+  float a = 0.f, b = 0.f;
+  for (int i = lane; i < nparts_l1; i += 64) a += l1_part[i];
+  for (int i = lane; i < nblocks; i += 64) b += pos_part[i];
+  a = wave_sum_shfl(a);
+  b = wave_sum_shfl(b);
+  if (lane == 0) {
     regs[0] = a;
     regs[1] = b;
   }
