@@ -46,8 +46,11 @@ def _setup(ctx, E, M, n, ss, seed, alpha_sigma=0.0, with_h=True):
 
 
 @pytest.mark.parametrize('E,M,n,ss,alpha', [(3, 1, 16, 1, 0.0), (4, 2, 16, 2, 0.0), (3, 2, 16, 2, 2.0),
-                                            (3, 3, 24, 2, 0.5), (2, 2, 32, 2, 0.3)])
+                                            (3, 3, 24, 2, 0.5), (2, 2, 32, 2, 0.3), (2, 2, 64, 2, 0.3),
+                                            (3, 2, 64, 2, 0.0)])
 def test_model_loss_and_gradients(ctx, E, M, n, ss, alpha):
+    # n = 64 is the instantiation BASELINE.json configs[3] (C4) runs: joint_epoch_kernel<JointCfg<128,2,192,...>> +
+    # joint_update_kernel<128,16>; alpha = 0.3 exercises the ordered-gather T^T, alpha = 0 the 4-tap translation path
     ds, j, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 100 + n + M, alpha_sigma=alpha)
     N = n * ss
     W = om.propagate_noise_deconv(sig2, psf, ss)
@@ -112,7 +115,7 @@ def test_noise_propagation_and_fisher(ctx, E, n, ss):
     assert H.rel_err(s, so) < 3e-5
 
 
-@pytest.mark.parametrize('n,ss,with_h', [(16, 2, True), (32, 2, True), (16, 1, False)])
+@pytest.mark.parametrize('n,ss,with_h', [(16, 2, True), (32, 2, True), (16, 1, False), (64, 2, True)])
 def test_adabelief_trajectory(ctx, n, ss, with_h):
     E, M, T = 4, 2, 20
     ds, j, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 40 + n, with_h=with_h)
@@ -136,7 +139,7 @@ def test_adabelief_trajectory(ctx, n, ss, with_h):
         assert dh.max() < 0.05 * T * 1e-3 and np.median(dh) < 1e-5
 
 
-@pytest.mark.parametrize('n,with_h', [(16, True), (32, True), (16, False)])
+@pytest.mark.parametrize('n,with_h', [(16, True), (32, True), (16, False), (64, True)])
 def test_adabelief_trajectory_with_point_source_starlet_term(ctx, n, with_h):
     """regularization_strength_pts_source is on by default in the reference's ROI fit (roi_modelling.py:311).  Inside
     lc_joint_run_adabelief the term is evaluated ahead of the update, on the second stream with the background

@@ -28,8 +28,9 @@ def _setup(n, ss, F, S, seed, ctx, jitter=0.3):
     return ds, plist, b
 
 
-@pytest.mark.parametrize('n,ss,S', [(16, 1, 3), (16, 2, 4), (24, 2, 5), (32, 2, 8)])
+@pytest.mark.parametrize('n,ss,S', [(16, 1, 3), (16, 2, 4), (24, 2, 5), (32, 2, 8), (64, 2, 8)])
 def test_eval_matches_oracle(ctx, n, ss, S):
+    # (64, 2, 8) is the instantiation BASELINE.json configs[2] (C3) runs: psf_fit_kernel<PsfCfg<128, ...>>
     F = 2
     ds, plist, b = _setup(n, ss, F, S, 11 + n + ss, ctx)
     N = n * ss
@@ -103,9 +104,9 @@ def test_noise_propagation_matches_oracle(ctx, n, ss, S):
     assert H.rel_err(b2.get_weights(), W) < 1e-6
 
 
-@pytest.mark.parametrize('n,ss,S', [(16, 2, 4), (32, 2, 8)])
+@pytest.mark.parametrize('n,ss,S', [(16, 2, 4), (32, 2, 8), (64, 2, 8)])
 def test_adabelief_trajectory_matches_oracle(ctx, n, ss, S):
-    F, T = (2 if n < 32 else 1), 25  # the oracle needs ~1 s per iteration and frame at n = 32
+    F, T = 2, 25
     ds, plist, b = _setup(n, ss, F, S, 5 + n, ctx, jitter=0.1)
     N = n * ss
     J = om.n_scales(N)
