@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
 """Throughput of the PSF-fit hot loop (BASELINE.json metric: cutouts/sec), one rank per GPU.
 
-A *step* is one launch of the persistent PSF-fit kernel: ITERS_PER_STEP AdaBelief iterations
-(forward model + chi2 + full gradient + starlet l1 + fused update) over every stamp of the rank's
-batch.  Workload at N = 1: BASELINE.json configs[1] (C2) = 100 frames x 8 stars, 32 x 32 stamps,
-subsampling 2, starlet-regularised pixel-grid stage of the PSF fit; for N > 1 every rank gets its
-own C2-sized batch (frames shard embarrassingly, no data-path collective => weak scaling).
-Inputs are resident in HBM before the timed region; the Moffat stage and noise propagation are
-one-time setup and not timed.
+A *step* is one pass of the hot path over one batch: the whole pixel-grid stage of the PSF fit of the batch
+(reference default ``psf_n_iter_pixels: 3000`` AdaBelief iterations, config.yaml:227; each iteration = forward model
++ chi2 + full gradient + starlet l1 + fused update of every stamp), from B = 0 at the Moffat-stage optimum, as ONE
+persistent launch.  Workload at N = 1: BASELINE.json configs[1] (C2) = 100 frames x 8 stars, 32 x 32 stamps,
+subsampling 2; for N > 1 every rank gets its own C2-sized batch (frames shard embarrassingly, no data-path
+collective => weak scaling) and, beside it, C4's 200 epochs sharded over the ranks with the in-place RCCL all-reduce
+of the shared block (strong scaling, reported under config.sharded_joint_fit).
+Inputs are resident in HBM before the timed region; the Moffat stage and noise propagation are one-time setup.
+
+`--gpus N` without a launcher (WORLD_SIZE unset) starts N rank processes itself before anything touches the GPU.
 """
 import argparse
+import csv
+import glob
 import json
 import math
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -21,82 +29,217 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ITERS_PER_STEP = 100
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ITERS_PER_STEP = 3000   # psf_n_iter_pixels (reference config.yaml:227)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3
 
 
-def algorithmic_bytes_per_cutout_iteration(n, ss, S):
+def psf_bytes_per_cutout_iteration(n, ss, S):
     """B_psf = 8 n^2 + (24 + 4 J) N^2 / S  (fp32)."""
     N = n * ss
     J = int(math.log2(N))
     return 8 * n * n + (24 + 4 * J) * N * N / S
 
 
-def cpu_baseline(ds, ss, n_frames=3, n_iter=100, threads=8):
-    """The float64 oracle (kind 'port') timed on the host cores on a bounded sample of the same
-    workload: n_frames frames x S stamps x n_iter AdaBelief iterations of the pixel-grid stage.
-    torch is limited to `threads` intra-op threads (more only oversubscribes these small FFTs)."""
-    import torch
-    from oracle import model as om, optim as oo
-    from tests import helpers as H
-    threads = max(1, min(threads, os.cpu_count() or 1))
-    torch.set_num_threads(threads)
-    S = ds['data'].shape[1]
-    t_total = 0.0
-    for f in range(n_frames):
-        data, sig2, mask = H.psf_oracle_inputs(ds, f, ss)
-        p = H.psf_initial_params(ds, f, ss)
-        W = om.propagate_noise_psf(p, sig2, mask, ss)
-        fn = lambda q: om.psf_loss(q, data, sig2, mask, ss, W=W, lam_scales=1.0, lam_hf=1.0)
+def joint_bytes_per_cutout_iteration(n, ss, E_local):
+    """B_roi = 8 n^2 + 4 N^2 + (24 + 4 J) N^2 / E_local."""
+    N = n * ss
+    J = int(math.log2(N))
+    return 8 * n * n + 4 * N * N + (24 + 4 * J) * N * N / E_local
+
+
+def joint_flops_per_cutout_iteration(n, ss):
+    N = n * ss
+    return 10.0 * (2 * N) ** 2 * math.log2((2 * N) ** 2) + 40.0 * N * N  # SURVEY.md 8(d), FFT route
+
+
+def hbm_roofline(bytes_per_launch, launch_s, kernel, extra=None):
+    achieved = bytes_per_launch / launch_s / 1e9
+    r = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+         'traffic': None, 'kernel': kernel, 'kernel_ms_per_launch': launch_s * 1e3,
+         'algorithmic_bytes_per_launch': bytes_per_launch}
+    if extra:
+        r.update(extra)
+    return r
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# multi-rank launch without a launcher
+# ---------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """Start n rank processes of this script (fresh interpreters: nothing in this process has touched the GPU)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, p.wait())
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# HBM traffic of the timed kernel from the PMC counters (separate rocprofv3 passes, run before this process
+# initialises the GPU; MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE in their own passes, KiB units,
+# FETCH_SIZE doubled on gfx950, WRITE_SIZE exact for 16-byte stores)
+# ---------------------------------------------------------------------------------------------------------------
+def measure_traffic(timeout_s=150):
+    exe = shutil.which('rocprofv3')
+    if not exe:
+        return None, 'rocprofv3 not found'
+    out = {}
+    tmp = tempfile.mkdtemp(prefix='lcmi_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable,
+                   os.path.abspath(__file__), '--pmc-child']
+            try:
+                subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=timeout_s, check=True)
+            except Exception as e:
+                return None, f'{counter} pass failed: {e!r}'
+            vals = []
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get('Counter_Name') != counter or 'psf_fit_kernel' not in r.get('Kernel_Name', ''):
+                        continue
+                    us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+                    if us > 5000.0:   # the ITERS_PER_STEP launches, not the one-iteration evaluations of the setup
+                        vals.append(float(r['Counter_Value']))
+            if not vals:
+                return None, f'no {counter} rows for the timed kernel'
+            out[counter] = sum(vals) / len(vals)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    traffic = (2.0 * out['FETCH_SIZE'] + out['WRITE_SIZE']) * 1024.0
+    return traffic, (f'rocprofv3 --pmc passes inside this run: FETCH_SIZE {out["FETCH_SIZE"]:.0f} KiB (x2 on gfx950) + '
+                     f'WRITE_SIZE {out["WRITE_SIZE"]:.0f} KiB per {ITERS_PER_STEP}-iteration launch')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------
+def setup_psf_batch(ctx, cfg_name, rank=0, moffat_iters=100):
+    from lightcurver_amd.psf_batch import PsfBatch
+    from lightcurver_amd.synthetic import CONFIGS, make_psf_dataset
+    cfg = dict(CONFIGS[cfg_name])
+    cfg.pop('kind')
+    cfg['seed'] += 1000 * rank
+    ds = make_psf_dataset(**cfg)
+    F, S, n, ss = cfg['F'], cfg['S'], cfg['n'], cfg['ss']
+    weight = (ds['masks'] / ds['noisemap'].astype(np.float64) ** 2).astype(np.float32)
+    b = PsfBatch(ds['data'], weight, ss, ctx)
+    g = ds['fwhm_guess']
+    f0 = np.sqrt(np.maximum(g * g - (2.0 / ss) ** 2, 1.0))
+    b.set_moffat(np.stack([f0, f0, np.zeros(F), np.full(F, 2.5)], axis=-1))
+    stars = np.zeros((F, S, 4), np.float32)
+    stars[..., 0] = (ds['data'] * ds['masks']).sum(axis=(-1, -2))
+    b.set_stars(stars)
+    b.set_grid(None)
+    t0 = time.perf_counter()
+    b.fit_moffat(moffat_iters)
+    b.propagate_noise()
+    ctx.synchronize()
+    setup_s = time.perf_counter() - t0
+    b.set_regularization(None, 1.0, 1.0)  # strengths; W stays the propagated one on the device
+    return ds, weight, b, b.get_stars(), setup_s, (F, S, n, ss)
+
+
+def psf_step(b, stars0, ab):
+    """One step: the pixel-grid stage from its start (B = 0, zero moments, stars at the Moffat-stage optimum)."""
+    b.set_grid(None)
+    b.set_stars(stars0)
+    b.run_adabelief(ITERS_PER_STEP, **ab)
+
+
+def cpu_baseline(ds, weight, b, stars0, ss, seconds_target=12.0):
+    """oracle/psf_cpu.c (fp32 C + OpenMP over frames, the same algorithm as the HIP path; kind 'port') timed on the
+    host cores on a bounded sample of the same C2 workload: all hardware threads, then one thread."""
+    from oracle import model as om, psf_cpu
+    try:  # compile for the CPU this runs on; the portable build shipped with the repo is the fall-back
+        path = psf_cpu.build(native=True, out=os.path.join(tempfile.mkdtemp(prefix='lcmi_cpu_', dir='/tmp'), 'libpsfcpu.so'))
+        handle = psf_cpu.lib(path)
+    except Exception:
+        handle = psf_cpu.lib()
+    F, S, n, _ = ds['data'].shape
+    N = n * ss
+    mof = b.get_moffat()
+    Tm = np.stack([om.moffat(N, ss, *[om.T(float(v)) for v in mof[f]]).numpy() for f in range(F)])
+    W = b.get_weights()
+    threads = os.cpu_count() or 1
+    out = {}
+    for label, thr, frames, iters in (('all', threads, F, 60), ('one', 1, min(F, 8), 20)):
+        st = psf_cpu.PsfCpuState(ds['data'][:frames], weight[:frames], ss, Tm[:frames], W[:frames],
+                                 np.zeros((frames, N * N), np.float32), stars0[:frames], handle)
         t0 = time.perf_counter()
-        oo.adabelief(fn, p, ['B', 'a', 'x0', 'y0'], 1e-4, n_iter, schedule=True)
-        t_total += time.perf_counter() - t0
-    return dict(value=n_frames * S * n_iter / t_total, unit='cutouts/sec', cores=threads,
-                kind='port',
-                sample=f'{n_frames} frames x {S} stamps x {n_iter} AdaBelief iterations of the same C2 data, '
-                       'torch float64 oracle')
+        st.run_adabelief(5, threads=thr)
+        rate = frames * S * 5 / (time.perf_counter() - t0)
+        budget = seconds_target * (0.75 if label == 'all' else 0.25)
+        iters = int(max(iters, min(3000, budget * rate / (frames * S))))
+        t0 = time.perf_counter()
+        hist = st.run_adabelief(iters, threads=thr)
+        dt = time.perf_counter() - t0
+        out[label] = dict(rate=frames * S * iters / dt, frames=frames, iters=iters, seconds=dt,
+                          finite=bool(np.all(np.isfinite(hist))))
+    return dict(value=out['all']['rate'], unit='cutouts/sec', cores=threads, kind='port',
+                sample=f"{out['all']['frames']} frames x {S} stamps x {out['all']['iters']} AdaBelief iterations of the same "
+                       f"C2 data ({out['all']['seconds']:.1f} s), oracle/psf_cpu.c fp32 + OpenMP over frames",
+                value_one_thread=out['one']['rate'],
+                sample_one_thread=f"{out['one']['frames']} frames x {S} stamps x {out['one']['iters']} iterations "
+                                  f"({out['one']['seconds']:.1f} s)",
+                loss_finite=out['all']['finite'] and out['one']['finite'])
 
 
-def joint_fit_secondary(ctx, iters=100):
-    """Secondary figure (not the contract metric): joint ROI forward-model iterations of BASELINE.json
-    configs[3] (C4: 200 epochs, 64x64 ROI, 2 point sources + starlet-regularised background) on this GPU."""
+def joint_workload(ctx, E, n, M, seed, iters, label):
+    """Joint ROI forward-model iterations (all parameters free, the reference's ROI regularisation strengths:
+    roi_modelling.py:308-321) on this GPU; returns an entry with its own roofline block."""
     from lightcurver_amd.joint import JointFit
     from lightcurver_amd.synthetic import make_roi_dataset
-    E, n, M, ss = 200, 64, 2, 2
-    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=104)
+    ss = 2
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=seed)
     j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
     p = dict(ds['truth'])
     p['a'] = p['a'] * 0.9
     j.set_params(**p)
+    t0 = time.perf_counter()
     W = j.propagate_noise()
-    # the reference's code fall-backs of the main ROI optimisation (roi_modelling.py:308-312)
+    ctx.synchronize()
+    setup_s = time.perf_counter() - t0
     j.set_loss(W=W, lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
     j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
-    ab = dict(init_learning_rate=1e-4, schedule_learning_rate=False)
-    j.run_adabelief(5, **ab)
+    ab = dict(init_learning_rate=1e-4, schedule_learning_rate=False)   # roi_modelling.py:329
+    j.run_adabelief(10, **ab)
     ctx.synchronize()
+    t0 = time.perf_counter()
     ctx.timer_start()
     j.run_adabelief(iters, **ab)
     ms = ctx.timer_stop()
+    wall = time.perf_counter() - t0
     hist = j.loss_history()
-    N = n * ss
-    J = int(math.log2(N))
-    bytes_per = 8 * n * n + 4 * N * N + (24 + 4 * J) * N * N / E
-    flops_per = 10.0 * (2 * N) ** 2 * math.log2((2 * N) ** 2) + 40.0 * N * N  # SURVEY.md 8(d), FFT route
-    rate = E * iters / (ms * 1e-3)
     j.close()
-    return {'workload': f'C4: {E} epochs x {n}x{n} ROI, {M} point sources + background, all parameters free, reference-default regularisation strengths, '
-                        f'{iters} AdaBelief iterations (3 launches per iteration)',
-            'cutouts_per_sec': rate, 'us_per_iteration': ms * 1e3 / iters,
-            'algorithmic_bytes_per_cutout_iteration': bytes_per,
-            'hbm_roofline_frac': rate * bytes_per / 1e9 / HBM_PEAK_GBS,
-            'algorithmic_flop_per_cutout_iteration': flops_per, 'fp32_valu_frac_of_157': rate * flops_per / 1e12 / 157.3,
-            'loss_finite': bool(np.all(np.isfinite(hist)))}
+    bytes_per = joint_bytes_per_cutout_iteration(n, ss, E)
+    flops_per = joint_flops_per_cutout_iteration(n, ss)
+    it_s = ms * 1e-3 / iters
+    return {'workload': f'{label}: {E} epochs x {n}x{n} ROI, {M} point sources + background, all parameters free, '
+                        f'reference-default regularisation, {iters} AdaBelief iterations',
+            'value': E * iters / (ms * 1e-3), 'unit': 'cutouts/sec', 'us_per_iteration': it_s * 1e6,
+            'wall_us_per_iteration': wall * 1e6 / iters, 'setup_seconds_untimed': setup_s,
+            'roofline': hbm_roofline(E * bytes_per, it_s, 'one joint iteration: joint_epoch_kernel + reduction + update',
+                                     {'algorithmic_bytes_per_cutout_iteration': bytes_per,
+                                      'fp32_valu_tflops': E * flops_per / it_s / 1e12,
+                                      'fp32_valu_frac_of_157': E * flops_per / it_s / 1e12 / FP32_PEAK_TFLOPS}),
+            'loss_finite': bool(np.all(np.isfinite(hist))), 'loss_first_last': [float(hist[0]), float(hist[-1])]}
 
 
-def c3_shard_secondary(ctx, iters=50):
-    """Secondary figure: one GPU's share of BASELINE.json configs[2] (C3: 500 frames x 8 stars x 64x64 over 8
-    GPUs = 63 frames per GPU), pixel-grid stage of the PSF fit."""
+def c3_shard_workload(ctx, iters=200):
+    """One GPU's share of BASELINE.json configs[2] (C3: 500 frames x 8 stars x 64x64 over 8 GPUs = 63 frames)."""
     from lightcurver_amd.psf_batch import PsfBatch
     from lightcurver_amd.synthetic import make_psf_dataset
     F, S, n, ss = 63, 8, 64, 2
@@ -120,18 +263,20 @@ def c3_shard_secondary(ctx, iters=50):
     b.run_adabelief(iters, **ab)
     ms = ctx.timer_stop()
     hist = b.loss_history()
-    bytes_per = algorithmic_bytes_per_cutout_iteration(n, ss, S)
-    rate = F * S * iters / (ms * 1e-3)
     b.close()
-    return {'workload': f'C3 shard: {F} frames x {S} stars, {n}x{n} stamps (1/8 of C3), {iters} AdaBelief iterations',
-            'cutouts_per_sec': rate, 'us_per_iteration': ms * 1e3 / iters,
-            'algorithmic_bytes_per_cutout_iteration': bytes_per,
-            'hbm_roofline_frac': rate * bytes_per / 1e9 / HBM_PEAK_GBS, 'loss_finite': bool(np.all(np.isfinite(hist)))}
+    bytes_per = psf_bytes_per_cutout_iteration(n, ss, S)
+    N = n * ss
+    return {'workload': f'C3 shard: {F} frames x {S} stars, {n}x{n} stamps (1/8 of C3), {iters} AdaBelief iterations, one launch',
+            'value': F * S * iters / (ms * 1e-3), 'unit': 'cutouts/sec', 'us_per_iteration': ms * 1e3 / iters,
+            'roofline': hbm_roofline(F * S * iters * bytes_per, ms * 1e-3, 'psf_fit_kernel (N = 128)',
+                                     {'algorithmic_bytes_per_cutout_iteration': bytes_per,
+                                      'fp32_valu_frac_of_157': F * S * iters * 70.0 * N * N / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}),
+            'loss_finite': bool(np.all(np.isfinite(hist)))}
 
 
-def sharded_joint_fit(ctx, rank, world, iters=100):
-    """Opt-in (--sharded-joint): C4's 200 epochs sharded over the ranks, shared block all-reduced in place by
-    RCCL every iteration (lightcurver_amd/distributed.py).  Strong scaling: the total work is fixed."""
+def sharded_joint_fit(ctx, rank, world, iters=500):
+    """C4's 200 epochs sharded over the ranks; the shared block is all-reduced in place by RCCL every iteration
+    (lightcurver_amd/distributed.py).  Strong scaling: the total work is fixed."""
     import datetime
     import torch
     import torch.distributed as dist
@@ -147,13 +292,13 @@ def sharded_joint_fit(ctx, rank, world, iters=100):
     for k in ('dx', 'dy', 'alpha', 'mean'):
         p[k] = np.asarray(p[k])[lo:hi]
     j.set_params(**p)
-    j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0)
+    j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
     j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
     torch.cuda.set_device(ctx.stream()[1])
-    group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=120))
+    group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=180))
     opt = ShardedJointOptimizer(j, group)
     ab = dict(init_learning_rate=1e-4, schedule_learning_rate=False)
-    opt.run(5, **ab)
+    opt.run(10, **ab)
     ctx.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
@@ -161,76 +306,77 @@ def sharded_joint_fit(ctx, rank, world, iters=100):
     ctx.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t[0])
     hist = j.loss_history()
     j.close()
-    return {'workload': f'C4 sharded: {E} epochs x {n}x{n} ROI over {world} ranks, RCCL all-reduce of the shared block',
-            'cutouts_per_sec': E * iters / dt, 'us_per_iteration': dt * 1e6 / iters, 'scaling': 'strong',
-            'device_collective': bool(opt._dev), 'loss_finite': bool(np.all(np.isfinite(hist)))}
+    return {'workload': f'C4 sharded: {E} epochs x {n}x{n} ROI over {world} ranks, RCCL all-reduce of the shared block '
+                        f'({n * ss * n * ss + 4 * M + 2} floats) once per iteration, {iters} iterations',
+            'value': E * iters / dt, 'unit': 'cutouts/sec', 'us_per_iteration': dt * 1e6 / iters, 'scaling': 'strong',
+            'rccl_ranks': world, 'device_collective': bool(opt._dev), 'loss_finite': bool(np.all(np.isfinite(hist)))}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-joint', action='store_true', help='skip the secondary joint-fit figure')
-    ap.add_argument('--sharded-joint', action='store_true',
-                    help='also time the epoch-sharded joint fit with the in-place RCCL all-reduce (every rank takes part)')
+    ap.add_argument('--no-extra', '--no-joint', dest='no_extra', action='store_true',
+                    help='skip the C4 / C5-shard / C3-shard entries')
+    ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc passes (roofline.traffic = null)')
+    ap.add_argument('--no-sharded-joint', action='store_true', help='N > 1: skip the epoch-sharded C4 fit with RCCL')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != max(args.gpus, 1):
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+        sys.exit(2)
+
+    traffic, traffic_source = None, 'not measured (--no-traffic, N > 1 or a profiler child)'
+    if world == 1 and not args.no_traffic and not args.pmc_child and args.config == 'C2':
+        traffic, traffic_source = measure_traffic()   # before this process touches the GPU
+
     dist = None
     if world > 1:
         import torch.distributed as dist
-        # frames shard with no data-path collective: the process group only carries the barrier and
-        # the max-over-ranks of the timing, so a host-side (gloo) group is sufficient and keeps the
-        # timed region free of foreign GPU work.
+        # frames shard with no data-path collective: this host-side (gloo) group only carries the barriers and the
+        # max-over-ranks of the timing; the sharded joint fit makes its own nccl (= RCCL) group
         dist.init_process_group('gloo', rank=rank, world_size=world)
 
     from lightcurver_amd import _lib
-    from lightcurver_amd.psf_batch import PsfBatch
-    from lightcurver_amd.synthetic import CONFIGS, make_psf_dataset
-
-    cfg = dict(CONFIGS[args.config])
-    cfg.pop('kind')
-    cfg['seed'] += 1000 * rank
-    ds = make_psf_dataset(**cfg)
-    F, S, n, ss = cfg['F'], cfg['S'], cfg['n'], cfg['ss']
-
     # rehearsal of the multi-rank path on a one-GPU box: LCMI_BENCH_DEVICE=0 puts every rank on that device
     ctx = _lib.Context(int(os.environ.get('LCMI_BENCH_DEVICE', local_rank)))
-    weight = (ds['masks'] / ds['noisemap'].astype(np.float64) ** 2).astype(np.float32)
-    b = PsfBatch(ds['data'], weight, ss, ctx)
-    # setup (not timed): Moffat stage from the seeing guess, then noise propagation for the l1 weights
-    g = ds['fwhm_guess']
-    f0 = np.sqrt(np.maximum(g * g - (2.0 / ss) ** 2, 1.0))
-    b.set_moffat(np.stack([f0, f0, np.zeros(F), np.full(F, 2.5)], axis=-1))
-    stars = np.zeros((F, S, 4), np.float32)
-    stars[..., 0] = (ds['data'] * ds['masks']).sum(axis=(-1, -2))
-    b.set_stars(stars)
-    b.set_grid(None)
-    t0 = time.perf_counter()
-    b.fit_moffat(100)
-    b.propagate_noise()
-    ctx.synchronize()
-    setup_s = time.perf_counter() - t0
-    b.set_regularization(None, 1.0, 1.0)  # strengths; W stays the propagated one on the device
-
+    ds, weight, b, stars0, setup_s, (F, S, n, ss) = setup_psf_batch(ctx, args.config, rank)
     ab = dict(init_learning_rate=1e-4, schedule_learning_rate=True)
+
+    if args.pmc_child:   # under rocprofv3 --pmc: two launches of the timed kind, nothing else
+        for _ in range(2):
+            psf_step(b, stars0, ab)
+        ctx.synchronize()
+        return
+
     for _ in range(args.warmup):
-        b.run_adabelief(ITERS_PER_STEP, **ab)
+        psf_step(b, stars0, ab)
     ctx.synchronize()
     if dist:
         dist.barrier()
     t0 = time.perf_counter()
-    ctx.timer_start()
+    kernel_ms = 0.0
     for _ in range(args.steps):
+        b.set_grid(None)
+        b.set_stars(stars0)
+        ctx.timer_start()                       # HIP events on the stream the kernel runs on
         b.run_adabelief(ITERS_PER_STEP, **ab)
-    kernel_ms = ctx.timer_stop()  # HIP events on the stream the kernels run on; also synchronises
+        kernel_ms += ctx.timer_stop()           # also synchronises
     ctx.synchronize()
     if dist:
         dist.barrier()
@@ -244,79 +390,68 @@ def main():
     hist = b.loss_history()
     finite = bool(np.all(np.isfinite(hist)))
     res = b.results()
+
     sharded = None
-    if args.sharded_joint:
-        import torch.distributed as tdist
-        own_group = False
-        if not tdist.is_initialized():
-            tdist.init_process_group('gloo', init_method='tcp://127.0.0.1:29531', rank=0, world_size=1)
-            own_group = True
+    if world > 1 and not args.no_sharded_joint:
         try:
             sharded = sharded_joint_fit(ctx, rank, world)
         except Exception as e:
             sharded = {'error': repr(e)}
-        if own_group:
-            tdist.destroy_process_group()
 
     if rank == 0:
-        cutouts = F * S * world
-        value = cutouts * ITERS_PER_STEP * args.steps / elapsed
-        bytes_per = algorithmic_bytes_per_cutout_iteration(n, ss, S)
+        value = F * S * world * ITERS_PER_STEP * args.steps / elapsed
+        bytes_per = psf_bytes_per_cutout_iteration(n, ss, S)
         launch_s = kernel_ms * 1e-3 / args.steps
-        achieved = F * S * ITERS_PER_STEP * bytes_per / launch_s / 1e9
         N = n * ss
         flops_per = 70.0 * N * N  # separable passes: 35 N^2 MAC per stamp-iteration
-        traffic = None
-        prof = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
-        if os.path.exists(prof) and args.config == 'C2':
-            try:
-                traffic = json.load(open(prof)).get('psf_fit_kernel', {}).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        roof = hbm_roofline(F * S * ITERS_PER_STEP * bytes_per, launch_s, 'psf_fit_kernel',
+                            {'algorithmic_bytes_per_cutout_iteration': bytes_per,
+                             'fp32_valu_tflops': F * S * ITERS_PER_STEP * flops_per / launch_s / 1e12,
+                             'fp32_valu_frac_of_157': F * S * ITERS_PER_STEP * flops_per / launch_s / 1e12 / FP32_PEAK_TFLOPS,
+                             'note': 'the pixel state stays on chip across the iterations of a launch, so HBM moves far '
+                                     'fewer bytes than the algorithmic figure; the kernel is bound by fp32 VALU issue'})
+        roof['traffic'] = traffic
+        roof['traffic_source'] = traffic_source
         out = {
             'metric': 'cutouts/sec (PSF-fit + joint forward-model iter), 32x32 & 64x64 stamps',
             'value': value, 'unit': 'cutouts/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.config}: {F} frames x {S} stars, {n}x{n} stamps, subsampling {ss}, '
-                                   f'starlet-regularised PSF pixel-grid fit, {ITERS_PER_STEP} AdaBelief '
-                                   'iterations per step (one persistent launch)',
+                                   f'starlet-regularised PSF pixel-grid fit; one step = the whole stage of '
+                                   f'{ITERS_PER_STEP} AdaBelief iterations from B = 0 (one persistent launch)',
                        'frames_per_gpu': F, 'stars': S, 'stamp': n, 'subsampling': ss,
-                       'iters_per_step': ITERS_PER_STEP, 'sharding': f'frames x{world} (no collective)',
+                       'iters_per_step': ITERS_PER_STEP, 'us_per_iteration': launch_s * 1e6 / ITERS_PER_STEP,
+                       'sharding': f'frames x{world} (no collective)',
                        'setup_seconds_untimed': setup_s, 'loss_finite': finite,
                        'median_reduced_chi2': float(np.median(res['chi2']))},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'traffic_source': 'profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch)' if traffic else None,
-                         'kernel': 'psf_fit_kernel', 'kernel_ms_per_launch': launch_s * 1e3,
-                         'algorithmic_bytes_per_cutout_iteration': bytes_per,
-                         'note': 'state is kept on-chip across iterations, so algorithmic bytes/s may exceed '
-                                 'what HBM actually moves; fp32 VALU fraction reported beside it',
-                         'fp32_valu_tflops': F * S * ITERS_PER_STEP * flops_per / launch_s / 1e12,
-                         'fp32_valu_frac_of_157': F * S * ITERS_PER_STEP * flops_per / launch_s / 1e12 / 157.3},
+            'roofline': roof,
         }
         try:  # the box's own copy bandwidth beside the 8 TB/s specification
             import ctypes
             g = ctypes.c_float()
             ctx.check(_lib.lib().lc_copy_bandwidth(ctx.h, 1 << 30, 10, ctypes.byref(g)), 'lc_copy_bandwidth')
             out['roofline']['measured_copy_GBps'] = g.value
-            out['roofline']['frac_of_measured_copy'] = achieved / g.value
-        except Exception as e:
+            out['roofline']['frac_of_measured_copy'] = roof['achieved'] / g.value
+        except Exception:
             out['roofline']['measured_copy_GBps'] = None
-        if world == 1 and not args.no_joint:
-            try:
-                out['config']['joint_fit'] = joint_fit_secondary(ctx)
-            except Exception as e:
-                out['config']['joint_fit'] = {'error': repr(e)}
-            try:
-                out['config']['c3_shard'] = c3_shard_secondary(ctx)
-            except Exception as e:
-                out['config']['c3_shard'] = {'error': repr(e)}
+        if world == 1 and not args.no_extra:
+            extra = []
+            for fn, kw in ((joint_workload, dict(E=200, n=64, M=2, seed=104, iters=2000, label='C4')),
+                           (joint_workload, dict(E=125, n=128, M=4, seed=105, iters=200,
+                                                 label="C5 shard (one GPU's eighth of C5's 1000 epochs)")),
+                           (c3_shard_workload, {})):
+                try:
+                    extra.append(fn(ctx, **kw))
+                except Exception as e:
+                    extra.append({'workload': kw.get('label', fn.__name__), 'error': repr(e)})
+            out['config']['other_workloads'] = extra
         if sharded is not None:
             out['config']['sharded_joint_fit'] = sharded
+            out['config']['rccl_ranks'] = sharded.get('rccl_ranks')
         if not args.no_cpu_baseline and world == 1:
             try:
-                out['cpu_baseline'] = cpu_baseline(ds, ss)
+                out['cpu_baseline'] = cpu_baseline(ds, weight, b, stars0, ss)
             except Exception as e:  # the bench line must still be printed
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}
         print(json.dumps(out))

@@ -182,8 +182,14 @@ int lc_joint_iterations_done(lc_joint *j);
 /* FisherCovariance(diagonal_only=True) with only `a` free -> sigma(a) [E*M]
  * (lightcurver/utilities/starred_utilities.py:36-38). */
 int lc_joint_fisher_flux_sigma(lc_joint *j, float *sigma_a);
-/* Multi-GPU epoch sharding: split one optimiser step around the caller's all-reduce of the
- * shared block [dL/dh (N*N) | dL/dc_x (M) | dL/dc_y (M) | loss (1)] living in device memory. */
+/* Multi-GPU epoch sharding: split one optimiser step around the caller's all-reduce of the shared block
+ * [dL/dh (N*N) | dL/dc_x (M) | dL/dc_y (M) | sum_e (a - ref) (M) | sum_e (a - ref)^2 (M) | chi2 | n_epochs]
+ * living in device memory.  The flux moments (flux-uniformity term, jnp.std over epochs in the reference:
+ * roi_modelling.py:273-276) are centred on one reference flux per source so that the variance does not cancel in
+ * fp32; lc_joint_set_param(LC_P_A) sets it to the mean of the local fluxes, a sharded fit must give every rank the
+ * same reference (lightcurver_amd/distributed.py does) with lc_joint_set_flux_reference. */
+int lc_joint_set_flux_reference(lc_joint *j, const float *ref, int count /* = M */);
+int lc_joint_get_flux_reference(lc_joint *j, float *ref, int count /* = M */);
 int lc_joint_step_local(lc_joint *j);                      /* forward/backward of local epochs */
 int lc_joint_shared_buffer_dev(lc_joint *j, void **dev_ptr, int *count);
 int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg); /* regularise + AdaBelief */

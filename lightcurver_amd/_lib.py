@@ -74,6 +74,8 @@ SIGNATURES = {
     'lc_joint_destroy': (None, [vp]),
     'lc_joint_set_param': (C.c_int, [vp, C.c_int, fp, C.c_int]),
     'lc_joint_get_param': (C.c_int, [vp, C.c_int, fp, C.c_int]),
+    'lc_joint_set_flux_reference': (C.c_int, [vp, fp, C.c_int]),
+    'lc_joint_get_flux_reference': (C.c_int, [vp, fp, C.c_int]),
     'lc_joint_set_free': (C.c_int, [vp, ip]),
     'lc_joint_set_loss': (C.c_int, [vp, C.POINTER(JointLossCfg), fp]),
     'lc_joint_propagate_noise': (C.c_int, [vp, fp]),

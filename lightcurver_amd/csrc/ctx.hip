@@ -61,6 +61,7 @@ const char *lc_last_error(const lc_ctx *ctx) { return ctx ? ctx->err.c_str() : g
 
 int lc_ctx_synchronize(lc_ctx *ctx) {
   if (!ctx) return LC_ERR_INVALID;
+  LC_ENTER(ctx);
   LC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LC_OK;
 }
@@ -74,12 +75,14 @@ int lc_ctx_stream(lc_ctx *ctx, void **hip_stream, int *device) {
 
 int lc_timer_start(lc_ctx *ctx) {
   if (!ctx) return LC_ERR_INVALID;
+  LC_ENTER(ctx);
   LC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   return LC_OK;
 }
 
 int lc_timer_stop(lc_ctx *ctx, float *elapsed_ms) {
   if (!ctx || !elapsed_ms) return LC_ERR_INVALID;
+  LC_ENTER(ctx);
   LC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   LC_HIP(ctx, hipEventSynchronize(ctx->ev1));
   LC_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));

@@ -40,6 +40,7 @@ struct lc_joint {
   float *model = nullptr, *fisher = nullptr, *shared = nullptr, *W = nullptr, *norms = nullptr,
         *qscr = nullptr, *out_loss = nullptr, *hist = nullptr, *scene2 = nullptr;
   float *prior = nullptr;  // [4][M]
+  float *a_ref = nullptr;  // [kMaxSources] reference fluxes the flux moments of the shared block are centred on
   int shared_count = 0, hist_cap = 0, iters_done = 0, n_prior = 0;
   int free_mask[LC_P_COUNT] = {};
   bool have_W = false, h_nonzero = false;
@@ -250,7 +251,7 @@ int launch_reduce(lc_joint *j, int need_h) {
   const int NN = j->N * j->N;
   const int nimg = (NN + kRedPix - 1) / kRedPix;
   hipLaunchKernelGGL(joint_reduce_kernel, dim3(nimg + 1), dim3(kRedPix * kRedParts), 0, j->ctx->stream, j->E, j->M, NN,
-                     need_h, j->HG, j->g_cx_e, j->g_cy_e, j->chi2_e, j->par[LC_P_A], j->shared);
+                     need_h, j->HG, j->g_cx_e, j->g_cy_e, j->chi2_e, j->par[LC_P_A], j->a_ref, j->shared);
   LC_HIP(j->ctx, hipGetLastError());
   return LC_OK;
 }
@@ -290,7 +291,7 @@ int launch_reg_gm(lc_joint *j, hipStream_t stream, bool with_pts, bool abar_from
   if (with_pts) {
     // point-source starlet term: scale 0 only, on Pbar (the work buffers of the chain above are free again)
     float *abar = j->gm_pts, *part = j->gm_pts + 8, *qp = j->qscr + (size_t)J * NN, *l1p = j->gm_l1 + (size_t)J * nb;
-    hipLaunchKernelGGL(gm_abar_kernel, dim3(1), dim3(256), 0, stream, j->E, j->M, NN, j->par[LC_P_A], j->shared,
+    hipLaunchKernelGGL(gm_abar_kernel, dim3(1), dim3(256), 0, stream, j->E, j->M, NN, j->par[LC_P_A], j->a_ref, j->shared,
                        abar_from_shared ? 1 : 0, abar);
     hipLaunchKernelGGL(gm_pbar_kernel, grid, block, 0, stream, N, j->ss, j->M, abar, j->par[LC_P_CX], j->par[LC_P_CY], j->gm_c);
     hipLaunchKernelGGL(gm_pass_kernel, grid, block, 0, stream, N, 1, 1, j->gm_c, j->gm_t);
@@ -342,6 +343,7 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
     A.gout[k] = (mode == 0 && all_grads) ? j->gout[k] : nullptr;
   }
   A.shared = j->shared;
+  A.a_ref = j->a_ref;
   A.h = j->par[LC_P_H];
   A.mh = j->pm[LC_P_H];
   A.sh = j->ps[LC_P_H];
@@ -510,6 +512,7 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   LC_HIP(ctx, hipEventRecord(j->evUpd, ctx->stream));
   TRY(dmalloc(j, &j->scene2, 2 * NN));
   TRY(dmalloc(j, &j->prior, 4 * std::max(M, 1)));
+  TRY(dmalloc(j, &j->a_ref, kMaxSources));
   TRY(ensure_hist(j, 64));
   {
     std::vector<float> d(data, data + E * nn), w(E * nn);
@@ -574,6 +577,7 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
 
 void lc_joint_destroy(lc_joint *j) {
   if (!j) return;
+  (void)hipSetDevice(j->ctx->device);
   hipStreamSynchronize(j->ctx->stream);
   if (j->streamB) {
     hipStreamSynchronize(j->streamB);
@@ -588,6 +592,7 @@ void lc_joint_destroy(lc_joint *j) {
 
 int lc_joint_set_param(lc_joint *j, int which, const float *values, int count) {
   if (!j || which < 0 || which >= LC_P_COUNT || !values) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   if (count != j->psize[which]) LC_FAIL(j->ctx, LC_ERR_INVALID, "lc_joint_set_param: wrong element count");
   if (which == LC_P_H) {
     j->h_nonzero = false;
@@ -597,15 +602,43 @@ int lc_joint_set_param(lc_joint *j, int which, const float *values, int count) {
         break;
       }
   }
+  if (which == LC_P_A && j->M > 0) {
+    // reference fluxes of the centred flux moments: the mean of the values set here (a sharded fit overrides them
+    // with one reference for all ranks, lc_joint_set_flux_reference)
+    float ref[kMaxSources] = {};
+    for (int i = 0; i < j->M; ++i) {
+      double acc = 0.0;
+      for (int e = 0; e < j->E; ++e) acc += values[(size_t)e * j->M + i];
+      ref[i] = (float)(acc / j->E);
+    }
+    int rc = h2d(j, j->a_ref, ref, sizeof(ref));
+    if (rc) return rc;
+  }
   return h2d(j, j->par[which], values, (size_t)count * sizeof(float));
+}
+int lc_joint_set_flux_reference(lc_joint *j, const float *ref, int count) {
+  if (!j || !ref) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
+  if (count != j->M) LC_FAIL(j->ctx, LC_ERR_INVALID, "lc_joint_set_flux_reference: one reference flux per point source");
+  float r[kMaxSources] = {};
+  for (int i = 0; i < count; ++i) r[i] = ref[i];
+  return h2d(j, j->a_ref, r, sizeof(r));
+}
+int lc_joint_get_flux_reference(lc_joint *j, float *ref, int count) {
+  if (!j || !ref) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
+  if (count != j->M) LC_FAIL(j->ctx, LC_ERR_INVALID, "lc_joint_get_flux_reference: one reference flux per point source");
+  return d2h(j, ref, j->a_ref, (size_t)count * sizeof(float));
 }
 int lc_joint_get_param(lc_joint *j, int which, float *values, int count) {
   if (!j || which < 0 || which >= LC_P_COUNT || !values) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   if (count != j->psize[which]) LC_FAIL(j->ctx, LC_ERR_INVALID, "lc_joint_get_param: wrong element count");
   return d2h(j, values, j->par[which], (size_t)count * sizeof(float));
 }
 int lc_joint_set_free(lc_joint *j, const int32_t *free_mask) {
   if (!j || !free_mask) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   if (free_mask[LC_P_ALPHA]) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "alpha is never optimised (roi_modelling.py:221-222)");
   for (int k = 0; k < LC_P_COUNT; ++k) j->free_mask[k] = free_mask[k] ? 1 : 0;
   // a new optimisation starts: reset the moments and the iteration counter
@@ -618,6 +651,7 @@ int lc_joint_set_free(lc_joint *j, const int32_t *free_mask) {
 }
 int lc_joint_set_loss(lc_joint *j, const lc_joint_loss_cfg *cfg, const float *W) {
   if (!j || !cfg) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   j->cfg = *cfg;
   j->n_prior = 0;
   if (cfg->n_prior > 0) {
@@ -682,6 +716,7 @@ int propagate_noise_device(lc_joint *j) {
 
 int lc_joint_propagate_noise(lc_joint *j, float *W_out) {
   if (!j) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   const int N = j->N, n = j->n, ss = j->ss, E = j->E, c = (N - 1) / 2;
   const size_t NN = (size_t)N * N, nn = (size_t)n * n;
   if (!std::getenv("LCMI_NOISE_HOST")) {
@@ -734,6 +769,7 @@ int lc_joint_propagate_noise(lc_joint *j, float *W_out) {
 
 int lc_joint_step_local(lc_joint *j) {
   if (!j) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   j->reg_pending = false;
   // inside lc_joint_run_adabelief (one GPU: the mean fluxes are all local) the point-source starlet term, which depends
   // on the current a, c_x, c_y only, is evaluated with the background regulariser on the second stream
@@ -758,20 +794,24 @@ int lc_joint_step_local(lc_joint *j) {
 }
 int lc_joint_shared_buffer_dev(lc_joint *j, void **dev_ptr, int *count) {
   if (!j || !dev_ptr || !count) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   *dev_ptr = j->shared;
   *count = j->shared_count;
   return LC_OK;
 }
 int lc_joint_shared_get(lc_joint *j, float *host, int count) {
   if (!j || !host || count != j->shared_count) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   return d2h(j, host, j->shared, (size_t)count * sizeof(float));
 }
 int lc_joint_shared_set(lc_joint *j, const float *host, int count) {
   if (!j || !host || count != j->shared_count) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   return h2d(j, j->shared, host, (size_t)count * sizeof(float));
 }
 int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   if (!j) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   int rc = ensure_hist(j, j->iters_done + 2);
   if (rc) return rc;
   if (j->reg_pending) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
@@ -787,6 +827,7 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
 
 int lc_joint_loss_grad(lc_joint *j, float *loss, float *const grads[LC_P_COUNT]) {
   if (!j) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   const bool want_h = grads && grads[LC_P_H];
   int need = launch_epochs(j, 0, 0, want_h, nullptr);
   if (need < 0) return need;
@@ -804,6 +845,7 @@ int lc_joint_loss_grad(lc_joint *j, float *loss, float *const grads[LC_P_COUNT])
 
 int lc_joint_model(lc_joint *j, float *model, float *chi2_per_epoch) {
   if (!j) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   int rc = launch_epochs(j, 1, 0, false, j->model);
   if (rc < 0) return rc;
   if (model && (rc = d2h(j, model, j->model, (size_t)j->E * j->n * j->n * sizeof(float)))) return rc;
@@ -814,6 +856,7 @@ int lc_joint_model(lc_joint *j, float *model, float *chi2_per_epoch) {
 
 int lc_joint_deconvolved(lc_joint *j, int epoch, float *scene, float *background) {
   if (!j || epoch < 0 || epoch >= j->E) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   const size_t NN = (size_t)j->N * j->N;
   hipLaunchKernelGGL(joint_scene_kernel, dim3(64), dim3(256), 0, j->ctx->stream, j->N, j->ss, j->M, epoch, j->par[LC_P_A],
                      j->par[LC_P_CX], j->par[LC_P_CY], j->par[LC_P_DX], j->par[LC_P_DY], j->par[LC_P_ALPHA],
@@ -827,6 +870,7 @@ int lc_joint_deconvolved(lc_joint *j, int epoch, float *scene, float *background
 
 int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg) {
   if (!j || n_iter <= 0) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   int rc = ensure_hist(j, j->iters_done + n_iter + 2);
   if (rc) return rc;
   j->in_device_loop = true;
@@ -841,6 +885,7 @@ int lc_joint_iterations_done(lc_joint *j) { return j ? j->iters_done : LC_ERR_IN
 
 int lc_joint_get_loss_history(lc_joint *j, float *history, int count) {
   if (!j || !history || count < j->iters_done + 1) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   int rc = ensure_hist(j, j->iters_done + 2);
   if (rc) return rc;
   int need = launch_epochs(j, 0, 0, false, nullptr);  // loss of the final parameters -> hist[T]
@@ -852,6 +897,7 @@ int lc_joint_get_loss_history(lc_joint *j, float *history, int count) {
 
 int lc_joint_fisher_flux_sigma(lc_joint *j, float *sigma_a) {
   if (!j || !sigma_a) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
   for (int i = 0; i < j->M; ++i) {
     int rc = launch_epochs(j, 2, i, false, nullptr);
     if (rc < 0) return rc;

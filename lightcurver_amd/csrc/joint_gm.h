@@ -142,11 +142,11 @@ __global__ void gm_regs_kernel(int nparts_l1, int nblocks, const float *l1_part,
 
 // ---- regularization_strength_pts_source for the large grids: lam * sum W_0 |starlet_0(Pbar)|, Pbar = sum_i abar_i G(c_i) ----
 // abar[i] = mean over the epochs of a[e][i]: from the parameters themselves (one GPU) or from the reduced block
-__global__ void gm_abar_kernel(int E, int M, int NN, const float *a, const float *shared, int from_shared, float *abar) {
+__global__ void gm_abar_kernel(int E, int M, int NN, const float *a, const float *a_ref, const float *shared, int from_shared, float *abar) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int i = wid; i < M; i += nw) {
     if (from_shared) {
-      if (lane == 0) abar[i] = shared[NN + 2 * M + i] / shared[NN + 4 * M + 1];
+      if (lane == 0) abar[i] = a_ref[i] + shared[NN + 2 * M + i] / shared[NN + 4 * M + 1];
     } else {
       float acc = 0.f;
       for (int e = lane; e < E; e += 64) acc += a[e * M + i];
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int E = A.E, M = A.M, NN = N * N;
   if (A.fuse_scalar_reduce) {  // grid of one block (the background is not updated)
-    reduce_scalars(E, M, NN, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.shared_w, lanes, tid);
+    reduce_scalars(E, M, NN, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.a_ref, A.shared_w, lanes, tid);
     __threadfence_block();
     __syncthreads();
   }
@@ -255,10 +255,10 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
       ga -= A.lam_pos_ps;
     }
     if (A.lam_fu != 0.f && Etot > 1.f) {
-      const float mean = A.shared[NN + 2 * M + i] / Etot;
-      const float var = fmaxf(A.shared[NN + 3 * M + i] / Etot - mean * mean, 0.f);
+      const float meanc = A.shared[NN + 2 * M + i] / Etot;  // centred on a_ref (joint_kernels.h, kernel 2)
+      const float var = fmaxf(A.shared[NN + 3 * M + i] / Etot - meanc * meanc, 0.f);
       const float sd = sqrtf(var);
-      if (sd > 0.f) ga += A.lam_fu * (av - mean) / (Etot * sd);
+      if (sd > 0.f) ga += A.lam_fu * ((av - A.a_ref[i]) - meanc) / (Etot * sd);
     }
     if (pts) ga += A.regs[4 + i * 3] / Etot;
     if (A.mode == 0) {
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
     const int which = (tid < M) ? LC_P_CX : LC_P_CY, i = tid % M;
     float gv = A.shared[NN + (which == LC_P_CX ? 0 : M) + i];
     float cv = A.par[which][i];
-    if (pts) gv += (A.shared[NN + 2 * M + i] / Etot) * A.ss * A.regs[4 + i * 3 + (which == LC_P_CX ? 1 : 2)];
+    if (pts) gv += (A.a_ref[i] + A.shared[NN + 2 * M + i] / Etot) * A.ss * A.regs[4 + i * 3 + (which == LC_P_CX ? 1 : 2)];
     if (A.n_prior > 0) {
       const float mu = (which == LC_P_CX) ? A.prior_cx_mean[i] : A.prior_cy_mean[i];
       const float sg = (which == LC_P_CX) ? A.prior_cx_sigma[i] : A.prior_cy_sigma[i];
@@ -311,8 +311,8 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
     if (pts) loss += (double)A.regs[2];
     if (A.lam_fu != 0.f && Etot > 1.f)
       for (int i = 0; i < M; ++i) {
-        const double mean = A.shared[NN + 2 * M + i] / Etot;
-        const double var = fmax((double)A.shared[NN + 3 * M + i] / Etot - mean * mean, 0.0);
+        const double meanc = A.shared[NN + 2 * M + i] / Etot;
+        const double var = fmax((double)A.shared[NN + 3 * M + i] / Etot - meanc * meanc, 0.0);
         loss += A.lam_fu * sqrt(var);
       }
     if (A.hist) A.hist[A.t] = (float)loss;

@@ -642,7 +642,11 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 }
 
 // ---- kernel 2: ordered reduction over the epochs of this rank -------------------------------------
-// shared = [ dL/dh (N*N) | dL/dc_x (M) | dL/dc_y (M) | sum_e a (M) | sum_e a^2 (M) | chi2 | n_epochs ]
+// shared = [ dL/dh (N*N) | dL/dc_x (M) | dL/dc_y (M) | sum_e (a - ref) (M) | sum_e (a - ref)^2 (M) | chi2 | n_epochs ]
+// The flux moments are centred on a per-source reference flux a_ref (the same on every rank of a sharded fit): the
+// flux-uniformity term needs var = <a^2> - <a>^2, which cancels catastrophically in fp32 when the relative scatter of
+// a source is below ~1e-3 (all fluxes start equal in the reference's ROI fit); centred, the cancellation is relative
+// to the scatter itself.
 // Image part: a block owns 32 consecutive pixels; its 8 groups of 32 lanes each sum one eighth of the epochs
 // (coalesced 128-byte rows, 4 independent loads in flight per lane), then the 8 partials are added in a fixed
 // order, so the result does not depend on scheduling.  Scalars: last block, one thread each, in double.
@@ -650,8 +654,8 @@ constexpr int kRedPix = 32, kRedParts = 8;
 // Scalars of the shared block: quantity q in [0, 4M] (dc_x, dc_y, sum a, sum a^2 per source, then chi2), one wave per
 // quantity at a time; lanes stride over the epochs in double, partials combined in lane order.  256 threads.
 __device__ __forceinline__ void reduce_scalars(int E, int M, int NN, const float *g_cx_e, const float *g_cy_e,
-                                               const float *chi2_e, const float *a, float *shared, double *lanes,
-                                               int tid) {
+                                               const float *chi2_e, const float *a, const float *a_ref, float *shared,
+                                               double *lanes, int tid) {
   const int lane = tid & 63, wid = tid >> 6, nw = (kRedPix * kRedParts) / 64;
   for (int q = wid; q <= 4 * M; q += nw) {
     double acc = 0.0;
@@ -660,8 +664,8 @@ __device__ __forceinline__ void reduce_scalars(int E, int M, int NN, const float
         acc += chi2_e[e];
       } else {
         const int kind = q / M, i = q % M;
-        const float ai = a[e * M + i];
-        acc += (kind == 0) ? (double)g_cx_e[e * M + i] : (kind == 1) ? (double)g_cy_e[e * M + i] : (kind == 2) ? (double)ai : (double)ai * ai;
+        const double ai = (double)a[e * M + i] - (double)a_ref[i];
+        acc += (kind == 0) ? (double)g_cx_e[e * M + i] : (kind == 1) ? (double)g_cy_e[e * M + i] : (kind == 2) ? ai : ai * ai;
       }
     }
     lanes[tid] = acc;
@@ -680,7 +684,7 @@ __device__ __forceinline__ void reduce_scalars(int E, int M, int NN, const float
 __global__ __launch_bounds__(kRedPix *kRedParts) void joint_reduce_kernel(int E, int M, int NN, int need_h, const float *HG,
                                                                            const float *g_cx_e, const float *g_cy_e,
                                                                            const float *chi2_e, const float *a,
-                                                                           float *shared) {
+                                                                           const float *a_ref, float *shared) {
   __shared__ float part[kRedParts][kRedPix];
   const int nimg = (NN + kRedPix - 1) / kRedPix;
   const int tid = threadIdx.x;
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(kRedPix *kRedParts) void joint_reduce_kernel(int E,
     return;
   }
   __shared__ double lanes[kRedPix * kRedParts];
-  reduce_scalars(E, M, NN, g_cx_e, g_cy_e, chi2_e, a, shared, lanes, tid);
+  reduce_scalars(E, M, NN, g_cx_e, g_cy_e, chi2_e, a, a_ref, shared, lanes, tid);
 }
 
 // ---- kernel 3: regularisers, loss, AdaBelief -------------------------------------------------------
@@ -729,6 +733,7 @@ struct JointUpdArgs {
   // fused scalar reduction (multi-block update kernel, background fixed): block 0 first sums the per-epoch scalars
   // into shared_w, sparing the separate reduction launch
   int fuse_scalar_reduce;
+  const float *a_ref;              // [M] reference fluxes the moments of the shared block are centred on
   const float *g_cx_e, *g_cy_e, *chi2_e;
   float *shared_w;
   float *gout[LC_P_COUNT];         // gradient outputs (mode 0), nullable
@@ -831,7 +836,7 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
 #pragma unroll
     for (int p = 0; p < PX; ++p) pb[p] = 0.f;
     for (int i = 0; i < M; ++i) {
-      const float abar = (A.reg_mode == 1) ? pts_abar[i] : A.shared[NN + 2 * M + i] / Etot;
+      const float abar = (A.reg_mode == 1) ? pts_abar[i] : A.a_ref[i] + A.shared[NN + 2 * M + i] / Etot;
       const float X = c0 + A.ss * A.par[LC_P_CX][i], Y = c0 + A.ss * A.par[LC_P_CY][i];
       const float ty = (float)pu - Y;
 #pragma unroll
@@ -925,8 +930,8 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
     // flux uniformity: lam * sum_i std_e(a_{e,i}) over ALL epochs of the fit
     if (A.lam_fu != 0.f && Etot > 1.f)
       for (int i = 0; i < M; ++i) {
-        const double mean = A.shared[NN + 2 * M + i] / Etot;
-        const double var = fmax((double)A.shared[NN + 3 * M + i] / Etot - mean * mean, 0.0);
+        const double meanc = A.shared[NN + 2 * M + i] / Etot;  // centred on a_ref
+        const double var = fmax((double)A.shared[NN + 3 * M + i] / Etot - meanc * meanc, 0.0);
         loss += A.lam_fu * sqrt(var);
       }
     if (A.n_prior > 0)
@@ -967,10 +972,10 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
       ga -= A.lam_pos_ps;
     }
     if (A.lam_fu != 0.f && Etot > 1.f) {
-      const float mean = A.shared[NN + 2 * M + i] / Etot;
-      const float var = fmaxf(A.shared[NN + 3 * M + i] / Etot - mean * mean, 0.f);
+      const float meanc = A.shared[NN + 2 * M + i] / Etot;
+      const float var = fmaxf(A.shared[NN + 3 * M + i] / Etot - meanc * meanc, 0.f);
       const float sd = sqrtf(var);
-      if (sd > 0.f) ga += A.lam_fu * (av - mean) / (Etot * sd);
+      if (sd > 0.f) ga += A.lam_fu * ((av - A.a_ref[i]) - meanc) / (Etot * sd);
     }
     if (A.lam_pts != 0.f) ga += ptsg[i * 3] / Etot;
     if (A.mode == 0) {
@@ -997,7 +1002,7 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
     const int which = (tid < M) ? LC_P_CX : LC_P_CY, i = tid % M;
     float gv = A.shared[NN + (which == LC_P_CX ? 0 : M) + i];
     float cv = A.par[which][i];
-    if (A.lam_pts != 0.f) gv += (A.shared[NN + 2 * M + i] / Etot) * A.ss * ptsg[i * 3 + (which == LC_P_CX ? 1 : 2)];
+    if (A.lam_pts != 0.f) gv += (A.a_ref[i] + A.shared[NN + 2 * M + i] / Etot) * A.ss * ptsg[i * 3 + (which == LC_P_CX ? 1 : 2)];
     if (A.n_prior > 0) {
       const float mu = (which == LC_P_CX) ? A.prior_cx_mean[i] : A.prior_cy_mean[i];
       const float sg = (which == LC_P_CX) ? A.prior_cx_sigma[i] : A.prior_cy_sigma[i];

@@ -53,6 +53,17 @@ inline void adabelief_schedule(const lc_adabelief_cfg &ab, int t, float &lr, flo
     }                                                                                      \
   } while (0)
 
+// Every entry point that can allocate, launch or copy makes its context's device current first: the calling thread
+// may have another device current (two contexts in one process, a call from another thread).
+#define LC_ENTER(ctx)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = hipSetDevice((ctx)->device);                                           \
+    if (e_ != hipSuccess) {                                                                \
+      (ctx)->err = std::string("hipSetDevice: ") + hipGetErrorString(e_);                  \
+      return LC_ERR_DEVICE;                                                                \
+    }                                                                                      \
+  } while (0)
+
 #define LC_FAIL(ctx, code, msg) \
   do {                          \
     (ctx)->err = (msg);         \

@@ -415,6 +415,7 @@ int lc_psf_batch_create(lc_ctx *ctx, int F, int S_max, int n, int ss, const floa
 
 void lc_psf_batch_destroy(lc_psf_batch *b) {
   if (!b) return;
+  (void)hipSetDevice(b->ctx->device);
   hipStreamSynchronize(b->ctx->stream);
   for (void *p : b->allocs) hipFree(p);
   if (b->hist) hipFree(b->hist);
@@ -423,6 +424,7 @@ void lc_psf_batch_destroy(lc_psf_batch *b) {
 
 int lc_psf_batch_set_moffat(lc_psf_batch *b, const float *moffat) {
   if (!b || !moffat) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
   int rc = h2d(b, b->moffat, moffat, (size_t)b->F * 4 * sizeof(float));
   if (rc) return rc;
   hipLaunchKernelGGL(moffat_raster_kernel, dim3(b->F), dim3(256), 0, b->ctx->stream, b->N, b->ss, b->moffat, b->Tm);
@@ -431,18 +433,22 @@ int lc_psf_batch_set_moffat(lc_psf_batch *b, const float *moffat) {
 }
 int lc_psf_batch_get_moffat(lc_psf_batch *b, float *moffat) {
   if (!b || !moffat) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
   return d2h(b, moffat, b->moffat, (size_t)b->F * 4 * sizeof(float));
 }
 int lc_psf_batch_set_stars(lc_psf_batch *b, const float *stars) {
   if (!b || !stars) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
   return h2d(b, b->stars, stars, (size_t)b->F * b->S * 4 * sizeof(float));
 }
 int lc_psf_batch_get_stars(lc_psf_batch *b, float *stars) {
   if (!b || !stars) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
   return d2h(b, stars, b->stars, (size_t)b->F * b->S * 4 * sizeof(float));
 }
 int lc_psf_batch_set_grid(lc_psf_batch *b, const float *grid) {
   if (!b) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
   const size_t bytes = (size_t)b->F * b->N * b->N * sizeof(float);
   if (grid) return h2d(b, b->B, grid, bytes);
   LC_HIP(b->ctx, hipMemsetAsync(b->B, 0, bytes, b->ctx->stream));
@@ -455,10 +461,12 @@ int lc_psf_batch_set_grid(lc_psf_batch *b, const float *grid) {
 }
 int lc_psf_batch_get_grid(lc_psf_batch *b, float *grid) {
   if (!b || !grid) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
   return d2h(b, grid, b->B, (size_t)b->F * b->N * b->N * sizeof(float));
 }
 int lc_psf_batch_set_regularization(lc_psf_batch *b, const float *W, float lam_scales, float lam_hf) {
   if (!b) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
   b->lam_sc = lam_scales;
   b->lam_hf = lam_hf;
   if (W) {
@@ -482,6 +490,7 @@ noise_fn find_noise_kernel(int N, int ss) {
 
 int lc_psf_batch_propagate_noise(lc_psf_batch *b) {
   if (!b) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
   const int F = b->F, S = b->S, N = b->N, n = b->n, ss = b->ss, J = b->J;
   const size_t NN = (size_t)N * N, nn = (size_t)n * n;
   if (!std::getenv("LCMI_NOISE_HOST")) {
@@ -552,6 +561,7 @@ int lc_psf_batch_propagate_noise(lc_psf_batch *b) {
 }
 int lc_psf_batch_get_weights(lc_psf_batch *b, float *W) {
   if (!b || !W) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
   return d2h(b, W, b->W, (size_t)b->F * b->J * b->N * b->N * sizeof(float));
 }
 
@@ -580,6 +590,7 @@ int lc_psf_batch_eval(lc_psf_batch *b, float *loss, float *chi2, float *grad_mof
 
 int lc_psf_batch_fit_moffat(lc_psf_batch *b, int n_iter, float *final_loss) {
   if (!b || n_iter < 0) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
   const int F = b->F, S = b->S, D = 4 + 3 * S;
   std::vector<float> mof((size_t)F * 4), st((size_t)F * S * 4);
   int rc;
@@ -666,6 +677,7 @@ int lc_psf_batch_fit_moffat(lc_psf_batch *b, int n_iter, float *final_loss) {
 
 int lc_psf_batch_run_adabelief(lc_psf_batch *b, int n_iter, const lc_adabelief_cfg *cfg) {
   if (!b || n_iter <= 0) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
   int rc = ensure_hist(b, b->iters_done + n_iter + 1);
   if (rc) return rc;
   rc = launch_psf(b, 1, n_iter, cfg, false, true);
@@ -677,6 +689,7 @@ int lc_psf_batch_iterations_done(lc_psf_batch *b) { return b ? b->iters_done : L
 
 int lc_psf_batch_get_loss_history(lc_psf_batch *b, float *history, int stride) {
   if (!b || !history || stride < b->iters_done + 1) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
   int rc = launch_psf(b, 0, 1, nullptr, false, true);  // loss of the final parameters -> hist[T]
   if (rc) return rc;
   LC_HIP(b->ctx, hipMemcpy2DAsync(history, stride * sizeof(float), b->hist, b->hist_stride * sizeof(float),
@@ -687,6 +700,7 @@ int lc_psf_batch_get_loss_history(lc_psf_batch *b, float *history, int stride) {
 
 int lc_psf_batch_get_results(lc_psf_batch *b, float *narrow_psf, float *full_psf, float *residuals, float *chi2) {
   if (!b) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
   int rc = ensure_hist(b, b->iters_done + 1);
   if (rc) return rc;
   rc = launch_psf(b, 0, 1, nullptr, true, true);

@@ -3,7 +3,7 @@
 Per-epoch parameters (a, dx, dy, mean) and their optimiser state live only on the rank that owns the
 epoch; the shared parameters (h, c_x, c_y) are replicated.  Each iteration every rank runs the
 forward/backward of its epochs, the shared block
-    [ dL/dh (N^2) | dL/dc_x (M) | dL/dc_y (M) | sum_e a (M) | sum_e a^2 (M) | chi2 | n_epochs ]
+    [ dL/dh (N^2) | dL/dc_x (M) | dL/dc_y (M) | sum_e (a - ref) (M) | sum_e (a - ref)^2 (M) | chi2 | n_epochs ]
 is sum-all-reduced, and every rank applies the identical regularisation + AdaBelief update, so the
 replicas stay in lock step.  The reference has no counterpart: it keeps all epochs in
 one JAX array on one device (lightcurver/processes/roi_modelling.py:154-160,213).
@@ -54,6 +54,30 @@ class ShardedJointOptimizer:
         self.fit = local_fit
         self.group = group
         self._dev = None  # (tensor view of the shared block, torch ExternalStream of the library's stream)
+        self._ref_agreed = False
+
+    def _agree_flux_reference(self):
+        """The flux moments of the shared block are centred on one reference flux per source (include/lcmi.h):
+        every rank must use the same one, so the epoch-weighted mean of the local references is all-reduced once."""
+        self._ref_agreed = True
+        if not (hasattr(self.fit, 'get_flux_reference') and hasattr(self.fit, 'set_flux_reference')):
+            return
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        E = float(self.fit.E)
+        local = np.concatenate([np.asarray(self.fit.get_flux_reference(), np.float64) * E, [E]])
+        if dist.get_backend(self.group) == 'nccl':
+            _, device = self.fit.ctx.stream()
+            t = torch.tensor(local, dtype=torch.float64, device=torch.device('cuda', device))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            tot = t.cpu().numpy()
+        else:
+            t = torch.from_numpy(local)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            tot = t.numpy()
+        self.fit.set_flux_reference((tot[:-1] / tot[-1]).astype(np.float32))
 
     def _device_collective(self):
         """RCCL path: available when the process group is nccl and the fit is a device object."""
@@ -91,6 +115,8 @@ class ShardedJointOptimizer:
 
     def run(self, n_iter, **adabelief_cfg):
         on_device = bool(self._device_collective())
+        if not self._ref_agreed:
+            self._agree_flux_reference()
         for _ in range(int(n_iter)):
             self.fit.step_local()
             if on_device:

@@ -50,6 +50,17 @@ class JointFit:
             out[k] = arr
         return out
 
+    def set_flux_reference(self, ref):
+        """Reference flux per source the flux moments of the shared block are centred on (set_params(a=...) sets the
+        local mean; every rank of a sharded fit must use the same values)."""
+        r = f32(np.ravel(ref))
+        self._chk(self._l.lc_joint_set_flux_reference(self.h, ptr(r), r.size), 'set_flux_reference')
+
+    def get_flux_reference(self):
+        r = np.empty(self.M, np.float32)
+        self._chk(self._l.lc_joint_get_flux_reference(self.h, ptr(r), r.size), 'get_flux_reference')
+        return r
+
     def set_free(self, free):
         mask = (C.c_int32 * P_COUNT)(*[1 if name in free else 0 for name in
                                        ('a', 'c_x', 'c_y', 'dx', 'dy', 'alpha', 'h', 'mean')])

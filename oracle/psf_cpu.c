@@ -1,0 +1,291 @@
+/* CPU restatement (plain C, fp32, OpenMP over frames) of the pixel-grid stage of the PSF fit.
+ *
+ * TEST / MEASUREMENT INFRASTRUCTURE ONLY (see oracle/__init__.py): this file is the "port" CPU baseline of
+ * bench.py (cpu_baseline.kind = "port") and a second, independent checker of the HIP path in tests/.  The product
+ * path never links, loads or calls it.  PARITY UNPINNED against STARRED itself: it restates
+ * the same frozen SPEC as oracle/model.py, and tests/test_psf_cpu_port_cpu.py pins it to that float64 oracle.
+ *
+ * What it restates (reference call site: lightcurver/processes/psf_modelling.py:164-171, build_psf(...,
+ * n_iter_adabelief=...) -- stage B of STARRED's build_psf):
+ *     f_i = a_i * D_ss[ G(x0_i, y0_i) (*) (Moffat + B) ] + sky_i                      (oracle/model.py psf_model)
+ *     L   = 1/2 sum w (d - f)^2 + lam_hf sum W_0 |w_0(B)| + lam_sc sum_{1<=j<J} W_j |w_j(B)|   (psf_loss)
+ *     AdaBelief (optax: b1 .9, b2 .999, eps 1e-16, eps_root 1e-16, lr_t = lr0 * 0.99^(t/10)) on B, a, x0, y0
+ *                                                                                      (oracle/optim.py adabelief)
+ * in the direct separable form: G is the FWHM-2 Gaussian, so the convolution is a 1-D row pass fused with the
+ * column down-sampling, then a 1-D column pass fused with the row down-sampling; the gradient runs the two
+ * transposed passes; the starlet is the edge-replicating a-trous B3 transform with its exact adjoint.
+ * The Gaussian is truncated at +-KRG samples around its rounded centre (exp(-25) relative: below fp32 resolution).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define KRG 6
+#define SIGMA_G 0.84932180028801907f
+#define MAXT (2 * KRG + 1)
+
+static int ilog2i(int n) { int j = 0; while (n > 1) { n >>= 1; ++j; } return j; }
+
+/* taps g(t - delta), dg/ddelta for t = o - KRG .. o + KRG, o = round(delta) */
+static void taps(float delta, int *o, float *g, float *dg) {
+  const float inv_s2 = 1.0f / (SIGMA_G * SIGMA_G), nrm = 0.3989422804014327f / SIGMA_G;
+  *o = (int)nearbyintf(delta);
+  for (int k = 0; k < MAXT; ++k) {
+    const float x = (float)(*o - KRG + k) - delta;
+    g[k] = nrm * expf(-0.5f * x * x * inv_s2);
+    dg[k] = g[k] * x * inv_s2;
+  }
+}
+
+/* one edge-replicating 5-tap a-trous pass (dilation d) along rows (axis = 1) or columns (axis = 0) */
+static void atrous(const float *in, float *out, int N, int d, int axis) {
+  static const float b3[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+  for (int u = 0; u < N; ++u)
+    for (int v = 0; v < N; ++v) {
+      float acc = 0.f;
+      for (int t = -2; t <= 2; ++t) {
+        int uu = u, vv = v;
+        if (axis) { vv = v + t * d; vv = vv < 0 ? 0 : (vv > N - 1 ? N - 1 : vv); }
+        else { uu = u + t * d; uu = uu < 0 ? 0 : (uu > N - 1 ? N - 1 : uu); }
+        acc += b3[t + 2] * in[uu * N + vv];
+      }
+      out[u * N + v] = acc;
+    }
+}
+/* exact adjoint of atrous(): scatter through the same clamped indices */
+static void atrous_adj(const float *gout, float *gin, int N, int d, int axis) {
+  static const float b3[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+  memset(gin, 0, sizeof(float) * (size_t)N * N);
+  for (int u = 0; u < N; ++u)
+    for (int v = 0; v < N; ++v) {
+      const float g = gout[u * N + v];
+      for (int t = -2; t <= 2; ++t) {
+        int uu = u, vv = v;
+        if (axis) { vv = v + t * d; vv = vv < 0 ? 0 : (vv > N - 1 ? N - 1 : vv); }
+        else { uu = u + t * d; uu = uu < 0 ? 0 : (uu > N - 1 ? N - 1 : uu); }
+        gin[uu * N + vv] += b3[t + 2] * g;
+      }
+    }
+}
+
+typedef struct {
+  float *T, *gB, *tmp, *tmpx, *V, *res, *c, *r, *cn, *q, *z, *y, *y2;
+} Work;
+
+static int work_alloc(Work *w, int N, int n, int J) {
+  const size_t NN = (size_t)N * N;
+  w->T = malloc(sizeof(float) * NN);
+  w->gB = malloc(sizeof(float) * NN);
+  w->tmp = malloc(sizeof(float) * (size_t)N * n);
+  w->tmpx = malloc(sizeof(float) * (size_t)N * n);
+  w->V = malloc(sizeof(float) * (size_t)N * n);
+  w->res = malloc(sizeof(float) * (size_t)n * n);
+  w->c = malloc(sizeof(float) * NN);
+  w->r = malloc(sizeof(float) * NN);
+  w->cn = malloc(sizeof(float) * NN);
+  w->q = malloc(sizeof(float) * NN * (size_t)J);
+  w->z = malloc(sizeof(float) * NN);
+  w->y = malloc(sizeof(float) * NN);
+  w->y2 = malloc(sizeof(float) * NN);
+  return w->T && w->gB && w->tmp && w->tmpx && w->V && w->res && w->c && w->r && w->cn && w->q && w->z && w->y && w->y2;
+}
+static void work_free(Work *w) {
+  free(w->T); free(w->gB); free(w->tmp); free(w->tmpx); free(w->V); free(w->res); free(w->c); free(w->r); free(w->cn);
+  free(w->q); free(w->z); free(w->y); free(w->y2);
+}
+
+/* loss and gradients of one frame at the current parameters.  gs[S][3] = dL/da, dL/dx0, dL/dy0; gB += chi2 part,
+ * z = l1 sub-gradient.  model_out (nullable) [S][n][n]. */
+static float frame_eval(int S, int n, int ss, const float *data, const float *wgt, const float *Tm, const float *W,
+                        const float *B, const float *stars, float lam_sc, float lam_hf, Work *w, float *gs,
+                        float *model_out, float *chi2_out) {
+  const int N = n * ss, J = ilog2i(N);
+  const size_t NN = (size_t)N * N;
+  const float c_off = (N % 2 == 0) ? 0.5f : 0.0f;
+  for (size_t i = 0; i < NN; ++i) { w->T[i] = Tm[i] + B[i]; w->gB[i] = 0.f; }
+  double chi2 = 0.0;
+  for (int s = 0; s < S; ++s) {
+    const float a = stars[s * 4 + 0], x0 = stars[s * 4 + 1], y0 = stars[s * 4 + 2], sky = stars[s * 4 + 3];
+    float gx[MAXT], dgx[MAXT], gy[MAXT], dgy[MAXT];
+    int ox, oy;
+    taps(ss * x0 + c_off, &ox, gx, dgx);
+    taps(ss * y0 + c_off, &oy, gy, dgy);
+    /* row pass + column down-sampling: tmp[u][jd] = sum_dv sum_k gx[k] T[u][ss jd + dv - t_k] */
+    for (int u = 0; u < N; ++u)
+      for (int jd = 0; jd < n; ++jd) {
+        float acc = 0.f, accx = 0.f;
+        for (int dv = 0; dv < ss; ++dv) {
+          const int base = ss * jd + dv - ox + KRG;  /* v = base - k must lie in [0, N) */
+          const int k0 = base - (N - 1) > 0 ? base - (N - 1) : 0, k1 = base < MAXT - 1 ? base : MAXT - 1;
+          const float *Tr = w->T + u * N + base;
+          for (int k = k0; k <= k1; ++k) { acc += gx[k] * Tr[-k]; accx += dgx[k] * Tr[-k]; }
+        }
+        w->tmp[u * n + jd] = acc;
+        w->tmpx[u * n + jd] = accx;
+      }
+    /* column pass + row down-sampling, residuals, chi2, star gradients */
+    double ga = 0.0, ggx = 0.0, ggy = 0.0;
+    const float *d = data + (size_t)s * n * n, *wg = wgt + (size_t)s * n * n;
+    for (int id = 0; id < n; ++id)
+      for (int jd = 0; jd < n; ++jd) {
+        float fv = 0.f, fx = 0.f, fy = 0.f;
+        for (int du = 0; du < ss; ++du) {
+          const int base = ss * id + du - oy + KRG;
+          const int k0 = base - (N - 1) > 0 ? base - (N - 1) : 0, k1 = base < MAXT - 1 ? base : MAXT - 1;
+          for (int k = k0; k <= k1; ++k) {
+            const int u = base - k;
+            fv += gy[k] * w->tmp[u * n + jd];
+            fy += dgy[k] * w->tmp[u * n + jd];
+            fx += gy[k] * w->tmpx[u * n + jd];
+          }
+        }
+        const float model = a * fv + sky;
+        const float r = model - d[id * n + jd], rw = wg[id * n + jd] * r;
+        chi2 += (double)rw * r;
+        ga += (double)rw * fv;
+        ggx += (double)rw * fx;
+        ggy += (double)rw * fy;
+        w->res[id * n + jd] = rw;
+        if (model_out) model_out[(size_t)s * n * n + id * n + jd] = model;
+      }
+    gs[s * 3 + 0] = (float)ga;
+    gs[s * 3 + 1] = (float)(ggx * a * ss);
+    gs[s * 3 + 2] = (float)(ggy * a * ss);
+    /* transposed column pass: V[u][jd] = sum_id gy(ss id + du - u) rw[id][jd] */
+    memset(w->V, 0, sizeof(float) * (size_t)N * n);
+    for (int id = 0; id < n; ++id)
+      for (int du = 0; du < ss; ++du)
+        for (int k = 0; k < MAXT; ++k) {
+          const int u = ss * id + du - (oy - KRG + k);
+          if (u < 0 || u >= N) continue;
+          const float g = gy[k];
+          for (int jd = 0; jd < n; ++jd) w->V[u * n + jd] += g * w->res[id * n + jd];
+        }
+    /* transposed row pass into dchi2/dB */
+    for (int u = 0; u < N; ++u)
+      for (int jd = 0; jd < n; ++jd) {
+        const float vv = a * w->V[u * n + jd];
+        for (int dv = 0; dv < ss; ++dv) {
+          const int base = ss * jd + dv - ox + KRG;
+          const int k0 = base - (N - 1) > 0 ? base - (N - 1) : 0, k1 = base < MAXT - 1 ? base : MAXT - 1;
+          float *gr = w->gB + u * N + base;
+          for (int k = k0; k <= k1; ++k) gr[-k] += gx[k] * vv;
+        }
+      }
+  }
+  /* starlet l1 of B: value, sub-gradient z through the exact adjoint */
+  double l1 = 0.0;
+  memset(w->z, 0, sizeof(float) * NN);
+  if (lam_sc != 0.f || lam_hf != 0.f) {
+    memcpy(w->c, B, sizeof(float) * NN);
+    for (int j = 0; j < J; ++j) {
+      const int dd = 1 << j;
+      const float lam = (j == 0) ? lam_hf : lam_sc;
+      atrous(w->c, w->r, N, dd, 1);
+      atrous(w->r, w->cn, N, dd, 0);
+      float *q = w->q + (size_t)j * NN;
+      const float *Wj = W + (size_t)j * NN;
+      for (size_t i = 0; i < NN; ++i) {
+        const float wv = w->c[i] - w->cn[i], lw = lam * Wj[i];
+        l1 += (double)lw * fabsf(wv);
+        q[i] = (wv > 0.f) ? lw : ((wv < 0.f) ? -lw : 0.f);
+      }
+      memcpy(w->c, w->cn, sizeof(float) * NN);
+    }
+    /* z_J = 0; z_j = q_j + Row_j^T Col_j^T (z_{j+1} - q_j) */
+    for (int j = J - 1; j >= 0; --j) {
+      const int dd = 1 << j;
+      const float *q = w->q + (size_t)j * NN;
+      for (size_t i = 0; i < NN; ++i) w->y[i] = w->z[i] - q[i];
+      atrous_adj(w->y, w->y2, N, dd, 0);
+      atrous_adj(w->y2, w->y, N, dd, 1);
+      for (size_t i = 0; i < NN; ++i) w->z[i] = q[i] + w->y[i];
+    }
+  }
+  if (chi2_out) *chi2_out = (float)chi2;
+  return (float)(0.5 * chi2 + l1);
+}
+
+static void adabelief_step(float *p, float *m, float *s, float g, float lr, float bc1, float bc2) {
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-16f, eps_root = 1e-16f;
+  const float mn = b1 * *m + (1.f - b1) * g;
+  const float dg = g - mn;
+  const float sn = b2 * *s + (1.f - b2) * dg * dg + eps_root;
+  *m = mn;
+  *s = sn;
+  *p -= lr * (mn * bc1) / (sqrtf(sn * bc2) + eps);
+}
+
+/* n_iter AdaBelief iterations on B, a, x0, y0 of every frame (state in / out).  loss_hist[F][n_iter + 1]:
+ * loss before each update, then the loss of the final parameters.  Returns 0, or -1 on allocation failure. */
+int psf_cpu_run(int F, int S, int n, int ss, const float *data, const float *wgt, const float *Tm, const float *W,
+                float *B, float *mB, float *sB, float *stars, float *stars_m, float *stars_s, float lam_sc,
+                float lam_hf, float lr0, int schedule, int t0, int n_iter, float *loss_hist, int n_threads) {
+  const int N = n * ss, J = ilog2i(N);
+  const size_t NN = (size_t)N * N, nn = (size_t)n * n;
+  int fail = 0;
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+#pragma omp parallel
+  {
+    Work w;
+    float *gs = malloc(sizeof(float) * (size_t)S * 3);
+    if (!work_alloc(&w, N, n, J) || !gs) {
+#pragma omp atomic write
+      fail = 1;
+    } else {
+#pragma omp for schedule(dynamic, 1)
+      for (int f = 0; f < F; ++f) {
+        const float *df = data + (size_t)f * S * nn, *wf = wgt + (size_t)f * S * nn, *Tf = Tm + (size_t)f * NN;
+        const float *Wf = W + (size_t)f * J * NN;
+        float *Bf = B + (size_t)f * NN, *mf = mB + (size_t)f * NN, *sf = sB + (size_t)f * NN;
+        float *st = stars + (size_t)f * S * 4, *stm = stars_m + (size_t)f * S * 4, *sts = stars_s + (size_t)f * S * 4;
+        for (int it = 0; it <= n_iter; ++it) {
+          const float loss = frame_eval(S, n, ss, df, wf, Tf, Wf, Bf, st, lam_sc, lam_hf, &w, gs, NULL, NULL);
+          loss_hist[(size_t)f * (n_iter + 1) + it] = loss;
+          if (it == n_iter) break;
+          const int t = t0 + it;
+          const double lr = schedule ? (double)lr0 * pow(0.99, (double)t / 10.0) : (double)lr0;
+          const float bc1 = (float)(1.0 / (1.0 - pow(0.9, t + 1))), bc2 = (float)(1.0 / (1.0 - pow(0.999, t + 1)));
+          for (size_t i = 0; i < NN; ++i) adabelief_step(&Bf[i], &mf[i], &sf[i], w.gB[i] + w.z[i], (float)lr, bc1, bc2);
+          for (int s = 0; s < S; ++s)
+            for (int q = 0; q < 3; ++q)
+              adabelief_step(&st[s * 4 + q], &stm[s * 4 + q], &sts[s * 4 + q], gs[s * 3 + q], (float)lr, bc1, bc2);
+        }
+      }
+    }
+    work_free(&w);
+    free(gs);
+  }
+  return fail ? -1 : 0;
+}
+
+/* one evaluation per frame: loss [F], chi2 [F], grad_grid [F][N*N] (regularisation included), grad_stars [F][S][3],
+ * model [F][S][n][n] (nullable outputs) */
+int psf_cpu_eval(int F, int S, int n, int ss, const float *data, const float *wgt, const float *Tm, const float *W,
+                 const float *B, const float *stars, float lam_sc, float lam_hf, float *loss, float *chi2,
+                 float *grad_grid, float *grad_stars, float *model) {
+  const int N = n * ss, J = ilog2i(N);
+  const size_t NN = (size_t)N * N, nn = (size_t)n * n;
+  Work w;
+  float *gs = malloc(sizeof(float) * (size_t)S * 3);
+  if (!work_alloc(&w, N, n, J) || !gs) return -1;
+  for (int f = 0; f < F; ++f) {
+    float c2 = 0.f;
+    const float L = frame_eval(S, n, ss, data + (size_t)f * S * nn, wgt + (size_t)f * S * nn, Tm + (size_t)f * NN,
+                               W + (size_t)f * J * NN, B + (size_t)f * NN, stars + (size_t)f * S * 4, lam_sc, lam_hf, &w,
+                               gs, model ? model + (size_t)f * S * nn : NULL, &c2);
+    if (loss) loss[f] = L;
+    if (chi2) chi2[f] = c2;
+    if (grad_grid)
+      for (size_t i = 0; i < NN; ++i) grad_grid[(size_t)f * NN + i] = w.gB[i] + w.z[i];
+    if (grad_stars) memcpy(grad_stars + (size_t)f * S * 3, gs, sizeof(float) * (size_t)S * 3);
+  }
+  work_free(&w);
+  free(gs);
+  return 0;
+}

@@ -122,19 +122,19 @@ def test_c5_shard_loss_and_gradients_match_oracle(ctx, c5_shard):
 def test_c5_shard_fit_decreases_the_loss_and_is_deterministic(ctx, c5_shard):
     from lightcurver_amd.joint import JointFit
     ds, p = c5_shard
-    E, M, n, ss, T = 125, 4, 128, 2, 12
-    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean']
+    E, M, n, ss, T = 125, 4, 128, 2, 60
+    free = ['a', 'dx', 'dy', 'h', 'mean']
     runs = []
     for rep in range(2):
         j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
-        j.set_params(**dict(p, a=0.8 * p['a']))
+        j.set_params(**dict(p, a=0.8 * p['a'], h=np.zeros_like(p['h'])))
         j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
         j.set_free(free)
         j.run_adabelief(T, init_learning_rate=2e-3)
         runs.append((j.loss_history(), j.get_params()))
         j.close()
     h = runs[0][0]
-    assert h.shape == (T + 1,) and np.all(np.isfinite(h)) and h[-1] < h[0]
+    assert h.shape == (T + 1,) and np.all(np.isfinite(h)) and h[-1] < 0.7 * h[0]
     np.testing.assert_array_equal(runs[0][0], runs[1][0])          # fixed-order reductions: bit-identical reruns
     np.testing.assert_array_equal(runs[0][1]['h'], runs[1][1]['h'])
     got = runs[0][1]['a']

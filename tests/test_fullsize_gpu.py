@@ -67,15 +67,16 @@ def test_c4_sharded_steps_equal_the_unsharded_fit(ctx):
     free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean']
     full, p = _joint(ctx, ds)
     full.set_params(**p)
-    full.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0)
+    full.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_flux_uniformity=0.5)
     full.set_free(free)
     full.run_adabelief(T, init_learning_rate=1e-3)
     shards = []
     for idx in (np.arange(0, 100), np.arange(100, 200)):
         j, q = _joint(ctx, ds, idx)
         j.set_params(**q)
-        j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0)
+        j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_flux_uniformity=0.5)
         j.set_free(free)
+        j.set_flux_reference(full.get_flux_reference())  # one reference for every shard (distributed.py does this)
         shards.append(j)
     for _ in range(T):
         bufs = []

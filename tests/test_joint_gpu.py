@@ -172,3 +172,39 @@ def test_adabelief_trajectory_with_point_source_starlet_term(ctx, n, with_h):
     got2 = j.get_params()
     assert H.rel_err(got2['a'], got['a']) < 1e-5
     assert np.abs(got2['c_x'] - got['c_x']).max() < 1e-5 and np.abs(got2['c_y'] - got['c_y']).max() < 1e-5
+
+
+@pytest.mark.parametrize('sigma_rel', [1e-4, 1e-2])
+def test_flux_uniformity_with_small_scatter(ctx, sigma_rel):
+    """regularization_strength_flux_uniformity = lam * sum_i std_e(a_{e,i}) (jnp.std is two-pass; the reference's ROI
+    fit starts with all fluxes of a source equal, roi_modelling.py:236-239,273-276).  With a relative scatter of 1e-4
+    the variance <a^2> - <a>^2 cancels to nothing in fp32; the device sums the moments centred on a reference flux
+    (csrc/joint_kernels.h, kernel 2), so value and gradient must still follow the oracle."""
+    from lightcurver_amd.joint import JointFit
+    E, M, n, ss = 24, 2, 16, 2
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=77)
+    rng = np.random.default_rng(78)
+    p = {k: np.array(v, dtype=np.float64) for k, v in ds['truth'].items()}
+    base = p['a'].reshape(E, M).mean(axis=0)
+    p['a'] = (base[None, :] * (1.0 + sigma_rel * rng.standard_normal((E, M)))).reshape(-1)
+    p['a'] = p['a'].astype(np.float32).astype(np.float64)  # the values the device actually holds
+    j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
+    j.set_params(**p)
+    free = ['a']
+    j.set_free(free)
+    po = {k: om.T(v) for k, v in p.items()}
+    data, sig2, psf = om.T(ds['data']), om.T(ds['noisemap']) ** 2, om.T(ds['psf'])
+    out = {}
+    for lam in (0.0, 10.0):
+        j.set_loss(lam_flux_uniformity=lam)
+        L, g = oo.value_and_grad(lambda q: om.deconv_loss(q, data, sig2, psf, ss, lam_fu=lam), po, free)
+        loss, grads = j.loss_grad(free)
+        out[lam] = (float(L), g['a'].numpy(), loss, grads['a'])
+    # the term alone (difference of the two evaluations): value and gradient
+    term_o, term_d = out[10.0][0] - out[0.0][0], out[10.0][2] - out[0.0][2]
+    g_o, g_d = out[10.0][1] - out[0.0][1], out[10.0][3].astype(np.float64) - out[0.0][3]
+    assert term_o > 0
+    assert abs(out[10.0][2] - out[10.0][0]) / abs(out[10.0][0]) < 3e-5
+    assert H.rel_err(out[10.0][3], out[10.0][1]) < 1e-4
+    # the chi2 gradient (~1e2..1e4) dwarfs the term's (lam / (E std) * (a - mean) ~ lam / E): isolate it with its own bound
+    assert np.abs(g_d - g_o).max() < 2e-3 * np.abs(g_o).max() + 2e-6 * np.abs(out[0.0][1]).max()
