@@ -9,7 +9,7 @@ from lightcurver_amd.synthetic import make_psf_dataset
 from tests import helpers as H
 
 
-def _problem(n, ss, S, F, seed, jitter=0.2):
+def _problem(n, ss, S, F, seed, jitter=0.2, double=False):
     ds = make_psf_dataset(F=F, S=S, n=n, ss=ss, seed=seed)
     rng = np.random.default_rng(seed + 1)
     plist = [H.psf_initial_params(ds, f, ss, rng, jitter) for f in range(F)]
@@ -21,7 +21,12 @@ def _problem(n, ss, S, F, seed, jitter=0.2):
         data, sig2, mask = H.psf_oracle_inputs(ds, f, ss)
         Ws.append(om.propagate_noise_psf(plist[f], sig2, mask, ss))
     st = psf_cpu.PsfCpuState(ds['data'], H.weights_from(ds), ss, Tm, np.stack([w[:J].numpy() for w in Ws]),
-                             np.stack([p['B'].numpy() for p in plist]), H.stars_array(plist))
+                             np.stack([p['B'].numpy() for p in plist]),
+                             H.stars_array(plist).astype(np.float64) if not double else
+                             np.stack([np.stack([p['a'].numpy(), p['x0'].numpy(), p['y0'].numpy(), p['sky'].numpy()], axis=-1)
+                                       for p in plist]), double=double)
+    if double:  # weights in full precision (helpers.weights_from rounds them to fp32 for the C ABI of the HIP path)
+        st.wgt[...] = ds['masks'] / ds['noisemap'].astype(np.float64) ** 2
     return ds, plist, Ws, st
 
 
@@ -55,3 +60,35 @@ def test_c_port_trajectory_matches_the_float64_oracle():
         assert np.abs(hist[f] - ref).max() / np.abs(ref).max() < 1e-4
         assert H.rel_err(st.stars[f][:, 0], pf['a'].numpy()) < 1e-5
         assert np.median(np.abs(st.B[f] - pf['B'].numpy())) < 1e-7
+
+
+def test_two_float64_implementations_agree_but_fp32_trajectories_drift():
+    """What the north-star tolerance 'residual chi2 within 1e-5' can and cannot mean for the l1-regularised pixel-grid fit.
+
+    (1) The float64 build of the C restatement (direct separable sums, hand-derived adjoints) and the float64 torch
+        oracle (FFT convolution, autograd) share no arithmetic, yet after 1000 AdaBelief iterations at the reference's
+        learning rate their losses agree to 1e-9 and their fluxes to 1e-11: the restated optimisation is a
+        well-conditioned, deterministic map in float64.
+    (2) The fp32 build of the same C code, run on the same inputs, ends 1e-6 .. 1e-3 away in the loss: rounding at the
+        6e-8 level is amplified ~1e3 x over the iterations (AdaBelief with eps = 1e-16 turns gradients that are within
+        rounding of their running mean into full-size steps).  No fp32 implementation - this one, the HIP kernels, or
+        the reference's own float32 JAX run on another machine - can therefore reproduce a float64 chi2 to 1e-5 after
+        thousands of iterations; fluxes and positions, which the data constrain, stay within the 1e-4 the north star
+        asks for.  tests/test_north_star_gpu.py asserts exactly this split for the HIP path."""
+    n, ss, S, F, T = 16, 2, 5, 2, 1000
+    ds, plist, Ws, st64 = _problem(n, ss, S, F, 2025, jitter=0.2, double=True)
+    _, _, _, st32 = _problem(n, ss, S, F, 2025, jitter=0.2)
+    h64 = st64.run_adabelief(T, lr0=1e-4, schedule=True, threads=2)
+    h32 = st32.run_adabelief(T, lr0=1e-4, schedule=True, threads=2)
+    for f in range(F):
+        data, sig2, mask = H.psf_oracle_inputs(ds, f, ss)
+        fn = lambda q: om.psf_loss(q, data, sig2, mask, ss, W=Ws[f], lam_scales=1.0, lam_hf=1.0)
+        pf, lh, l0 = oo.adabelief(fn, plist[f], ['B', 'a', 'x0', 'y0'], 1e-4, T, schedule=True)
+        ref = np.array([l0] + lh)
+        assert np.abs(h64[f] - ref).max() / np.abs(ref).max() < 1e-9
+        assert H.rel_err(st64.stars[f][:, 0], pf['a'].numpy()) < 1e-11
+        assert np.abs(st64.B[f] - pf['B'].numpy()).max() < 1e-11
+        d32 = abs(h32[f, -1] - ref[-1]) / ref[-1]
+        assert 1e-7 < d32 < 5e-3, d32                                     # drifts, but stays a small number
+        assert H.rel_err(st32.stars[f][:, 0], pf['a'].numpy()) < 1e-4    # fluxes: north-star level
+        assert np.abs(st32.stars[f][:, 1] - pf['x0'].numpy()).max() < 1e-4
