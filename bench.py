@@ -294,8 +294,13 @@ def sharded_joint_fit(ctx, rank, world, iters=500):
     j.set_params(**p)
     j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
     j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
-    torch.cuda.set_device(ctx.stream()[1])
-    group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=180))
+    if os.environ.get('LCMI_BENCH_DEVICE') is not None:
+        # one-GPU rehearsal (every rank on the same device): RCCL refuses two ranks on one GPU, so the shared block
+        # is staged through the host over the gloo group
+        group = None
+    else:
+        torch.cuda.set_device(ctx.stream()[1])
+        group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=180))
     opt = ShardedJointOptimizer(j, group)
     ab = dict(init_learning_rate=1e-4, schedule_learning_rate=False)
     opt.run(10, **ab)

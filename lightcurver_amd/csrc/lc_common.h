@@ -13,7 +13,7 @@ namespace lc {
 // Target resolution of the two-channel (MCS-style) scheme: Gaussian of FWHM 2 high-res pixels.
 constexpr float kGaussFwhm = 2.0f;
 constexpr float kSigmaG = 0.84932180028801907f;  // 2 / (2 sqrt(2 ln 2))
-constexpr int kRg = 6;                           // half support of the sampled Gaussian (7 sigma)
+constexpr int kRg = 5;                           // half support of the sampled Gaussian: the first dropped sample is >= 5.5 px = 6.5 sigma away (8e-10 of the peak)
 constexpr int kWave = 64;
 
 __host__ __device__ constexpr int ntaps(int ss) { return 2 * kRg + 1 + 2 * (ss - 1); }

@@ -77,7 +77,14 @@ __device__ __forceinline__ float load_sc1_f(const float *p) {
   return v;
 }
 
-template <int N_, int SS_, int PX_, int SG_, bool WC_ = false>
+// Packed fp32 arithmetic (v_pk_fma_f32: two FMAs per lane and instruction).  The separable passes are bound by VALU
+// issue, so they are written in forms whose operands pair up in aligned 64-bit registers: two taps of one output
+// (row pass, transposed column pass), or value and derivative taps of one sample (column pass, transposed row pass).
+typedef float lc_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lc_v2f pk_fma(lc_v2f a, lc_v2f b, lc_v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ lc_v2f pk_bcast(float v) { return (lc_v2f){v, v}; }
+
+template <int N_, int SS_, int PX_, int SG_, bool WC_ = false, int JB_ = 8>
 struct PsfCfg {
   static constexpr int N = N_, SS = SS_, PX = PX_, SG = SG_;
   // WC: the row pass, column pass and transposed column pass of one (star, block of JB down-sampled columns)
@@ -102,34 +109,40 @@ struct PsfCfg {
   // transposed row pass reads out-of-stamp samples as zeros through a clamped index, without selects
   static constexpr int VS = WC_ ? n + 3 : RS, VO = WC_ ? 1 : 0;
   static constexpr int SZ_V = SG * N * VS;
-  static constexpr int JB = LR;                       // down-sampled columns per wave task (WC)
+  static constexpr int JB = JB_;                      // down-sampled columns per wave task (WC)
   // WC tiles carry zero aprons so that the filter windows are read without clamping or selects.  The star
   // offsets are limited to +-N/4 high-res pixels (tap_entry), which bounds every window by AP / APR.
   static constexpr int AP = N / 4 + 10;               // apron of N-long rows (high-res pixels)
   static constexpr int TSA = N + 2 * AP + 1;          // row stride of T, R2, R2x in the WC layout
   static constexpr int APR = AP / SS + 2;             // apron of the residual rows (data pixels)
-  static constexpr int WSZ = 2 * JB * TSA + (n + 2 * APR) * JB;  // per-wave scratch: R2, R2x [JB][TSA], residuals [n+2APR][JB]
+  static constexpr int WSZ = JB * TSA + (n + 2 * APR) * JB;  // per-wave scratch: R2 [JB][TSA], residuals [n+2APR][JB]
   static constexpr int SZ_VR = (SZ_V > StarletLds<N>::FLOATS) ? SZ_V : StarletLds<N>::FLOATS;  // V, reused by the starlet
   static constexpr int OFF_WSC = OFF_R + SZ_VR;
   static constexpr int SZ_R = WC ? (SZ_VR + NW * WSZ) : ((2 * SZ_R2 > SZ_V) ? 2 * SZ_R2 : SZ_V);
   static constexpr int OFF_RES = OFF_R + SZ_R;
   static constexpr int SZ_RES = WC ? 0 : SG * n * n;
   static constexpr int OFF_TAPS = OFF_RES + SZ_RES;
-  static constexpr int SZ_TAPS = 16 * 4 * NT;  // every star of the frame
+  // tap rows are padded: [0] = 0, [1 + k] = tap k, [NT + 1] = [NT + 2] = 0, so that the paired-tap forms of the
+  // passes read their out-of-range partner as a zero
+  static constexpr int NTP = NT + 3;
+  static constexpr int SZ_TAPS = 16 * 4 * NTP;  // every star of the frame
   static constexpr int OFF_RED = OFF_TAPS + SZ_TAPS;
   static constexpr int IPS = n * n / LC;  // column-pass items per star
   static constexpr int IPS_PAD = (IPS + kWave - 1) / kWave * kWave;
   static constexpr int SLOTS = IPS_PAD / kWave;
-  static constexpr int SZ_RED = (WC ? 16 * (n / JB) * 5 : SG * SLOTS * 5) + NW + 8;
-  static constexpr int OFF_REDW = OFF_RED + (WC ? 16 * (n / JB) * 5 : SG * SLOTS * 5);
+  static constexpr int SZ_REDX = WC ? 16 * NW : 0;  // per-(star, wave) partial sums of the x0 gradient (transposed row pass)
+  static constexpr int SZ_RED = (WC ? 16 * (n / JB) * 5 : SG * SLOTS * 5) + SZ_REDX + NW + 8;
+  static constexpr int OFF_REDX = OFF_RED + (WC ? 16 * (n / JB) * 5 : SG * SLOTS * 5);
+  static constexpr int OFF_REDW = OFF_REDX + SZ_REDX;
   static constexpr int OFF_STAR = OFF_RED + SZ_RED;  // star params, grads, moments, ints
   static constexpr int MAXS = 16;
   static constexpr int SZ_STAR = MAXS * 20 + 16;
   static constexpr int LDS_FLOATS = OFF_STAR + SZ_STAR;
   static_assert(WC || StarletLds<N>::FLOATS <= SZ_T + SZ_R + SZ_RES, "starlet ping-pong buffers must fit over T + R + RES");
-  static_assert(PX % SS == 0 && N % PX == 0 && n % LR == 0 && n % LC == 0 && n % LA == 0, "tiling");
+  static_assert(PX % SS == 0 && N % PX == 0 && n % LR == 0 && n % LC == 0 && n % LA == 0 && n % JB == 0, "tiling");
   static_assert(LDS_FLOATS * 4 <= 163840, "LDS");
   static_assert(NTHR <= 1024 && NTHR % kWave == 0, "threads");
+  static_assert(!WC_ || PX_ <= 8, "the WC layout keeps the pixel state in registers");
 };
 
 
@@ -176,7 +189,9 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
   float *R2xt = R2t + C::SZ_R2;
   float *V = lds + C::OFF_R;
   float *RES = lds + C::OFF_RES;
-  float *TAPS = lds + C::OFF_TAPS;  // [S][4][NT]: tx, dtx, ty, dty
+  float *TAPS = lds + C::OFF_TAPS + 1;  // [S][4][NTP], entry k of a row at [k] (one zero in front, two behind): tx, dtx, ty, dty
+  constexpr int NTP = C::NTP;
+  float *REDX = lds + C::OFF_REDX;
   float *RED = lds + C::OFF_RED;    // [SG][SLOTS][5] + [NW] + scalars
   float *REDW = lds + C::OFF_REDW;
   float *SCAL = REDW + C::NW;  // lr, bc1, bc2, l1, loss
@@ -259,11 +274,15 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     float gB[PX];
 #pragma unroll
     for (int p = 0; p < PX; ++p) gB[p] = 0.f;
+    float tpix[PX];  // T at the thread's own pixels (WC layout)
     if (conv_role) {
     // ---- P1: T = Moffat + B into LDS -----------------------------------------------------
     if (C::WC && STATE_REGS) {
 #pragma unroll
-      for (int p = 0; p < PX; ++p) T[pu * C::TSA + C::AP + pv + p] = Bp[p] + Tp[p];
+      for (int p = 0; p < PX; ++p) {
+        tpix[p] = Bp[p] + Tp[p];
+        T[pu * C::TSA + C::AP + pv + p] = tpix[p];
+      }
     } else if (STATE_REGS) {
 #pragma unroll
       for (int p = 0; p < PX; ++p) T[pu * TS + pv + p] = Bp[p] + Tp[p];
@@ -282,16 +301,16 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     if (tid < S * 5) SGR[tid] = 0.f;
 
     // ---- tap tables of every star of the frame (once per iteration) ----------------------------
-    for (int e = tid; e < S * 2 * NT; e += NTHR) {
-      const int s = e / (2 * NT), ax = (e / NT) & 1, k = e % NT;
-      float tap, dtap;
-      int bq;
+    for (int e = tid; e < S * 2 * NTP; e += NTHR) {
+      const int s = e / (2 * NTP), ax = (e / NTP) & 1, k = e % NTP - 1;  // k = -1, NT, NT + 1: the zero padding
+      float tap = 0.f, dtap = 0.f;
+      int bq = 0;
       const float c_off = (N % 2 == 0) ? 0.5f : 0.0f;  // (N-1)/2 - (N-1)//2
       // a star further than N/4 high-res pixels from the stamp centre is a broken fit: pin the kernel there
       const float delta = fminf(fmaxf(SS * SP[s * 4 + 1 + ax], -(float)(N / 4)), (float)(N / 4)) + c_off;
-      tap_entry<SS, NT>(delta, k, tap, dtap, bq);
-      TAPS[(s * 4 + 2 * ax) * NT + k] = tap;
-      TAPS[(s * 4 + 2 * ax + 1) * NT + k] = dtap;
+      if (k >= 0 && k < NT) tap_entry<SS, NT>(delta, k, tap, dtap, bq);
+      TAPS[(s * 4 + 2 * ax) * NTP + k] = tap;
+      TAPS[(s * 4 + 2 * ax + 1) * NTP + k] = dtap;
       if (k == 0) BQ[s * 2 + ax] = bq;
     }
 
@@ -303,12 +322,12 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         constexpr int JB = C::JB, NBLK = n / JB;
         float *wsc = lds + C::OFF_WSC + wid * C::WSZ;
         constexpr int TSA = C::TSA, AP = C::AP, APR = C::APR;
-        float *R2w = wsc + AP, *R2xw = wsc + JB * TSA + AP, *RESw = wsc + 2 * JB * TSA + APR * JB;
+        float *R2w = wsc + AP, *RESw = wsc + JB * TSA + APR * JB;
         for (int task = wid; task < SG * NBLK; task += C::NW) {
           const int sl = task / NBLK, blk = task % NBLK, s = g0 + sl;
           if (s >= S) continue;  // wave-uniform
           const int jd0 = blk * JB;
-          const float *tx = TAPS + (s * 4 + 0) * NT, *dtx = tx + NT, *ty = tx + 2 * NT, *dty = tx + 3 * NT;
+          const float *tx = TAPS + (s * 4 + 0) * NTP, *ty = tx + 2 * NTP, *dty = tx + 3 * NTP;
           const int bqx = BQ[s * 2 + 0], bqy = BQ[s * 2 + 1];
           const float amp = SP[s * 4 + 0], sky = SP[s * 4 + 3];
           // data / weights of the task's pixels: requested now, used after the row pass
@@ -328,97 +347,100 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
             }
           }
           LC_STAMP(10);
-          // row pass (x taps) fused with the column down-sampling: lane = high-res row
+          // row pass (x taps) fused with the column down-sampling: lane = high-res row.  Only the value filter runs
+          // here; the x0 gradient is taken from the transposed row pass (P5), which has the derivative taps for free
+          // in the second half of its packed FMAs.
           {
-            constexpr int WL = SS * (JB - 1) + NT;
             const int ws = SS * (jd0 - bqx) - (NT - 1);
-            float tk[NT], dk[NT];
+            if constexpr (SS == 2) {
+              // out_j = sum_m tr[m] win[2 j + m], tr[m] = tx[NT - 1 - m]: taps and window samples pair up as
+              // (m, m + 1), m even, in aligned registers; the two halves of the packed accumulator are added at the end
+              constexpr int NP = (NT + 1) / 2, WL2 = (JB - 1) + NP;
+              lc_v2f tr2[NP];
 #pragma unroll
-            for (int k = 0; k < NT; ++k) {
-              tk[k] = tx[k];
-              dk[k] = dtx[k];
-            }
-            for (int u = lane; u < N; u += 64) {
-              float win[WL];
-              const float *trow = T + u * TSA + AP + ws;
+              for (int h = 0; h < NP; ++h) tr2[h] = (lc_v2f){tx[NT - 1 - 2 * h], tx[NT - 2 - 2 * h]};  // tx[-1] = 0
+              for (int u = lane; u < N; u += 64) {
+                lc_v2f win2[WL2];
+                const float *trow = T + u * TSA + AP + ws;
 #pragma unroll
-              for (int i = 0; i < WL; ++i) win[i] = trow[i];
+                for (int i = 0; i < WL2; ++i) win2[i] = (lc_v2f){trow[2 * i], trow[2 * i + 1]};
 #pragma unroll
-              for (int j = 0; j < JB; ++j) {
-                float acc = 0.f, accd = 0.f;
+                for (int j = 0; j < JB; ++j) {
+                  lc_v2f acc = (lc_v2f){0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < NT; ++k) {
-                  const float w = win[SS * j - k + NT - 1];
-                  acc = fmaf(tk[k], w, acc);
-                  accd = fmaf(dk[k], w, accd);
+                  for (int h = 0; h < NP; ++h) acc = pk_fma(tr2[h], win2[j + h], acc);
+                  R2w[j * TSA + u] = acc.x + acc.y;
                 }
-                R2w[j * TSA + u] = acc;
-                R2xw[j * TSA + u] = accd;
+              }
+            } else {
+              constexpr int WL = SS * (JB - 1) + NT;
+              float tk[NT];
+#pragma unroll
+              for (int k = 0; k < NT; ++k) tk[k] = tx[k];
+              for (int u = lane; u < N; u += 64) {
+                float win[WL];
+                const float *trow = T + u * TSA + AP + ws;
+#pragma unroll
+                for (int i = 0; i < WL; ++i) win[i] = trow[i];
+#pragma unroll
+                for (int j = 0; j < JB; ++j) {
+                  float acc = 0.f;
+#pragma unroll
+                  for (int k = 0; k < NT; ++k) acc = fmaf(tk[k], win[SS * j - k + NT - 1], acc);
+                  R2w[j * TSA + u] = acc;
+                }
               }
             }
           }
           wave_lds_sync();
           LC_STAMP(11);
-          // column pass (y taps) fused with the row down-sampling, residuals, reductions: lane = (column, row strip)
-          float chi = 0.f, ga = 0.f, gx = 0.f, gy = 0.f, gs = 0.f;
+          // column pass (y taps) fused with the row down-sampling, residuals, reductions: lane = (column, row strip);
+          // value and y-derivative share the window sample: one packed FMA per tap
+          float chi = 0.f, ga = 0.f, gy = 0.f, gs = 0.f;
           {
             constexpr int WL = SS * (LC - 1) + NT;
-            float tk[NT], dk[NT];
+            lc_v2f tyd[NT];
 #pragma unroll
-            for (int k = 0; k < NT; ++k) {
-              tk[k] = ty[k];
-              dk[k] = dty[k];
-            }
+            for (int k = 0; k < NT; ++k) tyd[k] = (lc_v2f){ty[k], dty[k]};
 #pragma unroll
             for (int i3 = 0; i3 < NI3; ++i3) {
               const int item = lane + 64 * i3;
               if (item < JB * (n / LC)) {
                 const int jl = item % JB, a0 = (item / JB) * LC;
                 const int ws = SS * (a0 - bqy) - (NT - 1);
-                float win[WL], winx[WL];
-                const float *r2 = R2w + jl * TSA + ws, *r2x = R2xw + jl * TSA + ws;
+                float win[WL];
+                const float *r2 = R2w + jl * TSA + ws;
 #pragma unroll
-                for (int i = 0; i < WL; ++i) {
-                  win[i] = r2[i];
-                  winx[i] = r2x[i];
-                }
-                float lgx = 0.f, lgy = 0.f;
+                for (int i = 0; i < WL; ++i) win[i] = r2[i];
+                float lgy = 0.f;
 #pragma unroll
                 for (int j = 0; j < LC; ++j) {
-                  float fv = 0.f, fx = 0.f, fy = 0.f;
+                  lc_v2f fvy = (lc_v2f){0.f, 0.f};
 #pragma unroll
-                  for (int k = 0; k < NT; ++k) {
-                    const float w = win[SS * j - k + NT - 1];
-                    fv = fmaf(tk[k], w, fv);
-                    fy = fmaf(dk[k], w, fy);
-                    fx = fmaf(tk[k], winx[SS * j - k + NT - 1], fx);
-                  }
+                  for (int k = 0; k < NT; ++k) fvy = pk_fma(tyd[k], pk_bcast(win[SS * j - k + NT - 1]), fvy);
+                  const float fv = fvy.x, fy = fvy.y;
                   const float model = fmaf(amp, fv, sky);
                   const float res = model - dpre[i3][j];
                   const float rw = wpre[i3][j] * res;
                   chi = fmaf(rw, res, chi);
                   ga = fmaf(rw, fv, ga);
-                  lgx = fmaf(rw, fx, lgx);
                   lgy = fmaf(rw, fy, lgy);
                   gs += rw;
                   RESw[(a0 + j) * JB + jl] = rw;
                   if (A.out_model) A.out_model[(size_t)f * S * n * n + (size_t)s * n * n + (size_t)(a0 + j) * n + jd0 + jl] = model;
                 }
-                gx += lgx * amp * SS;
                 gy += lgy * amp * SS;
               }
             }
           }
           chi = wave_sum(chi);
           ga = wave_sum(ga);
-          gx = wave_sum(gx);
           gy = wave_sum(gy);
           gs = wave_sum(gs);
           if (lane == 0) {
             float *r = RED + (s * NBLK + blk) * 5;
             r[0] = chi;
             r[1] = ga;
-            r[2] = gx;
             r[3] = gy;
             r[4] = gs;
           }
@@ -428,37 +450,77 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           {
             constexpr int WI = (SS * LA - 1 + NT - 1) / SS + 1;
             constexpr int NI4 = (JB * (n / LA) + 63) / 64;
-            float tk[NT];
+            if constexpr (SS == 2) {
+              // outputs pair up as (2 h, 2 h + 1): residual i feeds them through taps (2 (i - h), 2 (i - h) - 1)
+              constexpr int NP = (NT + 1) / 2;
+              lc_v2f py[NP];
 #pragma unroll
-            for (int k = 0; k < NT; ++k) tk[k] = ty[k];
+              for (int q = 0; q < NP; ++q) py[q] = (lc_v2f){ty[2 * q], ty[2 * q - 1]};  // ty[-1] = ty[NT] = 0
 #pragma unroll
-            for (int i4 = 0; i4 < NI4; ++i4) {
-              const int item = lane + 64 * i4;
-              if (item < JB * (n / LA)) {
-                const int jl = item % JB, a0 = (item / JB) * LA;
-                float out[SS * LA];
+              for (int i4 = 0; i4 < NI4; ++i4) {
+                const int item = lane + 64 * i4;
+                if (item < JB * (n / LA)) {
+                  const int jl = item % JB, a0 = (item / JB) * LA;
+                  lc_v2f out2[LA];
 #pragma unroll
-                for (int r = 0; r < SS * LA; ++r) out[r] = 0.f;
-                const float *rcol = RESw + (bqy + a0) * JB + jl;
+                  for (int h = 0; h < LA; ++h) out2[h] = (lc_v2f){0.f, 0.f};
+                  const float *rcol = RESw + (bqy + a0) * JB + jl;
 #pragma unroll
-                for (int i = 0; i < WI; ++i) {
-                  const float rv = rcol[i * JB];
+                  for (int i = 0; i < WI; ++i) {
+                    const lc_v2f rv = pk_bcast(rcol[i * JB]);
 #pragma unroll
-                  for (int k = 0; k < NT; ++k) {
-                    const int rel = SS * i - k;
-                    if (rel >= 0 && rel < SS * LA) out[rel] = fmaf(tk[k], rv, out[rel]);
+                    for (int h = 0; h < LA; ++h)
+                      if (i - h >= 0 && i - h < NP) out2[h] = pk_fma(py[i - h], rv, out2[h]);
+                  }
+                  float *vrow = V + (sl * N + SS * a0) * C::VS + C::VO + jd0 + jl;
+#pragma unroll
+                  for (int h = 0; h < LA; ++h) {
+                    vrow[(2 * h) * C::VS] = out2[h].x;
+                    vrow[(2 * h + 1) * C::VS] = out2[h].y;
+                  }
+                  // the zero columns (the starlet phase reuses this region, so they are rewritten every iteration)
+                  if (jd0 + jl == 0) {
+#pragma unroll
+                    for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * C::VS] = 0.f;
+                  }
+                  if (jd0 + jl == n - 1) {
+#pragma unroll
+                    for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * C::VS + n + 1] = 0.f;
                   }
                 }
+              }
+            } else {
+              float tk[NT];
 #pragma unroll
-                for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * C::VS + C::VO + jd0 + jl] = out[r];
-                // the zero columns (the starlet phase reuses this region, so they are rewritten every iteration)
-                if (jd0 + jl == 0) {
+              for (int k = 0; k < NT; ++k) tk[k] = ty[k];
 #pragma unroll
-                  for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * C::VS] = 0.f;
-                }
-                if (jd0 + jl == n - 1) {
+              for (int i4 = 0; i4 < NI4; ++i4) {
+                const int item = lane + 64 * i4;
+                if (item < JB * (n / LA)) {
+                  const int jl = item % JB, a0 = (item / JB) * LA;
+                  float out[SS * LA];
 #pragma unroll
-                  for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * C::VS + n + 1] = 0.f;
+                  for (int r = 0; r < SS * LA; ++r) out[r] = 0.f;
+                  const float *rcol = RESw + (bqy + a0) * JB + jl;
+#pragma unroll
+                  for (int i = 0; i < WI; ++i) {
+                    const float rv = rcol[i * JB];
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                      const int rel = SS * i - k;
+                      if (rel >= 0 && rel < SS * LA) out[rel] = fmaf(tk[k], rv, out[rel]);
+                    }
+                  }
+#pragma unroll
+                  for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * C::VS + C::VO + jd0 + jl] = out[r];
+                  if (jd0 + jl == 0) {
+#pragma unroll
+                    for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * C::VS] = 0.f;
+                  }
+                  if (jd0 + jl == n - 1) {
+#pragma unroll
+                    for (int r = 0; r < SS * LA; ++r) V[(sl * N + SS * a0 + r) * C::VS + n + 1] = 0.f;
+                  }
                 }
               }
             }
@@ -471,7 +533,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         LC_STAMP(15);
         if (tid < SG * 5) {
           const int sl = tid / 5, q = tid % 5;
-          if (g0 + sl < S) {
+          if (g0 + sl < S && q != 2) {  // the x0 gradient (slot 2) comes out of the transposed row pass below
             float acc = 0.f;
             for (int k = 0; k < NBLK; ++k) acc += RED[((g0 + sl) * NBLK + k) * 5 + q];
             SGR[(g0 + sl) * 5 + q] = acc;
@@ -503,7 +565,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         for (int item = tid; item < SG * N * NSTRIP; item += NTHR) {
           const int u = item % N, strip = (item / N) % NSTRIP, sl = item / (N * NSTRIP);
           if (g0 + sl >= S) continue;
-          const float *tx = TAPS + ((g0 + sl) * 4 + 0) * NT, *dtx = tx + NT;
+          const float *tx = TAPS + ((g0 + sl) * 4 + 0) * NTP, *dtx = tx + NTP;
           const int bq = BQ[(g0 + sl) * 2 + 0];
           const int a0 = strip * LR;
           const int ws = SS * (a0 - bq) - (NT - 1);
@@ -552,7 +614,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           float chi = 0.f, ga = 0.f, gx = 0.f, gy = 0.f, gs = 0.f;
           if (s < S && within < C::IPS) {
             const int jd = within % n, strip = within / n;
-            const float *ty = TAPS + (s * 4 + 2) * NT, *dty = ty + NT;
+            const float *ty = TAPS + (s * 4 + 2) * NTP, *dty = ty + NTP;
             const int bq = BQ[s * 2 + 1];
             const int a0 = strip * LC;
             const int ws = SS * (a0 - bq) - (NT - 1);
@@ -634,7 +696,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         for (int item = tid; item < SG * n * NSTRIP; item += NTHR) {
           const int jd = item % n, strip = (item / n) % NSTRIP, sl = item / (n * NSTRIP);
           if (g0 + sl >= S) continue;
-          const float *ty = TAPS + ((g0 + sl) * 4 + 2) * NT;
+          const float *ty = TAPS + ((g0 + sl) * 4 + 2) * NTP;
           const int bq = BQ[(g0 + sl) * 2 + 1];
           const int a0 = strip * LA;
           float tk[NT];
@@ -664,12 +726,46 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       }
       // ---- P5: transposed row pass, summed over the stars of the group into registers ------
       LC_STAMP(16);
-      {
+      if constexpr (C::WC) {
+        // value and derivative taps ride in the two halves of one packed FMA: accp[p] = (sum_k tx V, sum_k dtx V).
+        // The first half is this star's share of dchi2/dB at the thread's pixels; the second, multiplied by T at the
+        // same pixels and summed over the frame, is dchi2/dx0 / (amp * SS) of the star (the adjoint form of the
+        // x-derivative filter of the forward pass: same number, no second row pass, no second column pass).
         constexpr int WJ = (PX - 1 + NT - 1) / SS + 1;
         for (int sl = 0; sl < SG; ++sl) {
           const int s = g0 + sl;
           if (s >= S) break;
-          const float *tx = TAPS + (s * 4 + 0) * NT;
+          const float *tx = TAPS + (s * 4 + 0) * NTP, *dtx = tx + NTP;
+          const int bq = BQ[s * 2 + 0];
+          const float amp = SP[s * 4 + 0];
+          lc_v2f accp[PX];
+#pragma unroll
+          for (int p = 0; p < PX; ++p) accp[p] = (lc_v2f){0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < WJ; ++i) {
+            const int jd = i + bq + pv / SS;
+            const lc_v2f vv = pk_bcast(V[(sl * N + pu) * C::VS + 1 + min(max(jd, -1), n)]);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+              const int rel = SS * i - k;
+              if (rel >= 0 && rel < PX) accp[rel] = pk_fma((lc_v2f){tx[k], dtx[k]}, vv, accp[rel]);
+            }
+          }
+          float gxs = 0.f;
+#pragma unroll
+          for (int p = 0; p < PX; ++p) {
+            gB[p] = fmaf(amp, accp[p].x, gB[p]);
+            gxs = fmaf(accp[p].y, tpix[p], gxs);
+          }
+          gxs = wave_sum(gxs);
+          if (lane == 0) REDX[s * C::NW + wid] = gxs;
+        }
+      } else {
+        constexpr int WJ = (PX - 1 + NT - 1) / SS + 1;
+        for (int sl = 0; sl < SG; ++sl) {
+          const int s = g0 + sl;
+          if (s >= S) break;
+          const float *tx = TAPS + (s * 4 + 0) * NTP;
           const int bq = BQ[s * 2 + 0];
           const float amp = SP[s * 4 + 0];
           float acc[PX];
@@ -678,14 +774,9 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
 #pragma unroll
           for (int i = 0; i < WJ; ++i) {
             const int jd = i + bq + pv / SS;
-            float vv;
-            if constexpr (C::WC) {
-              vv = V[(sl * N + pu) * C::VS + 1 + min(max(jd, -1), n)];
-            } else {
-              const int ci = min(max(jd, 0), n - 1);
-              vv = V[(sl * N + pu) * RS + ci];
-              vv = (jd >= 0 && jd < n) ? vv : 0.f;
-            }
+            const int ci = min(max(jd, 0), n - 1);
+            float vv = V[(sl * N + pu) * RS + ci];
+            vv = (jd >= 0 && jd < n) ? vv : 0.f;
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
               const int rel = SS * i - k;
@@ -701,6 +792,14 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     }  // conv_role
     __syncthreads();
     LC_STAMP(40);
+    if constexpr (C::WC) {
+      if (conv_role && tid < S) {  // dchi2/dx0 of every star: the waves' partial sums in fixed order
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < C::NW; ++w) acc += REDX[tid * C::NW + w];
+        SGR[tid * 5 + 2] = acc * SP[tid * 4 + 0] * SS;
+      }
+    }
 
     if (A.out_gT) {
 #pragma unroll
