@@ -96,8 +96,10 @@ struct PsfCfg {
   static constexpr int NT = ntaps(SS);
   static constexpr int J = ilog2(N);
   static constexpr int LR = 8;  // row-pass strip (down-sampled columns per work item)
-  static constexpr int LC = 4;  // column-pass strip (down-sampled rows per work item)
-  static constexpr int LA = 4;  // transposed column pass: LA data rows = SS*LA high-res rows
+  // column-pass strip (down-sampled rows per work item) and transposed column pass strip (LA data rows = SS*LA
+  // high-res rows): sized so that a wave task of JB columns keeps all 64 lanes busy
+  static constexpr int LC = (JB_ * (N_ / SS_) / 4 >= 64) ? 4 : 2;
+  static constexpr int LA = LC;
   static constexpr int TS = N + 1;  // padded LDS row stride of N-long rows
   static constexpr int RS = n + 1;  // padded LDS row stride of n-long rows
   // LDS carve-up (floats)
@@ -115,7 +117,8 @@ struct PsfCfg {
   static constexpr int AP = N / 4 + 10;               // apron of N-long rows (high-res pixels)
   static constexpr int TSA = N + 2 * AP + 1;          // row stride of T, R2, R2x in the WC layout
   static constexpr int APR = AP / SS + 2;             // apron of the residual rows (data pixels)
-  static constexpr int WSZ = JB * TSA + (n + 2 * APR) * JB;  // per-wave scratch: R2 [JB][TSA], residuals [n+2APR][JB]
+  static constexpr int JBP = JB + 1;                  // padded row stride of the per-wave residual tile
+  static constexpr int WSZ = JB * TSA + (n + 2 * APR) * JBP;  // per-wave scratch: R2 [JB][TSA], residuals [n+2APR][JBP]
   static constexpr int SZ_VR = (SZ_V > StarletLds<N>::FLOATS) ? SZ_V : StarletLds<N>::FLOATS;  // V, reused by the starlet
   static constexpr int OFF_WSC = OFF_R + SZ_VR;
   static constexpr int SZ_R = WC ? (SZ_VR + NW * WSZ) : ((2 * SZ_R2 > SZ_V) ? 2 * SZ_R2 : SZ_V);
@@ -125,7 +128,9 @@ struct PsfCfg {
   // tap rows are padded: [0] = 0, [1 + k] = tap k, [NT + 1] = [NT + 2] = 0, so that the paired-tap forms of the
   // passes read their out-of-range partner as a zero
   static constexpr int NTP = NT + 3;
-  static constexpr int SZ_TAPS = 16 * 4 * NTP;  // every star of the frame
+  // plus the same taps interleaved as (value, derivative) pairs per axis, 8-byte aligned: [star][axis][NT] float2
+  static constexpr int SZ_TAPS = (16 * 4 * NTP + 1) / 2 * 2 + 16 * 2 * NT * 2;  // every star of the frame
+  static constexpr int OFF_TAPP = OFF_TAPS + (16 * 4 * NTP + 1) / 2 * 2;
   static constexpr int OFF_RED = OFF_TAPS + SZ_TAPS;
   static constexpr int IPS = n * n / LC;  // column-pass items per star
   static constexpr int IPS_PAD = (IPS + kWave - 1) / kWave * kWave;
@@ -141,6 +146,7 @@ struct PsfCfg {
   static_assert(WC || StarletLds<N>::FLOATS <= SZ_T + SZ_R + SZ_RES, "starlet ping-pong buffers must fit over T + R + RES");
   static_assert(PX % SS == 0 && N % PX == 0 && n % LR == 0 && n % LC == 0 && n % LA == 0 && n % JB == 0, "tiling");
   static_assert(LDS_FLOATS * 4 <= 163840, "LDS");
+  static_assert(OFF_TAPP % 2 == 0, "tap pairs are read as 64-bit words");
   static_assert(NTHR <= 1024 && NTHR % kWave == 0, "threads");
   static_assert(!WC_ || PX_ <= 8, "the WC layout keeps the pixel state in registers");
 };
@@ -191,6 +197,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
   float *RES = lds + C::OFF_RES;
   float *TAPS = lds + C::OFF_TAPS + 1;  // [S][4][NTP], entry k of a row at [k] (one zero in front, two behind): tx, dtx, ty, dty
   constexpr int NTP = C::NTP;
+  lc_v2f *TAPP = (lc_v2f *)(lds + C::OFF_TAPP);  // [S][2 axes][NT] (tap, dtap)
   float *REDX = lds + C::OFF_REDX;
   float *RED = lds + C::OFF_RED;    // [SG][SLOTS][5] + [NW] + scalars
   float *REDW = lds + C::OFF_REDW;
@@ -311,6 +318,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       if (k >= 0 && k < NT) tap_entry<SS, NT>(delta, k, tap, dtap, bq);
       TAPS[(s * 4 + 2 * ax) * NTP + k] = tap;
       TAPS[(s * 4 + 2 * ax + 1) * NTP + k] = dtap;
+      if (k >= 0 && k < NT) TAPP[(s * 2 + ax) * NT + k] = (lc_v2f){tap, dtap};
       if (k == 0) BQ[s * 2 + ax] = bq;
     }
 
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         constexpr int JB = C::JB, NBLK = n / JB;
         float *wsc = lds + C::OFF_WSC + wid * C::WSZ;
         constexpr int TSA = C::TSA, AP = C::AP, APR = C::APR;
-        float *R2w = wsc + AP, *RESw = wsc + JB * TSA + APR * JB;
+        float *R2w = wsc + AP, *RESw = wsc + JB * TSA + APR * C::JBP;
         for (int task = wid; task < SG * NBLK; task += C::NW) {
           const int sl = task / NBLK, blk = task % NBLK, s = g0 + sl;
           if (s >= S) continue;  // wave-uniform
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
             constexpr int WL = SS * (LC - 1) + NT;
             lc_v2f tyd[NT];
 #pragma unroll
-            for (int k = 0; k < NT; ++k) tyd[k] = (lc_v2f){ty[k], dty[k]};
+            for (int k = 0; k < NT; ++k) tyd[k] = TAPP[(s * 2 + 1) * NT + k];
 #pragma unroll
             for (int i3 = 0; i3 < NI3; ++i3) {
               const int item = lane + 64 * i3;
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
                   ga = fmaf(rw, fv, ga);
                   lgy = fmaf(rw, fy, lgy);
                   gs += rw;
-                  RESw[(a0 + j) * JB + jl] = rw;
+                  RESw[(a0 + j) * C::JBP + jl] = rw;
                   if (A.out_model) A.out_model[(size_t)f * S * n * n + (size_t)s * n * n + (size_t)(a0 + j) * n + jd0 + jl] = model;
                 }
                 gy += lgy * amp * SS;
@@ -464,10 +472,10 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
                   lc_v2f out2[LA];
 #pragma unroll
                   for (int h = 0; h < LA; ++h) out2[h] = (lc_v2f){0.f, 0.f};
-                  const float *rcol = RESw + (bqy + a0) * JB + jl;
+                  const float *rcol = RESw + (bqy + a0) * C::JBP + jl;
 #pragma unroll
                   for (int i = 0; i < WI; ++i) {
-                    const lc_v2f rv = pk_bcast(rcol[i * JB]);
+                    const lc_v2f rv = pk_bcast(rcol[i * C::JBP]);
 #pragma unroll
                     for (int h = 0; h < LA; ++h)
                       if (i - h >= 0 && i - h < NP) out2[h] = pk_fma(py[i - h], rv, out2[h]);
@@ -501,10 +509,10 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
                   float out[SS * LA];
 #pragma unroll
                   for (int r = 0; r < SS * LA; ++r) out[r] = 0.f;
-                  const float *rcol = RESw + (bqy + a0) * JB + jl;
+                  const float *rcol = RESw + (bqy + a0) * C::JBP + jl;
 #pragma unroll
                   for (int i = 0; i < WI; ++i) {
-                    const float rv = rcol[i * JB];
+                    const float rv = rcol[i * C::JBP];
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
                       const int rel = SS * i - k;
@@ -738,17 +746,24 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           const float *tx = TAPS + (s * 4 + 0) * NTP, *dtx = tx + NTP;
           const int bq = BQ[s * 2 + 0];
           const float amp = SP[s * 4 + 0];
+          lc_v2f txd[NT];  // (value tap, derivative tap) pairs of this star, in registers for the whole window
+#pragma unroll
+          for (int k = 0; k < NT; ++k) txd[k] = TAPP[(s * 2 + 0) * NT + k];
           lc_v2f accp[PX];
 #pragma unroll
           for (int p = 0; p < PX; ++p) accp[p] = (lc_v2f){0.f, 0.f};
+          const float *vrow = V + (sl * N + pu) * C::VS + 1;
+          const int jd0 = bq + pv / SS;
+          float vwin[WJ];
+#pragma unroll
+          for (int i = 0; i < WJ; ++i) vwin[i] = vrow[min(max(jd0 + i, -1), n)];
 #pragma unroll
           for (int i = 0; i < WJ; ++i) {
-            const int jd = i + bq + pv / SS;
-            const lc_v2f vv = pk_bcast(V[(sl * N + pu) * C::VS + 1 + min(max(jd, -1), n)]);
+            const lc_v2f vv = pk_bcast(vwin[i]);
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
               const int rel = SS * i - k;
-              if (rel >= 0 && rel < PX) accp[rel] = pk_fma((lc_v2f){tx[k], dtx[k]}, vv, accp[rel]);
+              if (rel >= 0 && rel < PX) accp[rel] = pk_fma(txd[k], vv, accp[rel]);
             }
           }
           float gxs = 0.f;

@@ -215,10 +215,10 @@ struct StarletLds {
 // Wf: [J][N*N] weights or null (then norms[j] is used); qscr: [J][N*N] thread-private scratch, only
 // touched when the sub-gradients do not fit in registers.  All N*N/PX threads of the block must call.
 // On return l1 holds this thread's share of the value and z[PX] the sub-gradient at its pixels.
-template <int N, int PX, int JUSE = ilog2(N)>
-__device__ __forceinline__ void starlet_l1_grad(const float img[PX], const float *Wf, const float *norms, float *qscr,
-                                                float lam_sc, float lam_hf, float *lds, int tid, float &l1,
-                                                float z[PX]) {
+template <int N, int PX, int JUSE>
+__device__ __forceinline__ void starlet_l1_grad_lds(const float img[PX], const float *Wf, const float *norms, float *qscr,
+                                                    float lam_sc, float lam_hf, float *lds, int tid, float &l1,
+                                                    float z[PX]) {
   constexpr int J = JUSE;  // detail scales entering the penalty (the PSF / background terms use all of them)
   constexpr int TS = StarletLds<N>::TS;
   float *bufA = lds, *bufB = lds + N * TS;
@@ -421,6 +421,260 @@ __device__ __forceinline__ void starlet_l1_grad(const float img[PX], const float
 #pragma unroll
     for (int p = 0; p < PX; ++p) z[p] = q[p] + rt[p];
   });
+}
+
+
+// ---- register / DPP form (line layouts DPP can serve: LPR = N / PX in {4, 8, 16}) ------------------------------------
+// One 5-tap B3 pass at dilation D along a line of N samples held by LPR consecutive lanes (PX samples each, lil = lane
+// index inside the line), entirely in registers.  ADJ = false: the edge-replicating pass r[x] = sum_t b_t c[clamp(x + t D)];
+// ADJ = true: its exact adjoint.  Both are the zero-padded symmetric stencil plus a boundary term:
+//   forward:  r[x] += c[0] * sum_{t: x + t D < 0} b_t + c[N-1] * sum_{t: x + t D > N-1} b_t
+//   adjoint:  g[0] += b_1 sum_{x < D} y[x] + b_2 sum_{x < 2D} y[x],   g[N-1] likewise from the other end.
+// Neighbours in other lanes arrive by zero-filling DPP row shifts; a neighbour that lies in another line of the same
+// 16-lane DPP row is switched off through its tap coefficient (per lane, a handful of selects per pass) instead of a
+// select per fetched value, so that a tap is one multiply-add on a DPP operand.
+struct LineLane {
+  int lil;
+  float is_first, is_last;  // 1 in the first / last lane of the line, else 0
+};
+template <int LPR>
+__device__ __forceinline__ float swz_line_first(float v) {
+  constexpr int pat = (~(LPR - 1)) & 0x1F;
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), pat));
+}
+template <int LPR>
+__device__ __forceinline__ float swz_line_last(float v) {
+  constexpr int pat = ((~(LPR - 1)) & 0x1F) | ((LPR - 1) << 5);
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), pat));
+}
+template <int K>
+__device__ __forceinline__ float dpp_lower(float v) {  // value of lane - K (same DPP row), 0 beyond the row
+  if constexpr (K >= 16) return 0.f; else return dpp_mov0<0x110 + K>(v);
+}
+template <int K>
+__device__ __forceinline__ float dpp_upper(float v) {  // value of lane + K (same DPP row), 0 beyond the row
+  if constexpr (K >= 16) return 0.f; else return dpp_mov0<0x100 + K>(v);
+}
+template <int LPR>
+__device__ __forceinline__ float line_sum_fused(float v) {  // sum over the line's lanes, in every lane
+  v += dpp_mov0<0xB1>(v);                             // quad_perm [1,0,3,2]
+  v += dpp_mov0<0x4E>(v);                             // quad_perm [2,3,0,1]
+  if constexpr (LPR >= 8) v += dpp_mov0<0x141>(v);    // row_half_mirror
+  if constexpr (LPR >= 16) v += dpp_mov0<0x140>(v);   // row_mirror
+  return v;
+}
+
+template <int N, int PX, int LPR, int D, bool ADJ>
+__device__ __forceinline__ void line_pass(const float (&own)[PX], const LineLane &L, float (&out)[PX]) {
+  constexpr float b0 = 0.375f, b1 = 0.25f, b2 = 0.0625f;
+  const int lil = L.lil;
+  if constexpr (D >= PX) {
+    constexpr int K1 = D / PX, K2 = 2 * D / PX;
+    // taps: lanes lil -+ K1, lil -+ K2 of the same line
+    const float cl1 = (K1 < LPR && lil >= K1) ? b1 : 0.f, cu1 = (K1 < LPR && lil + K1 < LPR) ? b1 : 0.f;
+    const float cl2 = (K2 < LPR && lil >= K2) ? b2 : 0.f, cu2 = (K2 < LPR && lil + K2 < LPR) ? b2 : 0.f;
+    // boundary weights: how much of the stencil of this lane's samples reaches beyond either end
+    const float ef = ((lil < K1) ? b1 : 0.f) + ((lil < K2) ? b2 : 0.f);
+    const float el = ((lil + K1 >= LPR) ? b1 : 0.f) + ((lil + K2 >= LPR) ? b2 : 0.f);
+    float e = 0.f;
+    if constexpr (!ADJ) e = fmaf(ef, swz_line_first<LPR>(own[0]), el * swz_line_last<LPR>(own[PX - 1]));
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      float acc = fmaf(b0, own[p], e);
+      if constexpr (K1 < LPR) {
+        acc = fmaf(cl1, dpp_lower<K1>(own[p]), acc);
+        acc = fmaf(cu1, dpp_upper<K1>(own[p]), acc);
+      }
+      if constexpr (K2 < LPR) {
+        acc = fmaf(cl2, dpp_lower<K2>(own[p]), acc);
+        acc = fmaf(cu2, dpp_upper<K2>(own[p]), acc);
+      }
+      out[p] = acc;
+    }
+    if constexpr (ADJ) {
+      float full = own[0];
+#pragma unroll
+      for (int p = 1; p < PX; ++p) full += own[p];
+      const float hs = line_sum_fused<LPR>(full * ef), ts = line_sum_fused<LPR>(full * el);
+      out[0] = fmaf(L.is_first, hs, out[0]);
+      out[PX - 1] = fmaf(L.is_last, ts, out[PX - 1]);
+    }
+  } else {
+    static_assert(2 * D <= PX, "dilations below PX reach the adjacent lane only");
+    const float has_lower = 1.f - L.is_first, has_upper = 1.f - L.is_last;
+    float w[3 * PX];  // [lower lane | own | upper lane], only the entries the stencil touches are formed
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+      w[q] = (q >= PX - 2 * D) ? has_lower * dpp_lower<1>(own[q]) : 0.f;
+      w[PX + q] = own[q];
+      w[2 * PX + q] = (q < 2 * D) ? has_upper * dpp_upper<1>(own[q]) : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      float acc = b0 * own[p];
+      acc = fmaf(b1, w[PX + p - D] + w[PX + p + D], acc);
+      acc = fmaf(b2, w[PX + p - 2 * D] + w[PX + p + 2 * D], acc);
+      out[p] = acc;
+    }
+    if constexpr (!ADJ) {
+      const float cf = L.is_first * own[0], cl = L.is_last * own[PX - 1];  // only the end lanes reach beyond the line
+#pragma unroll
+      for (int p = 0; p < 2 * D; ++p) {
+        out[p] = fmaf((p < D) ? b1 + b2 : b2, cf, out[p]);
+        out[PX - 1 - p] = fmaf((p < D) ? b1 + b2 : b2, cl, out[PX - 1 - p]);
+      }
+    } else {
+      float h1 = 0.f, h2 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int p = 0; p < 2 * D; ++p) {
+        if (p < D) {
+          h1 += own[p];
+          t1 += own[PX - 1 - p];
+        }
+        h2 += own[p];
+        t2 += own[PX - 1 - p];
+      }
+      out[0] = fmaf(L.is_first, fmaf(b1, h1, b2 * h2), out[0]);
+      out[PX - 1] = fmaf(L.is_last, fmaf(b1, t1, b2 * t2), out[PX - 1]);
+    }
+  }
+}
+
+// Starlet l1 value and sub-gradient with every pass in registers: the image alternates between the row-major layout
+// (thread = row pu, samples pv .. pv + PX - 1) and the column-major one (thread = column cv, samples cu0 .. cu0 + PX - 1)
+// through two LDS transposes per scale and direction; weights, coefficients and sub-gradients live in the row-major one.
+template <int N, int PX, int JUSE>
+__device__ __forceinline__ void starlet_l1_grad_dpp(const float img[PX], const float *Wf, const float *norms, float *qscr,
+                                                    float lam_sc, float lam_hf, float *lds, int tid, float &l1,
+                                                    float z[PX]) {
+  constexpr int J = JUSE, TS = StarletLds<N>::TS, LPR = N / PX;
+  float *bufA = lds, *bufB = lds + N * TS;
+  const int pu_ = tid / LPR, pv_ = (tid % LPR) * PX;  // row-major: row, first column
+  const int cv_ = tid / LPR, cu0_ = (tid % LPR) * PX; // column-major: column, first row
+  LineLane L;
+  L.lil = tid % LPR;
+  L.is_first = (L.lil == 0) ? 1.f : 0.f;
+  L.is_last = (L.lil == LPR - 1) ? 1.f : 0.f;
+  l1 = 0.f;
+  constexpr bool QREG = (J * PX <= 64);  // sub-gradients stay in registers when they fit
+  float qreg[QREG ? J : 1][PX];
+  float c[PX];
+#pragma unroll
+  for (int p = 0; p < PX; ++p) {
+    c[p] = img[p];
+    z[p] = 0.f;
+  }
+  // transposes: row-major -> column-major through bufA, back through bufB (one barrier each: a buffer is rewritten
+  // only after a barrier that every reader of its previous contents has passed)
+  auto to_columns = [&](const float (&v)[PX], float (&o)[PX]) {
+    int pu = pu_, pv = pv_, cu0 = cu0_, cv = cv_;
+    LC_LAUNDER(pu);
+    LC_LAUNDER(pv);
+    LC_LAUNDER(cu0);
+    LC_LAUNDER(cv);
+#pragma unroll
+    for (int p = 0; p < PX; ++p) bufA[pu * TS + pv + p] = v[p];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PX; ++p) o[p] = bufA[(cu0 + p) * TS + cv];
+  };
+  auto to_rows = [&](const float (&v)[PX], float (&o)[PX]) {
+    int pu = pu_, pv = pv_, cu0 = cu0_, cv = cv_;
+    LC_LAUNDER(pu);
+    LC_LAUNDER(pv);
+    LC_LAUNDER(cu0);
+    LC_LAUNDER(cv);
+#pragma unroll
+    for (int p = 0; p < PX; ++p) bufB[(cu0 + p) * TS + cv] = v[p];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PX; ++p) o[p] = bufB[pu * TS + pv + p];
+  };
+  static_for(std::make_integer_sequence<int, J>{}, [&](auto jc) {
+    constexpr int j = decltype(jc)::value, d = 1 << j;
+    // weights of this scale: requested before the passes so that the latency hides behind them
+    float wj[PX];
+    if (Wf) {
+      int pu = pu_, pv = pv_;
+      LC_LAUNDER(pu);
+      LC_LAUNDER(pv);
+      const float4 *wp = (const float4 *)(Wf + (size_t)j * N * N + (size_t)pu * N + pv);
+#pragma unroll
+      for (int q = 0; q < PX / 4; ++q) {
+        const float4 w4 = wp[q];
+        wj[4 * q] = w4.x;
+        wj[4 * q + 1] = w4.y;
+        wj[4 * q + 2] = w4.z;
+        wj[4 * q + 3] = w4.w;
+      }
+    } else {
+      const float nv = norms[j];
+#pragma unroll
+      for (int p = 0; p < PX; ++p) wj[p] = nv;
+    }
+    float r[PX], rc[PX], cc[PX], cn[PX];
+    line_pass<N, PX, LPR, d, false>(c, L, r);    // rows
+    to_columns(r, rc);
+    line_pass<N, PX, LPR, d, false>(rc, L, cc);  // columns
+    to_rows(cc, cn);
+    const float lam = (j == 0) ? lam_hf : lam_sc;
+    float q[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      const float w = c[p] - cn[p];
+      const float lw = lam * wj[p];
+      l1 = fmaf(lw, fabsf(w), l1);
+      q[p] = (w > 0.f) ? lw : ((w < 0.f) ? -lw : 0.f);
+      c[p] = cn[p];
+    }
+    if constexpr (QREG) {
+#pragma unroll
+      for (int p = 0; p < PX; ++p) qreg[j][p] = q[p];
+    } else {
+      float4 *qp = (float4 *)(qscr + (size_t)j * N * N + (size_t)pu_ * N + pv_);
+#pragma unroll
+      for (int qq = 0; qq < PX / 4; ++qq) qp[qq] = make_float4(q[4 * qq], q[4 * qq + 1], q[4 * qq + 2], q[4 * qq + 3]);
+    }
+  });
+  // backward: z_J = 0; z_j = q_j + Col_j^T Row_j^T (z_{j+1} - q_j)   (the two adjoint passes commute)
+  static_for(std::make_integer_sequence<int, J>{}, [&](auto jc) {
+    constexpr int j = J - 1 - decltype(jc)::value, d = 1 << j;
+    float q[PX];
+    if constexpr (QREG) {
+#pragma unroll
+      for (int p = 0; p < PX; ++p) q[p] = qreg[j][p];
+    } else {
+      const float4 *qp = (const float4 *)(qscr + (size_t)j * N * N + (size_t)pu_ * N + pv_);
+#pragma unroll
+      for (int qq = 0; qq < PX / 4; ++qq) {
+        const float4 v4 = qp[qq];
+        q[4 * qq] = v4.x;
+        q[4 * qq + 1] = v4.y;
+        q[4 * qq + 2] = v4.z;
+        q[4 * qq + 3] = v4.w;
+      }
+    }
+    float y[PX], rt[PX], yc[PX], ct[PX], back[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) y[p] = z[p] - q[p];
+    line_pass<N, PX, LPR, d, true>(y, L, rt);    // Row^T
+    to_columns(rt, yc);
+    line_pass<N, PX, LPR, d, true>(yc, L, ct);   // Col^T
+    to_rows(ct, back);
+#pragma unroll
+    for (int p = 0; p < PX; ++p) z[p] = q[p] + back[p];
+  });
+}
+
+template <int N, int PX, int JUSE = ilog2(N)>
+__device__ __forceinline__ void starlet_l1_grad(const float img[PX], const float *Wf, const float *norms, float *qscr,
+                                                float lam_sc, float lam_hf, float *lds, int tid, float &l1,
+                                                float z[PX]) {
+  constexpr int LPR = N / PX;
+  if constexpr ((LPR == 4 || LPR == 8 || LPR == 16) && PX >= 2 && PX <= 8)  // PX = 16 (1024 threads, 128 registers): the LDS form spills less
+    starlet_l1_grad_dpp<N, PX, JUSE>(img, Wf, norms, qscr, lam_sc, lam_hf, lds, tid, l1, z);
+  else
+    starlet_l1_grad_lds<N, PX, JUSE>(img, Wf, norms, qscr, lam_sc, lam_hf, lds, tid, l1, z);
 }
 
 }  // namespace lc
