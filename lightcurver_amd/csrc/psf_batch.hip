@@ -203,7 +203,7 @@ const PsfVariant *find_variant(int n, int ss) {
       make_variant<PsfCfg<16, 1, 4, 8, true>>(),    // n = 16, ss = 1 (reference test fixture size)
       make_variant<PsfCfg<32, 2, 4, 8, true>, true>(),    // n = 16, ss = 2
       make_variant<PsfCfg<48, 2, 4, 8, true>, true>(),    // n = 24 (lightcurver default stamp_size_stars)
-      make_variant<PsfCfg<64, 2, 8, 4, true>, true>(),    // n = 32 (C1, C2)
+      make_variant<PsfCfg<64, 2, 8, 8, true>, true>(),    // n = 32 (C1, C2): all (up to) 8 stars in one group
       make_variant<PsfCfg<128, 2, 16, 1>, true>(),  // n = 64 (C3)
   };
   for (const auto &v : table)

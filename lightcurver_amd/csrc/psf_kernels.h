@@ -135,7 +135,7 @@ struct PsfCfg {
   static constexpr int IPS = n * n / LC;  // column-pass items per star
   static constexpr int IPS_PAD = (IPS + kWave - 1) / kWave * kWave;
   static constexpr int SLOTS = IPS_PAD / kWave;
-  static constexpr int SZ_REDX = WC ? 16 * NW : 0;  // per-(star, wave) partial sums of the x0 gradient (transposed row pass)
+  static constexpr int SZ_REDX = 16 * NW;  // per-(star, wave) partial sums of the x0 gradient (transposed row pass)
   static constexpr int SZ_RED = (WC ? 16 * (n / JB) * 5 : SG * SLOTS * 5) + SZ_REDX + NW + 8;
   static constexpr int OFF_REDX = OFF_RED + (WC ? 16 * (n / JB) * 5 : SG * SLOTS * 5);
   static constexpr int OFF_REDW = OFF_REDX + SZ_REDX;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         for (int item = tid; item < SG * N * NSTRIP; item += NTHR) {
           const int u = item % N, strip = (item / N) % NSTRIP, sl = item / (N * NSTRIP);
           if (g0 + sl >= S) continue;
-          const float *tx = TAPS + ((g0 + sl) * 4 + 0) * NTP, *dtx = tx + NTP;
+          const float *tx = TAPS + ((g0 + sl) * 4 + 0) * NTP;
           const int bq = BQ[(g0 + sl) * 2 + 0];
           const int a0 = strip * LR;
           const int ws = SS * (a0 - bq) - (NT - 1);
@@ -585,23 +585,15 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
             const float v = T[u * TS + ci];
             win[i] = (idx >= 0 && idx < N) ? v : 0.f;
           }
-          float tk[NT], dk[NT];
+          float tk[NT];
 #pragma unroll
-          for (int k = 0; k < NT; ++k) {
-            tk[k] = tx[k];
-            dk[k] = dtx[k];
-          }
+          for (int k = 0; k < NT; ++k) tk[k] = tx[k];
 #pragma unroll
           for (int j = 0; j < LR; ++j) {
-            float acc = 0.f, accd = 0.f;
+            float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < NT; ++k) {
-              const float w = win[SS * j - k + NT - 1];
-              acc = fmaf(tk[k], w, acc);
-              accd = fmaf(dk[k], w, accd);
-            }
+            for (int k = 0; k < NT; ++k) acc = fmaf(tk[k], win[SS * j - k + NT - 1], acc);
             R2t[(sl * n + a0 + j) * TS + u] = acc;
-            R2xt[(sl * n + a0 + j) * TS + u] = accd;
           }
         }
       }
@@ -627,16 +619,14 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
             const int a0 = strip * LC;
             const int ws = SS * (a0 - bq) - (NT - 1);
             const float amp = SP[s * 4 + 0], sky = SP[s * 4 + 3];
-            float win[WL], winx[WL];
+            float win[WL];
 #pragma unroll
             for (int i = 0; i < WL; ++i) {
               const int idx = ws + i;
               const int ci = min(max(idx, 0), N - 1);
               const bool ok = (idx >= 0 && idx < N);
               const float v = R2t[(sl * n + jd) * TS + ci];
-              const float vx = R2xt[(sl * n + jd) * TS + ci];
               win[i] = ok ? v : 0.f;
-              winx[i] = ok ? vx : 0.f;
             }
             float tk[NT], dk[NT];
 #pragma unroll
@@ -646,13 +636,12 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
             }
 #pragma unroll
             for (int j = 0; j < LC; ++j) {
-              float fv = 0.f, fx = 0.f, fy = 0.f;
+              float fv = 0.f, fy = 0.f;
 #pragma unroll
               for (int k = 0; k < NT; ++k) {
                 const float w = win[SS * j - k + NT - 1];
                 fv = fmaf(tk[k], w, fv);
                 fy = fmaf(dk[k], w, fy);
-                fx = fmaf(tk[k], winx[SS * j - k + NT - 1], fx);
               }
               const int id = a0 + j;
               const size_t pix = (size_t)s * n * n + (size_t)id * n + jd;
@@ -662,13 +651,11 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
               const float rw = w * res;
               chi = fmaf(rw, res, chi);
               ga = fmaf(rw, fv, ga);
-              gx = fmaf(rw, fx, gx);
               gy = fmaf(rw, fy, gy);
               gs += rw;
               RES[(sl * n + id) * n + jd] = rw;
               if (A.out_model) A.out_model[(size_t)f * S * n * n + pix] = model;
             }
-            gx *= amp * SS;
             gy *= amp * SS;
           }
           chi = wave_sum(chi);
@@ -691,7 +678,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       // per-star sums in fixed slot order
       if (tid < SG * 5) {
         const int sl = tid / 5, q = tid % 5;
-        if (g0 + sl < S) {
+        if (g0 + sl < S && q != 2) {  // the x0 gradient (slot 2) comes out of the transposed row pass (P5)
           float acc = 0.f;
           for (int k = 0; k < C::SLOTS; ++k) acc += RED[(sl * C::SLOTS + k) * 5 + q];
           SGR[(g0 + sl) * 5 + q] = acc;
@@ -780,26 +767,35 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         for (int sl = 0; sl < SG; ++sl) {
           const int s = g0 + sl;
           if (s >= S) break;
-          const float *tx = TAPS + (s * 4 + 0) * NTP;
+          const float *tx = TAPS + (s * 4 + 0) * NTP, *dtx = tx + NTP;
           const int bq = BQ[s * 2 + 0];
           const float amp = SP[s * 4 + 0];
-          float acc[PX];
+          float acc[PX], gxs = 0.f;
 #pragma unroll
           for (int p = 0; p < PX; ++p) acc[p] = 0.f;
+          // in halves of the thread's pixels: value taps into acc, derivative taps straight into the x0 gradient
+          // (dotted with T, still in LDS), so that no second accumulator array is live
 #pragma unroll
           for (int i = 0; i < WJ; ++i) {
             const int jd = i + bq + pv / SS;
             const int ci = min(max(jd, 0), n - 1);
             float vv = V[(sl * N + pu) * RS + ci];
             vv = (jd >= 0 && jd < n) ? vv : 0.f;
+            float dsum = 0.f;
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
               const int rel = SS * i - k;
-              if (rel >= 0 && rel < PX) acc[rel] = fmaf(tx[k], vv, acc[rel]);
+              if (rel >= 0 && rel < PX) {
+                acc[rel] = fmaf(tx[k], vv, acc[rel]);
+                dsum = fmaf(dtx[k], T[pu * TS + pv + rel], dsum);
+              }
             }
+            gxs = fmaf(vv, dsum, gxs);
           }
 #pragma unroll
           for (int p = 0; p < PX; ++p) gB[p] = fmaf(amp, acc[p], gB[p]);
+          gxs = wave_sum(gxs);
+          if (lane == 0) REDX[s * C::NW + wid] = gxs;
         }
       }
       LC_STAMP(17);
@@ -807,7 +803,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     }  // conv_role
     __syncthreads();
     LC_STAMP(40);
-    if constexpr (C::WC) {
+    {
       if (conv_role && tid < S) {  // dchi2/dx0 of every star: the waves' partial sums in fixed order
         float acc = 0.f;
 #pragma unroll
