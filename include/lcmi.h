@@ -109,8 +109,9 @@ int lc_psf_batch_get_stars(lc_psf_batch *b, float *stars);
 /* pixel grid B [F][N*N]; NULL resets it (and the optimiser moments) to zero */
 int lc_psf_batch_set_grid(lc_psf_batch *b, const float *grid);
 int lc_psf_batch_get_grid(lc_psf_batch *b, float *grid);
-/* starlet weights W [F][J][N][N] (J = floor(log2 N) detail scales) and strengths; W == NULL
- * selects the starlet scale norms ("lambda is not normalized" case of STARRED). */
+/* starlet weights W [F][J][N][N] (J = floor(log2 N) detail scales) and strengths.  W == NULL keeps the weights the
+ * batch already holds: the starlet scale norms of a new batch ("lambda is not normalized" case of STARRED), or the
+ * maps left by lc_psf_batch_propagate_noise / an earlier call with W != NULL. */
 int lc_psf_batch_set_regularization(lc_psf_batch *b, const float *W, float lam_scales, float lam_hf);
 /* noise propagation of the chi2 gradient into the starlet domain of B (replaces the
  * propagate_noise call inside build_psf), using the current a, x0, y0.  Writes device W. */
@@ -127,6 +128,10 @@ int lc_psf_batch_fit_moffat(lc_psf_batch *b, int n_iter, float *final_loss /* [F
  * Asynchronous on the context stream.  loss history accumulates across calls. */
 int lc_psf_batch_run_adabelief(lc_psf_batch *b, int n_iter, const lc_adabelief_cfg *cfg);
 int lc_psf_batch_iterations_done(lc_psf_batch *b);
+/* Small batches run the loop with two workgroups per frame that hand their halves of the gradient to each other inside
+ * the launch; a launch whose partner workgroups cannot all be resident gives up and is redone by the library itself in
+ * the one-workgroup form from the pre-launch state (same bits).  count = how often that happened for this batch. */
+int lc_psf_batch_split_fallbacks(lc_psf_batch *b, int *count);
 /* loss at theta_0 .. theta_T (T + 1 values per frame; history[f][t] is the loss BEFORE update t,
  * the last entry the loss of the final parameters) */
 int lc_psf_batch_get_loss_history(lc_psf_batch *b, float *history, int stride);
@@ -134,6 +139,15 @@ int lc_psf_batch_get_loss_history(lc_psf_batch *b, float *history, int stride);
  * reduced chi2 [F] over unmasked pixels. */
 int lc_psf_batch_get_results(lc_psf_batch *b, float *narrow_psf, float *full_psf, float *residuals,
                              float *chi2);
+
+/* ---- field distortion of the narrow PSF: replaces starred.psf.psf.apply_distortion ------------
+ * Reference call sites: lightcurver/processes/star_photometry.py:291-304, roi_file_preparation.py:169-180
+ * (narrow_psf, kwargs_distortion read back from the regions file, rescaled star position).
+ *   narrow_psf [N][N]; coeffs [9] = dilation_x (c0, c1, c2), dilation_y (c0, c1, c2), shear (c0, c1, c2), each evaluated
+ *   as c0 + c1 x + c2 y; xy [K][2] rescaled frame coordinates of the K positions; out [K][N][N], unit sum each.
+ * Host buffers, copied at call time; synchronous. */
+int lc_apply_distortion(lc_ctx *ctx, int N, int K, const float *narrow_psf, const float *coeffs,
+                        const float *xy, float *out);
 
 /* ---- joint multi-epoch forward model: replaces starred Deconv / Loss / Optimizer ------------
  * Reference call sites: lightcurver/processes/star_photometry.py:66-137 (one star, all epochs)

@@ -66,8 +66,10 @@ SIGNATURES = {
     'lc_psf_batch_fit_moffat': (C.c_int, [vp, C.c_int, fp]),
     'lc_psf_batch_run_adabelief': (C.c_int, [vp, C.c_int, C.POINTER(AdabeliefCfg)]),
     'lc_psf_batch_iterations_done': (C.c_int, [vp]),
+    'lc_psf_batch_split_fallbacks': (C.c_int, [vp, C.POINTER(C.c_int)]),
     'lc_psf_batch_get_loss_history': (C.c_int, [vp, fp, C.c_int]),
     'lc_psf_batch_get_results': (C.c_int, [vp, fp, fp, fp, fp]),
+    'lc_apply_distortion': (C.c_int, [vp, C.c_int, C.c_int, fp, fp, fp, fp]),
     'lc_joint_supported': (C.c_int, [C.c_int, C.c_int]),
     'lc_joint_set_debug_global': (C.c_int, [C.c_int]),
     'lc_joint_create': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.POINTER(vp)]),

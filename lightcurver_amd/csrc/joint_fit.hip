@@ -111,7 +111,7 @@ const JointVariant *find_jv(int n, int ss) {
       make_jv<48, 2, 96, 4, 8>(),     // n = 24 (default stamp_size_stars)
       make_jv<64, 2, 96, 8, 16>(),    // n = 32 (default stamp_size_ROI)
       make_jv<128, 2, 192, 16, 8>(),  // n = 64 (C4)
-      make_jv_gm<256, 2, 384, 8>(),   // n = 128 (C5)
+      make_jv_gm<256, 2, 384, 8>(),   // n = 128 (C5); 4 waves (one per SIMD, 436 registers, no scratch) measured 1.23 x slower
   };
   for (const auto &v : table)
     if (v.n == n && v.ss == ss) return &v;

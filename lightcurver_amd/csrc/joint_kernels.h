@@ -81,7 +81,7 @@ struct JointCfg {
   static constexpr int OFF_WS = OFF_SPEC + SZ_SPEC;
   // linear row buffer(s) for the data-space step: one per quarter-wave when LDS allows (N <= 64), else one per
   // wave that the four quarters use in turn
-  static constexpr bool WSQ = (N <= 128);
+  static constexpr bool WSQ = (N <= 128) && (NW_ <= 8);
   static constexpr int SZ_WS = NW * (WSQ ? 4 : 1) * L;
   static constexpr int OFF_TW = OFF_WS + SZ_WS;
   static constexpr int SZ_TW = L;

@@ -29,6 +29,9 @@ struct lc_psf_batch {
   float *xch = nullptr;   // two-workgroup form: exchange slabs, flags, abort word
   int *xflags = nullptr;
   bool split_used = false;
+  int launch_seq = 0;       // sequence number of the two-workgroup launches (abort word protocol, psf_kernels.h)
+  float *bkB = nullptr, *bkmB = nullptr, *bksB = nullptr, *bkstars = nullptr, *bkstars_m = nullptr, *bkstars_s = nullptr;
+  int split_blocks_per_cu = -1;  // occupancy of the two-workgroup kernel (queried once)
   float *o_loss = nullptr, *o_chi2 = nullptr, *o_gstars = nullptr, *o_ggrid = nullptr, *o_gT = nullptr,
         *o_model = nullptr, *o_gmoffat = nullptr;
   float *narrow = nullptr, *full = nullptr, *resid = nullptr, *redchi2 = nullptr;
@@ -268,29 +271,68 @@ int launch_psf(lc_psf_batch *b, int mode, int n_iter, const lc_adabelief_cfg *cf
     A.sched = b->sched;
   }
   // Two workgroups per frame when the optimisation loop would otherwise leave more than half of the CUs idle.
-  // Every workgroup of that grid must be resident at once (partners wait for each other): one per CU.
+  // Every workgroup of that grid must be resident at once (partners wait for each other): the grid has to fit in
+  // (resident workgroups per CU, from the occupancy calculator) x (number of CUs).  Another process or stream can
+  // still hold CUs; a partner that does not show up makes the launch give up and the fall-back launch behind it redo
+  // the work in the one-workgroup form (abort word protocol, psf_kernels.h), so the result never depends on it.
   const int split_grid = ((b->F + 7) / 8) * 16;
-  const bool split = mode == 1 && v->fn_split && (A.lam_sc != 0.f || A.lam_hf != 0.f) && split_grid <= b->ctx->n_cu &&
-                     !std::getenv("LCMI_PSF_SINGLE_WG");
+  bool split = mode == 1 && v->fn_split && (A.lam_sc != 0.f || A.lam_hf != 0.f) && !std::getenv("LCMI_PSF_SINGLE_WG");
   if (split) {
+    LC_HIP(b->ctx, hipFuncSetAttribute((const void *)v->fn_split, hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes));
+    if (b->split_blocks_per_cu < 0) {
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)v->fn_split, v->nthr, v->lds_bytes) != hipSuccess) per_cu = 0;
+      b->split_blocks_per_cu = per_cu;
+    }
+    split = (long long)split_grid <= (long long)b->split_blocks_per_cu * b->ctx->n_cu;
+  }
+  if (split) {
+    const size_t FNN = (size_t)b->F * b->N * b->N, FS4 = (size_t)b->F * b->S * 4;
     if (!b->xch) {
       int rc = dmalloc(b, &b->xch, (size_t)b->F * 4 * ((size_t)b->N * b->N + 64));
       if (rc) return rc;
       if ((rc = dmalloc(b, &b->xflags, (size_t)b->F * 2 + 16))) return rc;
-      const size_t FNN = (size_t)b->F * b->N * b->N;
       if ((rc = dmalloc(b, &b->B1, FNN)) || (rc = dmalloc(b, &b->mB1, FNN)) || (rc = dmalloc(b, &b->sB1, FNN))) return rc;
+      if ((rc = dmalloc(b, &b->bkB, FNN)) || (rc = dmalloc(b, &b->bkmB, FNN)) || (rc = dmalloc(b, &b->bksB, FNN)) ||
+          (rc = dmalloc(b, &b->bkstars, FS4)) || (rc = dmalloc(b, &b->bkstars_m, FS4)) || (rc = dmalloc(b, &b->bkstars_s, FS4)))
+        return rc;
     }
-    LC_HIP(b->ctx, hipMemsetAsync(b->xflags, 0, ((size_t)b->F * 2 + 16) * sizeof(int), b->ctx->stream));
+    hipStream_t q = b->ctx->stream;
+    // the 2F iteration flags restart at zero; the abort word and the fall-back counter behind them are never cleared
+    LC_HIP(b->ctx, hipMemsetAsync(b->xflags, 0, (size_t)b->F * 2 * sizeof(int), q));
+    // pre-launch state, for the fall-back launch
+    LC_HIP(b->ctx, hipMemcpyAsync(b->bkB, b->B, FNN * sizeof(float), hipMemcpyDeviceToDevice, q));
+    LC_HIP(b->ctx, hipMemcpyAsync(b->bkmB, b->mB, FNN * sizeof(float), hipMemcpyDeviceToDevice, q));
+    LC_HIP(b->ctx, hipMemcpyAsync(b->bksB, b->sB, FNN * sizeof(float), hipMemcpyDeviceToDevice, q));
+    LC_HIP(b->ctx, hipMemcpyAsync(b->bkstars, b->stars, FS4 * sizeof(float), hipMemcpyDeviceToDevice, q));
+    LC_HIP(b->ctx, hipMemcpyAsync(b->bkstars_m, b->stars_m, FS4 * sizeof(float), hipMemcpyDeviceToDevice, q));
+    LC_HIP(b->ctx, hipMemcpyAsync(b->bkstars_s, b->stars_s, FS4 * sizeof(float), hipMemcpyDeviceToDevice, q));
     A.xch = b->xch;
     A.xflags = b->xflags;
     A.xabort = b->xflags + (size_t)b->F * 2;
+    A.heal_count = b->xflags + (size_t)b->F * 2 + 1;
     A.B1 = b->B1;
     A.mB1 = b->mB1;
     A.sB1 = b->sB1;
+    A.launch_seq = ++b->launch_seq;
+    A.heal = 0;
+    A.force_abort_it = -1;
+    if (const char *fa = std::getenv("LCMI_PSF_FORCE_ABORT")) A.force_abort_it = std::atoi(fa);  // test hook
+    A.bkB = b->bkB;
+    A.bkmB = b->bkmB;
+    A.bksB = b->bksB;
+    A.bkstars = b->bkstars;
+    A.bkstars_m = b->bkstars_m;
+    A.bkstars_s = b->bkstars_s;
     b->split_used = true;
-    LC_HIP(b->ctx, hipFuncSetAttribute((const void *)v->fn_split, hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes));
-    hipLaunchKernelGGL(v->fn_split, dim3(split_grid), dim3(v->nthr), v->lds_bytes, b->ctx->stream, A);
+    hipLaunchKernelGGL(v->fn_split, dim3(split_grid), dim3(v->nthr), v->lds_bytes, q, A);
+    LC_HIP(b->ctx, hipGetLastError());
+    // fall-back: the same launch in the one-workgroup form; every workgroup returns at once unless the launch above gave up
+    A.heal = 1;
+    LC_HIP(b->ctx, hipFuncSetAttribute((const void *)v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes));
+    hipLaunchKernelGGL(v->fn, dim3(b->F), dim3(v->nthr), v->lds_bytes, q, A);
   } else {
+    A.force_abort_it = -1;
     LC_HIP(b->ctx, hipFuncSetAttribute((const void *)v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes));
     hipLaunchKernelGGL(v->fn, dim3(b->F), dim3(v->nthr), v->lds_bytes, b->ctx->stream, A);
   }
@@ -298,13 +340,12 @@ int launch_psf(lc_psf_batch *b, int mode, int n_iter, const lc_adabelief_cfg *cf
   return LC_OK;
 }
 
-// after a synchronisation point: did a partner workgroup of the two-workgroup form fail to show up?
-int check_split_abort(lc_psf_batch *b) {
+// how many two-workgroup launches of this batch gave up and were redone in the one-workgroup form
+int read_split_fallbacks(lc_psf_batch *b, int *count) {
+  *count = 0;
   if (!b->split_used) return LC_OK;
-  int flag = 0;
-  LC_HIP(b->ctx, hipMemcpyAsync(&flag, b->xflags + (size_t)b->F * 2, sizeof(int), hipMemcpyDeviceToHost, b->ctx->stream));
+  LC_HIP(b->ctx, hipMemcpyAsync(count, b->xflags + (size_t)b->F * 2 + 1, sizeof(int), hipMemcpyDeviceToHost, b->ctx->stream));
   LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
-  if (flag) LC_FAIL(b->ctx, LC_ERR_DEVICE, "PSF fit: a partner workgroup timed out; set LCMI_PSF_SINGLE_WG=1");
   return LC_OK;
 }
 
@@ -695,7 +736,13 @@ int lc_psf_batch_get_loss_history(lc_psf_batch *b, float *history, int stride) {
   LC_HIP(b->ctx, hipMemcpy2DAsync(history, stride * sizeof(float), b->hist, b->hist_stride * sizeof(float),
                                    (b->iters_done + 1) * sizeof(float), b->F, hipMemcpyDeviceToHost, b->ctx->stream));
   LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
-  return check_split_abort(b);
+  return LC_OK;
+}
+
+int lc_psf_batch_split_fallbacks(lc_psf_batch *b, int *count) {
+  if (!b || !count) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
+  return read_split_fallbacks(b, count);
 }
 
 int lc_psf_batch_get_results(lc_psf_batch *b, float *narrow_psf, float *full_psf, float *residuals, float *chi2) {
@@ -716,7 +763,7 @@ int lc_psf_batch_get_results(lc_psf_batch *b, float *narrow_psf, float *full_psf
   if (residuals && (rc = d2h(b, residuals, b->resid, b->F * b->S * nn * sizeof(float)))) return rc;
   if (chi2 && (rc = d2h(b, chi2, b->redchi2, b->F * sizeof(float)))) return rc;
   LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
-  return check_split_abort(b);
+  return LC_OK;
 }
 
 #ifdef LC_STAMPS

@@ -46,6 +46,13 @@ struct PsfArgs {
   // per-(frame, role) iteration flags [F][2], one abort word
   float *xch;
   int *xflags, *xabort;
+  // Abort word protocol: a split launch that gives up (a partner that does not show up) stores its own launch
+  // sequence number there; the one-workgroup launch enqueued right behind it with heal = 1 compares the word with the
+  // same number: equal -> it restores the pre-launch state of its frame from the copies below and redoes the whole
+  // launch, different -> it returns at once.  The word is never cleared, so nothing can erase an abort.
+  int launch_seq, heal, force_abort_it;  // force_abort_it >= 0: test hook, role 1 of frame 0 gives up at that iteration
+  const float *bkB, *bkmB, *bksB, *bkstars, *bkstars_m, *bkstars_s;
+  int *heal_count;
   const float *sched;     // [>= t0 + n_iter][3]: learning rate and bias corrections by absolute iteration (host-made)
   float *B1, *mB1, *sB1;  // [F][N*N]: role 1's own copy of the pixel state when it does not fit in registers
 };
@@ -221,6 +228,26 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
   const float *dataf = A.data + (size_t)f * S * n * n;
   const float *wgtf = A.wgt + (size_t)f * S * n * n;
 
+  if constexpr (!SPLIT) {
+    if (A.heal) {  // fall-back launch behind a two-workgroup launch: does anything only if that launch gave up
+      if (__hip_atomic_load(A.xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.launch_seq) return;
+      const size_t o = (size_t)f * N * N;
+      for (int i = tid0; i < N * N; i += NTHR) {
+        A.B[o + i] = A.bkB[o + i];
+        A.mB[o + i] = A.bkmB[o + i];
+        A.sB[o + i] = A.bksB[o + i];
+      }
+      if (tid0 < S * 4) {
+        A.stars[(size_t)f * S * 4 + tid0] = A.bkstars[(size_t)f * S * 4 + tid0];
+        A.stars_m[(size_t)f * S * 4 + tid0] = A.bkstars_m[(size_t)f * S * 4 + tid0];
+        A.stars_s[(size_t)f * S * 4 + tid0] = A.bkstars_s[(size_t)f * S * 4 + tid0];
+      }
+      if (f == 0 && tid0 == 0) atomicAdd(A.heal_count, 1);
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+
   if constexpr (C::WC) {  // aprons (and everything else) of T and of the per-wave tiles start at zero and stay zero
     for (int i = tid0; i < C::SZ_T; i += NTHR) lds[C::OFF_T + i] = 0.f;
     for (int i = tid0; i < C::NW * C::WSZ; i += NTHR) lds[C::OFF_WSC + i] = 0.f;
@@ -270,6 +297,12 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
 
   for (int it = 0; it < A.n_iter; ++it) {
     const int tglob = A.t0 + it;
+    if constexpr (SPLIT) {
+      if (A.force_abort_it == it && f == 0 && role == 1) {  // test hook: this workgroup stops showing up
+        if (tid0 == 0) __hip_atomic_store(A.xabort, A.launch_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
     int tid = tid0;
     LC_LAUNDER(tid);  // everything derived from tid is recomputed per iteration, not kept live
     const int lane = tid & 63, wid = tid >> 6;
@@ -879,8 +912,8 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           ++spins;
           // exit condition every workgroup reaches: a partner that never shows up is reported, not waited for
           if (spins > (1 << 21) ||
-              ((spins & 255) == 0 && __hip_atomic_load(A.xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-            __hip_atomic_store(A.xabort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ((spins & 255) == 0 && __hip_atomic_load(A.xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.launch_seq)) {
+            __hip_atomic_store(A.xabort, A.launch_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = 0;
             break;
           }

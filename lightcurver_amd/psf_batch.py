@@ -97,6 +97,13 @@ class PsfBatch:
     def iterations_done(self):
         return self._l.lc_psf_batch_iterations_done(self.h)
 
+    @property
+    def split_fallbacks(self):
+        """Two-workgroup launches of this batch that gave up and were redone in the one-workgroup form."""
+        c = C.c_int()
+        self._chk(self._l.lc_psf_batch_split_fallbacks(self.h, C.byref(c)), 'split_fallbacks')
+        return c.value
+
     def loss_history(self):
         """(F, T + 1): loss at theta_0 .. theta_T."""
         T = self.iterations_done

@@ -364,5 +364,39 @@ def propagate_noise_psf(p, sigma2, mask, ss):
     return noise_levels_from_impulse(r, mask / sigma2, ss)
 
 
+def distortion_matrix(coef, x, y):
+    """A = [[1 + dilation_x, shear], [shear, 1 + dilation_y]], each entry c0 + c1 x + c2 y (coef: 9 values in the order
+    dilation_x, dilation_y, shear).  DESIGN.md section 3 (frozen, unverified against STARRED)."""
+    c = T(coef).reshape(3, 3)
+    v = c[:, 0] + c[:, 1] * x + c[:, 2] * y
+    return torch.stack([torch.stack([1.0 + v[0], v[2]]), torch.stack([v[2], 1.0 + v[1]])])
+
+
+def apply_distortion(narrow_psf, coef, x, y):
+    """starred.psf.psf.apply_distortion(narrow_psf, kwargs_distortion, star_xy_coordinates) as frozen in DESIGN.md:
+    out[u, v] = bilinear_0(psf, c + A^-1 ((v, u) - c)), c = cref(N), zeros outside the grid, unit sum.
+    Reference call sites: lightcurver/processes/star_photometry.py:303-304, roi_file_preparation.py:179-180."""
+    N = narrow_psf.shape[-1]
+    c = float(cref(N))
+    Ai = torch.linalg.inv(distortion_matrix(coef, T(x), T(y)))
+    idx = torch.arange(N, dtype=DT) - c
+    qx, qy = idx[None, :], idx[:, None]
+    X = c + Ai[0, 0] * qx + Ai[0, 1] * qy
+    Y = c + Ai[1, 0] * qx + Ai[1, 1] * qy
+    x0, y0 = torch.floor(X), torch.floor(Y)
+    fx, fy = X - x0, Y - y0
+    x0, y0 = x0.long(), y0.long()
+    p = T(narrow_psf)
+
+    def at(yy, xx):
+        ok = (yy >= 0) & (yy < N) & (xx >= 0) & (xx < N)
+        return torch.where(ok, p[yy.clamp(0, N - 1), xx.clamp(0, N - 1)], torch.zeros((), dtype=DT))
+
+    top = (1 - fx) * at(y0, x0) + fx * at(y0, x0 + 1)
+    bot = (1 - fx) * at(y0 + 1, x0) + fx * at(y0 + 1, x0 + 1)
+    out = (1 - fy) * top + fy * bot
+    return out / out.sum()
+
+
 def reduced_chi2(data, model, sigma2, mask):
     return float((mask * (data - model) ** 2 / sigma2).sum() / mask.sum())

@@ -1,117 +1,99 @@
-"""End results against the tolerance BASELINE.json's north_star states (fluxes and positions within 1e-4 relative,
-residual chi2 within 1e-5): the same problem run for 300 optimiser iterations by the HIP path (fp32) and by the oracle
-(fp64), at the reference's learning rates.  What holds at that level: fluxes, positions and shifts of well-constrained
-sources.  What does not, and why: AdaBelief with eps = 1e-16 takes sign-like steps of size ~lr wherever a gradient
-component is within rounding of zero (every pixel of the grid / background once it hovers around its optimum, the
-position of a source 15 x fainter than its neighbour), so fp32 and fp64 trajectories decorrelate at the scale of the
-learning rate in those directions; the chi2 of an unconverged fit inherits that at the 1e-4 ... 1e-3 level.  A single
-evaluation at identical parameters agrees to 1e-6 (tests/test_psf_gpu.py, tests/test_joint_gpu.py).  (Against STARRED
-itself the parity is unpinned; this is the statement the oracle allows.)"""
+"""End results at the REFERENCE's iteration counts against the tolerance BASELINE.json's north_star states (fluxes and
+positions within 1e-4 relative, residual chi2 within 1e-5).  The float64 oracle's end results are committed fixtures
+(tests/golden/*_converged.npz, made by tests/golden/make_converged_golden.py); the HIP path (fp32) runs the same
+problems for the same number of iterations at the reference's learning rates.
+
+What is asserted, and why the chi2 bound differs between the cases:
+
+* default star photometry (point sources only, smooth loss): fluxes, shifts 1e-4 and chi2 1e-5 - the north-star numbers.
+* fits with the l1-starlet-regularised pixel grid / background (PSF stage B, ROI stage 2): fluxes and the positions the
+  data constrain within 1e-4 - the north-star numbers - and chi2 within 5e-4.  tests/test_psf_cpu_port_cpu.py
+  (test_two_float64_implementations_agree_but_fp32_trajectories_drift) shows where that floor comes from: two
+  independent float64 implementations of the same fit agree to 1e-9 after 1000 iterations, while the fp32 build of one
+  of them, on identical inputs, ends 1e-5 .. 1e-4 away in the loss - AdaBelief with eps = 1e-16 amplifies rounding at
+  the 6e-8 level about a thousandfold through the pixels whose gradient is within rounding of its running mean.  No
+  fp32 implementation can reproduce a float64 chi2 to 1e-5 there; a single evaluation at identical parameters does
+  (1e-6: tests/test_psf_gpu.py, tests/test_joint_gpu.py).
+(Against STARRED itself the parity is unpinned; this is the statement the oracle allows.)"""
+import os
+
 import numpy as np
 import pytest
 
-from oracle import model as om, optim as oo
-from lightcurver_amd.synthetic import make_psf_dataset, make_roi_dataset
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
-def test_joint_fit_end_results(ctx):
-    from lightcurver_amd.joint import JointFit
-    E, M, n, ss, T = 6, 2, 16, 2, 300
-    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=2024)
-    p = {k: np.array(v, dtype=np.float64) for k, v in ds['truth'].items()}
-    rng = np.random.default_rng(1)
-    p['a'] = p['a'] * rng.uniform(0.8, 1.2, p['a'].shape)
-    p['c_x'] = p['c_x'] + rng.normal(0, 0.2, M)
-    p['c_y'] = p['c_y'] + rng.normal(0, 0.2, M)
-    p['h'] = np.zeros_like(p['h'])
-    data, sig2, psf = om.T(ds['data']), om.T(ds['noisemap']) ** 2, om.T(ds['psf'])
-    W = om.propagate_noise_deconv(sig2, psf, ss)
-    j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
-    j.set_params(**p)
-    j.set_loss(W=W.numpy(), lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
-    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h']
-    j.set_free(free)
-    j.run_adabelief(T, init_learning_rate=1e-3, schedule_learning_rate=True)  # star_photometry.py:117
-    got = j.get_params()
-    model, chi2_e = j.model()
-    fn = lambda q: om.deconv_loss(q, data, sig2, psf, ss, W=W, lam_scales=1.0, lam_hf=1.0, lam_pos=100.0, lam_pts=0.01,
-                                  lam_fu=10.0)
-    po = {k: om.T(v) for k, v in p.items()}
-    pf, lh, l0 = oo.adabelief(fn, po, free, 1e-3, T, schedule=True)
-    mo = om.deconv_model(pf, psf, ss, n)
-    chi2_o = (((data - mo) ** 2) / sig2).sum().item()
-    print('joint: flux', H.rel_err(got['a'], pf['a'].numpy()), 'c_x', np.abs(got['c_x'] - pf['c_x'].numpy()), 'c_y',
-          np.abs(got['c_y'] - pf['c_y'].numpy()), 'dx', np.abs(got['dx'] - pf['dx'].numpy()).max(), 'chi2',
-          abs(chi2_e.sum() - chi2_o) / chi2_o, 'a', pf['a'].numpy()[:2])
-    assert H.rel_err(got['a'], pf['a'].numpy()) < 1e-4                       # north-star level
-    bright = int(np.argmax(pf['a'].numpy()[:M]))
-    assert np.abs(got['c_x'] - pf['c_x'].numpy())[bright] < 1e-4 and np.abs(got['c_y'] - pf['c_y'].numpy())[bright] < 1e-3
-    assert np.abs(got['dx'] - pf['dx'].numpy()).max() < 1e-4 and np.abs(got['dy'] - pf['dy'].numpy()).max() < 1e-3
-    assert np.abs(got['c_x'] - pf['c_x'].numpy()).max() < 5e-3 and np.abs(got['c_y'] - pf['c_y'].numpy()).max() < 5e-3  # ~lr-scale wander of the faint source
-    assert abs(chi2_e.sum() - chi2_o) / chi2_o < 1e-3
-    assert lh[-1] < l0  # the fit went somewhere
-
-
-def test_psf_fit_end_results(ctx):
+def test_psf_fit_end_results_at_3000_iterations(ctx):
     from lightcurver_amd.psf_batch import PsfBatch
-    F, S, n, ss, T = 2, 5, 16, 2, 300
-    ds = make_psf_dataset(F=F, S=S, n=n, ss=ss, seed=2025)
-    rng = np.random.default_rng(2)
-    plist = [H.psf_initial_params(ds, f, ss, rng, 0.2) for f in range(F)]
-    b = PsfBatch(ds['data'], H.weights_from(ds), ss, ctx)
-    b.set_moffat(H.moffat_array(plist))
-    b.set_stars(H.stars_array(plist))
-    b.set_grid(np.stack([p['B'].numpy() for p in plist]))
-    Ws = []
-    for f in range(F):
-        data, sig2, mask = H.psf_oracle_inputs(ds, f, ss)
-        Ws.append(om.propagate_noise_psf(plist[f], sig2, mask, ss))
-    J = om.n_scales(n * ss)
-    b.set_regularization(np.stack([w[:J].numpy() for w in Ws]), 1.0, 1.0)
+    g = np.load(os.path.join(GOLD, 'psf_converged.npz'))
+    ss, T = int(g['ss']), int(g['T'])
+    assert T == 3000
+    w = (g['masks'] / g['noisemap'].astype(np.float64) ** 2).astype(np.float32)
+    b = PsfBatch(g['data'], w, ss, ctx)
+    b.set_moffat(g['moffat'])
+    b.set_stars(g['stars0'])
+    b.set_grid(g['B0'])
+    b.set_regularization(g['W'], 1.0, 1.0)
     b.run_adabelief(T, init_learning_rate=1e-4, schedule_learning_rate=True)
     stars = b.get_stars()
     res = b.results()
-    for f in range(F):
-        data, sig2, mask = H.psf_oracle_inputs(ds, f, ss)
-        fn = lambda q: om.psf_loss(q, data, sig2, mask, ss, W=Ws[f], lam_scales=1.0, lam_hf=1.0)
-        pf, lh, l0 = oo.adabelief(fn, plist[f], ['B', 'a', 'x0', 'y0'], 1e-4, T, schedule=True)
-        chi2_o = om.reduced_chi2(data, om.psf_model(pf, ss, n), sig2, mask)
-        print('psf: flux', H.rel_err(stars[f][:, 0], pf['a'].numpy()), 'x0', np.abs(stars[f][:, 1] - pf['x0'].numpy()).max(),
-              'y0', np.abs(stars[f][:, 2] - pf['y0'].numpy()).max(), 'chi2', abs(res['chi2'][f] - chi2_o) / chi2_o)
-        assert H.rel_err(stars[f][:, 0], pf['a'].numpy()) < 1e-4                   # north-star level
-        assert np.abs(stars[f][:, 1] - pf['x0'].numpy()).max() < 1e-3 and np.abs(stars[f][:, 2] - pf['y0'].numpy()).max() < 1e-3
-        assert abs(res['chi2'][f] - chi2_o) / chi2_o < 5e-3
+    hist = b.loss_history()
+    for f in range(g['data'].shape[0]):
+        flux = H.rel_err(stars[f][:, 0], g['a'][f])
+        dx0, dy0 = np.abs(stars[f][:, 1] - g['x0'][f]).max(), np.abs(stars[f][:, 2] - g['y0'][f]).max()
+        dchi = abs(res['chi2'][f] - g['chi2'][f]) / g['chi2'][f]
+        dloss = abs(hist[f, -1] - g['loss_final'][f]) / g['loss_final'][f]
+        print('psf: flux', flux, 'x0', dx0, 'y0', dy0, 'chi2', dchi, 'loss', dloss)
+        assert flux < 1e-4                       # north-star level
+        assert dx0 < 1e-4 and dy0 < 1e-4         # north-star level (data pixels)
+        assert dchi < 5e-4 and dloss < 5e-4      # fp32 floor of the l1 / AdaBelief trajectory, see the module docstring
+
+
+def test_joint_roi_fit_end_results_at_2000_iterations(ctx):
+    from lightcurver_amd.joint import JointFit
+    g = np.load(os.path.join(GOLD, 'joint_converged.npz'))
+    ss, M, T = int(g['ss']), int(g['M']), int(g['T'])
+    assert T == 2000
+    j = JointFit(g['data'], g['noisemap'].astype(np.float64) ** 2, g['psf'], ss, M, ctx)
+    j.set_params(**{k[3:]: g[k] for k in g.files if k.startswith('p0_')})
+    j.set_loss(W=g['W'], lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
+    j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
+    j.run_adabelief(T, init_learning_rate=1e-4, schedule_learning_rate=False)   # roi_modelling.py:329
+    got = j.get_params()
+    model, chi2_e = j.model()
+    hist = j.loss_history()
+    flux = H.rel_err(got['a'], g['pf_a'])
+    dc = max(np.abs(got['c_x'] - g['pf_c_x']).max(), np.abs(got['c_y'] - g['pf_c_y']).max())
+    dd = max(np.abs(got['dx'] - g['pf_dx']).max(), np.abs(got['dy'] - g['pf_dy']).max())
+    dchi = abs(chi2_e.sum() - float(g['chi2'])) / float(g['chi2'])
+    dloss = abs(hist[-1] - float(g['loss_final'])) / float(g['loss_final'])
+    print('joint: flux', flux, 'c', dc, 'shift', dd, 'chi2', dchi, 'loss', dloss)
+    assert hist[-1] < float(g['loss_initial'])
+    assert flux < 1e-4                           # north-star level
+    assert dc < 1e-4 and dd < 1e-4               # north-star level (data pixels)
+    assert dchi < 5e-4 and dloss < 5e-4          # fp32 floor, see the module docstring
 
 
 def test_star_photometry_end_results_meet_the_north_star_tolerances(ctx):
     """The reference's default star photometry (point source only, star_photometry.py:74-122: learning rate 1e-3 with
-    the schedule): a smooth problem in a handful of parameters per epoch.  After 600 iterations fluxes and shifts agree
-    with the oracle within 1e-4 relative and chi2 within 1e-5."""
+    the schedule, star_deconv_n_iter = 2000): a smooth problem in a handful of parameters per epoch.  Fluxes and shifts
+    agree with the oracle within 1e-4 relative and chi2 within 1e-5."""
     from lightcurver_amd.joint import JointFit
-    E, M, n, ss, T = 6, 1, 16, 2, 600
-    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=2026, with_background=False)
-    p = {k: np.array(v, dtype=np.float64) for k, v in ds['truth'].items()}
-    rng = np.random.default_rng(3)
-    p['a'] = p['a'] * rng.uniform(0.8, 1.2, p['a'].shape)
-    p['h'] = np.zeros_like(p['h'])
-    data, sig2, psf = om.T(ds['data']), om.T(ds['noisemap']) ** 2, om.T(ds['psf'])
-    j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
-    j.set_params(**p)
+    g = np.load(os.path.join(GOLD, 'star_converged.npz'))
+    ss, M, T = int(g['ss']), int(g['M']), int(g['T'])
+    assert T == 2000
+    j = JointFit(g['data'], g['noisemap'].astype(np.float64) ** 2, g['psf'], ss, M, ctx)
+    j.set_params(**{k[3:]: g[k] for k in g.files if k.startswith('p0_')})
     j.set_loss()
-    free = ['a', 'dx', 'dy', 'mean']
-    j.set_free(free)
+    j.set_free(['a', 'dx', 'dy', 'mean'])
     j.run_adabelief(T, init_learning_rate=1e-3, schedule_learning_rate=True)
     got = j.get_params()
     model, chi2_e = j.model()
-    po = {k: om.T(v) for k, v in p.items()}
-    pf, lh, l0 = oo.adabelief(lambda q: om.deconv_loss(q, data, sig2, psf, ss), po, free, 1e-3, T, schedule=True)
-    mo = om.deconv_model(pf, psf, ss, n)
-    chi2_o = (((data - mo) ** 2) / sig2).sum().item()
-    print('star: flux', H.rel_err(got['a'], pf['a'].numpy()), 'dx', np.abs(got['dx'] - pf['dx'].numpy()).max(), 'dy',
-          np.abs(got['dy'] - pf['dy'].numpy()).max(), 'chi2', abs(chi2_e.sum() - chi2_o) / chi2_o)
-    assert H.rel_err(got['a'], pf['a'].numpy()) < 1e-4
-    assert np.abs(got['dx'] - pf['dx'].numpy()).max() < 1e-4 and np.abs(got['dy'] - pf['dy'].numpy()).max() < 1e-4
-    assert abs(chi2_e.sum() - chi2_o) / chi2_o < 1e-5
+    flux = H.rel_err(got['a'], g['pf_a'])
+    dd = max(np.abs(got['dx'] - g['pf_dx']).max(), np.abs(got['dy'] - g['pf_dy']).max())
+    dchi = abs(chi2_e.sum() - float(g['chi2'])) / float(g['chi2'])
+    print('star: flux', flux, 'shift', dd, 'chi2', dchi)
+    assert flux < 1e-4 and dd < 1e-4 and dchi < 1e-5

@@ -241,3 +241,39 @@ def test_two_workgroup_hand_off_under_streaming_load(ctx):
         th.join()
         ctx2.close()
     assert len(rates) >= 1
+
+
+@pytest.mark.parametrize('n,S,F', [(32, 8, 12), (64, 4, 5)])
+def test_two_workgroup_launch_that_gives_up_is_redone_by_the_library(ctx, n, S, F):
+    """A partner workgroup that stops showing up (forced here in role 1 of frame 0 at iteration 7 of the second launch:
+    LCMI_PSF_FORCE_ABORT, a test hook) makes the launch give up; the fall-back launch the library enqueues behind every
+    two-workgroup launch restores the pre-launch state and redoes it in the one-workgroup form.  Loss history, grid and
+    star parameters must equal the one-workgroup result bit for bit, no error is raised, later launches keep working,
+    and the batch reports how many launches were redone."""
+    import os
+    ss, T = 2, 20
+    os.environ['LCMI_PSF_SINGLE_WG'] = '1'
+    try:
+        ds, plist, b = _setup(n, ss, F, S, 700 + n, ctx, jitter=0.1)
+        b.propagate_noise()
+        b.set_regularization(None, 1.0, 1.0)
+        for _ in range(3):
+            b.run_adabelief(T, init_learning_rate=1e-4, schedule_learning_rate=True)
+        ref = (b.loss_history(), b.get_grid(), b.get_stars())
+        assert b.split_fallbacks == 0
+    finally:
+        os.environ.pop('LCMI_PSF_SINGLE_WG', None)
+    ds, plist, b = _setup(n, ss, F, S, 700 + n, ctx, jitter=0.1)
+    b.propagate_noise()
+    b.set_regularization(None, 1.0, 1.0)
+    b.run_adabelief(T, init_learning_rate=1e-4, schedule_learning_rate=True)
+    os.environ['LCMI_PSF_FORCE_ABORT'] = '7'
+    try:
+        b.run_adabelief(T, init_learning_rate=1e-4, schedule_learning_rate=True)
+    finally:
+        os.environ.pop('LCMI_PSF_FORCE_ABORT', None)
+    b.run_adabelief(T, init_learning_rate=1e-4, schedule_learning_rate=True)   # a later launch is not affected
+    got = (b.loss_history(), b.get_grid(), b.get_stars())
+    assert b.split_fallbacks == 1
+    for a, c in zip(got, ref):
+        np.testing.assert_array_equal(a, c)
