@@ -1,0 +1,47 @@
+"""One rank of the two-process HIP test (tests/test_distributed_gpu.py): fits its contiguous block of the epochs on GPU 0
+through lightcurver_amd.distributed.ShardedJointOptimizer with a real JointFit object, the shared block summed over the
+ranks by a gloo all-reduce (both ranks share the one GPU of the test box, where RCCL refuses to run two ranks).
+usage: RANK=r WORLD_SIZE=w MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/_sharded_hip_worker.py out.npz E M n T"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out, E, M, n, T = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lightcurver_amd import _lib
+    from lightcurver_amd.distributed import ShardedJointOptimizer, gather_epoch_blocks, shard_epochs, shard_kwargs
+    from lightcurver_amd.joint import JointFit
+    from lightcurver_amd.synthetic import make_roi_dataset
+    ss = 2
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=4242)
+    p = {k: np.asarray(v, dtype=np.float64) for k, v in ds['truth'].items()}
+    p['a'] = p['a'] * 0.9
+    lo, hi = shard_epochs(E, world, rank)
+    ctx = _lib.Context(0)
+    j = JointFit(ds['data'][lo:hi], ds['noisemap'][lo:hi].astype(np.float64) ** 2, ds['psf'][lo:hi], ss, M, ctx)
+    j.set_params(**shard_kwargs(p, E, M, world, rank))
+    j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
+    j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
+    opt = ShardedJointOptimizer(j)
+    opt.run(T, init_learning_rate=1e-3)
+    ctx.synchronize()
+    hist = j.loss_history()
+    full = gather_epoch_blocks(j.get_params(), M)
+    ref = j.get_flux_reference()
+    if rank == 0:
+        np.savez(out, hist=hist, flux_reference=ref, device_collective=bool(opt._dev), **{'p_' + k: v for k, v in full.items()})
+    dist.barrier()
+    j.close()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -53,3 +53,44 @@ def test_rccl_in_place_all_reduce_world_size_1(ctx):
     a0, a1 = fits[0].get_params()['a'], fits[1].get_params()['a']
     np.testing.assert_array_equal(a0, a1)
     np.testing.assert_array_equal(fits[0].get_params()['h'], fits[1].get_params()['h'])
+
+
+def test_two_hip_ranks_equal_the_unsharded_fit(ctx, tmp_path):
+    """Two processes, each with its own JointFit over half of the epochs (both on the one GPU of the box, the shared
+    block all-reduced over gloo), driven by ShardedJointOptimizer: the replicas of h / c and the gathered per-epoch
+    parameters must equal the single-object fit of all epochs (fp32 summation order of the epoch reduction aside),
+    including the flux-uniformity term whose centred moments need one flux reference on all ranks."""
+    import os
+    import subprocess
+    import sys
+    from lightcurver_amd.joint import JointFit
+    E, M, n, ss, T = 12, 2, 32, 2, 10
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=4242)
+    p = {k: np.asarray(v, dtype=np.float64) for k, v in ds['truth'].items()}
+    p['a'] = p['a'] * 0.9
+    full = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
+    full.set_params(**p)
+    full.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
+    full.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
+    for _ in range(T):   # the same step-by-step drive the sharded optimiser uses
+        full.step_local()
+        full.step_update(init_learning_rate=1e-3)
+    pf, hf = full.get_params(), full.loss_history()
+    out = tmp_path / 'sharded.npz'
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_sharded_hip_worker.py')
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, worker, str(out), str(E), str(M), str(n), str(T)], env=env))
+    for pr in procs:
+        assert pr.wait(timeout=600) == 0
+    g = np.load(out)
+    assert not bool(g['device_collective'])   # gloo staging here; the RCCL path is the world-size-1 test above
+    assert np.allclose(g['flux_reference'], full.get_flux_reference(), rtol=1e-6)
+    assert np.abs(g['hist'][:T] - hf[:T]).max() <= 2e-5 * np.abs(hf).max()
+    assert np.abs(g['p_a'] - pf['a']).max() <= 2e-5 * np.abs(pf['a']).max()
+    for k in ('c_x', 'c_y', 'dx', 'dy'):
+        assert np.abs(g['p_' + k] - pf[k]).max() <= 2e-5, k
+    assert np.abs(g['p_h'] - pf['h']).max() <= 0.02 * T * 1e-3 + 1e-7   # a sign flip of a ~0 gradient moves a pixel by <= 2 lr
+    assert np.median(np.abs(g['p_h'] - pf['h'])) <= 1e-6
