@@ -120,6 +120,7 @@ int lc_psf_batch_get_weights(lc_psf_batch *b, float *W);
 /* One evaluation at the current parameters.  Any output may be NULL.
  *   loss [F] (0.5 chi2 + l1), chi2 [F], grad_moffat [F][4], grad_stars [F][S_max][4] (a,x0,y0,sky),
  *   grad_grid [F][N*N] (d loss / d B, regularisation included), model [F][S_max][n][n]. */
+/* (after lc_psf_batch_set_moffat_q, grad_moffat is d loss / d (q11, q12, q22, beta)) */
 int lc_psf_batch_eval(lc_psf_batch *b, float *loss, float *chi2, float *grad_moffat,
                       float *grad_stars, float *grad_grid, float *model);
 /* Stage A of build_psf: Moffat + a, x0, y0 by bounded L-BFGS with B = 0 (n_iter_analytic). */
@@ -139,6 +140,25 @@ int lc_psf_batch_get_loss_history(lc_psf_batch *b, float *history, int stride);
  * reduced chi2 [F] over unmasked pixels. */
 int lc_psf_batch_get_results(lc_psf_batch *b, float *narrow_psf, float *full_psf, float *residuals,
                              float *chi2);
+
+/* ---- build_psf(field_distortion=True): lightcurver/processes/psf_modelling.py:164-171 with field_distortion and
+ * stamp_coordinates.  Star i of a frame sees T_i = Moffat_i + W_i[B] (csrc/psf_distort.h).  Two
+ * batches work together: `frames` (F frames; holds B, the starlet term and the AdaBelief state of B) and `stars` (F * S
+ * single-star frames, frame-major; holds the stamps, each star's Moffat by its quadratic form, and the AdaBelief state of
+ * a, x0, y0).  One iteration = forward (resample B for every star) -> step of `stars` with export_grad -> backward
+ * (adjoint resampling summed over the stars) -> step of `frames` with use_ext_grad; everything asynchronous. */
+int lc_psf_batch_set_moffat_q(lc_psf_batch *b, const float *q /* [F][4] = q11, q12, q22, beta */);
+int lc_psf_batch_set_distortion(lc_psf_batch *frames, int S_stars, const float *coeffs /* [F][9] */,
+                                const float *xy /* [F][S_stars][2] rescaled frame coordinates */);
+int lc_psf_distortion_forward(lc_psf_batch *frames, lc_psf_batch *stars);
+int lc_psf_distortion_backward(lc_psf_batch *frames, lc_psf_batch *stars);
+int lc_psf_batch_get_ext_grad(lc_psf_batch *b, float *grad /* [F][N*N] */);
+int lc_psf_batch_step_adabelief(lc_psf_batch *b, const lc_adabelief_cfg *cfg, int use_ext_grad, int export_grad);
+/* The batched bounded L-BFGS of the analytic stage with a caller-supplied evaluation (the distortion fit adds nine
+ * coefficients per frame to the variables): x, lo, hi [nb][D]; eval fills F [nb] and G [nb][D] for the trial points X. */
+int lc_batched_lbfgs(int nb, int D, double *x, const double *lo, const double *hi, int maxiter,
+                     int (*eval)(void *user, const double *X, double *F, double *G), void *user,
+                     double *f_final /* [nb] or NULL */, int *evaluations /* or NULL */);
 
 /* ---- field distortion of the narrow PSF: replaces starred.psf.psf.apply_distortion ------------
  * Reference call sites: lightcurver/processes/star_photometry.py:291-304, roi_file_preparation.py:169-180

@@ -18,8 +18,10 @@ PARAM_INDEX = {'a': P_A, 'c_x': P_CX, 'c_y': P_CY, 'dx': P_DX, 'dy': P_DY, 'alph
                'h': P_H, 'mean': P_MEAN}
 
 fp = C.POINTER(C.c_float)
+dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int32)
 vp = C.c_void_p
+LBFGS_EVAL = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp, dp)
 
 
 class AdabeliefCfg(C.Structure):
@@ -69,6 +71,13 @@ SIGNATURES = {
     'lc_psf_batch_split_fallbacks': (C.c_int, [vp, C.POINTER(C.c_int)]),
     'lc_psf_batch_get_loss_history': (C.c_int, [vp, fp, C.c_int]),
     'lc_psf_batch_get_results': (C.c_int, [vp, fp, fp, fp, fp]),
+    'lc_psf_batch_set_moffat_q': (C.c_int, [vp, fp]),
+    'lc_psf_batch_set_distortion': (C.c_int, [vp, C.c_int, fp, fp]),
+    'lc_psf_distortion_forward': (C.c_int, [vp, vp]),
+    'lc_psf_distortion_backward': (C.c_int, [vp, vp]),
+    'lc_psf_batch_get_ext_grad': (C.c_int, [vp, fp]),
+    'lc_psf_batch_step_adabelief': (C.c_int, [vp, C.POINTER(AdabeliefCfg), C.c_int, C.c_int]),
+    'lc_batched_lbfgs': (C.c_int, [C.c_int, C.c_int, dp, dp, dp, C.c_int, LBFGS_EVAL, vp, dp, C.POINTER(C.c_int)]),
     'lc_apply_distortion': (C.c_int, [vp, C.c_int, C.c_int, fp, fp, fp, fp]),
     'lc_joint_supported': (C.c_int, [C.c_int, C.c_int]),
     'lc_joint_set_debug_global': (C.c_int, [C.c_int]),

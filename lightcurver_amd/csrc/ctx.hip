@@ -2,6 +2,7 @@
 #include <cstring>
 
 #include "lc_common.h"
+#include "lbfgs_host.h"
 
 static thread_local std::string g_create_error;
 
@@ -86,6 +87,26 @@ int lc_timer_stop(lc_ctx *ctx, float *elapsed_ms) {
   LC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   LC_HIP(ctx, hipEventSynchronize(ctx->ev1));
   LC_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+  return LC_OK;
+}
+
+// The batched projected L-BFGS of the Moffat stage (csrc/lbfgs_host.h) with the evaluation left to the caller: nb
+// independent problems of D variables advance in lock step, `eval` returns every loss and gradient for one set of trial
+// points (one device launch per call in the callers of this library).
+int lc_batched_lbfgs(int nb, int D, double *x, const double *lo, const double *hi, int maxiter,
+                     int (*eval)(void *user, const double *X, double *F, double *G), void *user, double *f_final,
+                     int *evaluations) {
+  if (nb <= 0 || D <= 0 || !x || !lo || !hi || !eval || maxiter < 0) return LC_ERR_INVALID;
+  std::vector<double> xv(x, x + (size_t)nb * D), lov(lo, lo + (size_t)nb * D), hiv(hi, hi + (size_t)nb * D);
+  lc::LbfgsResult res;
+  lc::BatchEval fn = [&](const std::vector<double> &X, std::vector<double> &F, std::vector<double> &G) -> int {
+    return eval(user, X.data(), F.data(), G.data());
+  };
+  const int rc = lc::batched_lbfgs(nb, D, xv, lov, hiv, maxiter, fn, res);
+  if (rc) return rc;
+  std::copy(xv.begin(), xv.end(), x);
+  if (f_final) std::copy(res.f.begin(), res.f.end(), f_final);
+  if (evaluations) *evaluations = res.evaluations;
   return LC_OK;
 }
 

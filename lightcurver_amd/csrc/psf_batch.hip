@@ -11,6 +11,7 @@
 
 #include "psf_kernels.h"
 #include "psf_noise.h"
+#include "psf_distort.h"
 
 using namespace lc;
 
@@ -32,6 +33,13 @@ struct lc_psf_batch {
   int launch_seq = 0;       // sequence number of the two-workgroup launches (abort word protocol, psf_kernels.h)
   float *bkB = nullptr, *bkmB = nullptr, *bksB = nullptr, *bkstars = nullptr, *bkstars_m = nullptr, *bkstars_s = nullptr;
   int split_blocks_per_cu = -1;  // occupancy of the two-workgroup kernel (queried once)
+  // field distortion (csrc/psf_distort.h): Moffat given by its quadratic form, distortion of the stars of every frame,
+  // external gradient of B
+  bool moffat_is_q = false;
+  float *moffat_q = nullptr, *o_gq = nullptr;  // [F][4]
+  float *dist_coef = nullptr, *dist_xy = nullptr, *ext_grad = nullptr;  // [F][9], [F][S_stars][2], [F][N*N]
+  int dist_S = 0;
+  bool use_ext_grad = false;
   float *o_loss = nullptr, *o_chi2 = nullptr, *o_gstars = nullptr, *o_ggrid = nullptr, *o_gT = nullptr,
         *o_model = nullptr, *o_gmoffat = nullptr;
   float *narrow = nullptr, *full = nullptr, *resid = nullptr, *redchi2 = nullptr;
@@ -247,6 +255,7 @@ int launch_psf(lc_psf_batch *b, int mode, int n_iter, const lc_adabelief_cfg *cf
     A.out_gT = b->o_gT;
     A.out_model = b->o_model;
   }
+  A.ext_grad = b->use_ext_grad ? b->ext_grad : nullptr;
   A.lam_sc = reg ? b->lam_sc : 0.f;
   A.lam_hf = reg ? b->lam_hf : 0.f;
   if (cfg) A.ab = *cfg; else lc_adabelief_defaults(&A.ab);
@@ -470,6 +479,77 @@ int lc_psf_batch_set_moffat(lc_psf_batch *b, const float *moffat) {
   if (rc) return rc;
   hipLaunchKernelGGL(moffat_raster_kernel, dim3(b->F), dim3(256), 0, b->ctx->stream, b->N, b->ss, b->moffat, b->Tm);
   LC_HIP(b->ctx, hipGetLastError());
+  b->moffat_is_q = false;
+  return LC_OK;
+}
+int lc_psf_batch_set_moffat_q(lc_psf_batch *b, const float *q) {
+  if (!b || !q) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
+  int rc;
+  if (!b->moffat_q && (rc = dmalloc(b, &b->moffat_q, (size_t)b->F * 4))) return rc;
+  if ((rc = h2d(b, b->moffat_q, q, (size_t)b->F * 4 * sizeof(float)))) return rc;
+  hipLaunchKernelGGL(moffat_q_raster_kernel, dim3(b->F), dim3(256), 0, b->ctx->stream, b->N, b->moffat_q, b->Tm);
+  LC_HIP(b->ctx, hipGetLastError());
+  b->moffat_is_q = true;
+  return LC_OK;
+}
+int lc_psf_batch_set_distortion(lc_psf_batch *b, int S_stars, const float *coeffs, const float *xy) {
+  if (!b || !coeffs || !xy || S_stars <= 0) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
+  for (size_t i = 0; i < (size_t)b->F * 9; ++i)
+    if (!std::isfinite(coeffs[i]) || std::fabs(coeffs[i]) > 0.25f)
+      LC_FAIL(b->ctx, LC_ERR_INVALID, "lc_psf_batch_set_distortion: coefficients must be finite and within +-0.25");
+  int rc;
+  if (b->dist_S != S_stars) {
+    b->dist_coef = b->dist_xy = nullptr;  // earlier buffers stay in the allocation list until the object goes
+    if ((rc = dmalloc(b, &b->dist_coef, (size_t)b->F * 9)) || (rc = dmalloc(b, &b->dist_xy, (size_t)b->F * S_stars * 2))) return rc;
+    if (!b->ext_grad && (rc = dmalloc(b, &b->ext_grad, (size_t)b->F * b->N * b->N))) return rc;
+    b->dist_S = S_stars;
+  }
+  if ((rc = h2d(b, b->dist_coef, coeffs, (size_t)b->F * 9 * sizeof(float)))) return rc;
+  return h2d(b, b->dist_xy, xy, (size_t)b->F * S_stars * 2 * sizeof(float));
+}
+// frames->B resampled at every star -> stars->B (stars: one single-star frame per (frame, star), frame-major)
+int lc_psf_distortion_forward(lc_psf_batch *frames, lc_psf_batch *stars) {
+  if (!frames || !stars) return LC_ERR_INVALID;
+  LC_ENTER(frames->ctx);
+  if (frames->ctx != stars->ctx || frames->dist_S <= 0 || stars->F != frames->F * frames->dist_S || stars->N != frames->N)
+    LC_FAIL(frames->ctx, LC_ERR_INVALID, "lc_psf_distortion_forward: the star batch must hold F * S single-star frames of the same grid");
+  hipLaunchKernelGGL(psf_warp_kernel, dim3(stars->F), dim3(256), 0, frames->ctx->stream, frames->N, frames->dist_S,
+                     frames->dist_coef, frames->dist_xy, frames->B, stars->B);
+  LC_HIP(frames->ctx, hipGetLastError());
+  return LC_OK;
+}
+// adjoint: the gradients d loss / d B of the star batch (from its last step / evaluation) -> frames' external gradient
+int lc_psf_distortion_backward(lc_psf_batch *frames, lc_psf_batch *stars) {
+  if (!frames || !stars) return LC_ERR_INVALID;
+  LC_ENTER(frames->ctx);
+  if (frames->ctx != stars->ctx || frames->dist_S <= 0 || stars->F != frames->F * frames->dist_S || stars->N != frames->N)
+    LC_FAIL(frames->ctx, LC_ERR_INVALID, "lc_psf_distortion_backward: the star batch must hold F * S single-star frames of the same grid");
+  hipLaunchKernelGGL(psf_warp_adjoint_kernel, dim3(frames->F), dim3(256), 0, frames->ctx->stream, frames->N, frames->dist_S,
+                     frames->dist_coef, frames->dist_xy, stars->o_ggrid, frames->ext_grad);
+  LC_HIP(frames->ctx, hipGetLastError());
+  frames->use_ext_grad = true;
+  return LC_OK;
+}
+int lc_psf_batch_get_ext_grad(lc_psf_batch *b, float *grad) {
+  if (!b || !grad) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
+  if (!b->ext_grad) LC_FAIL(b->ctx, LC_ERR_INVALID, "no external gradient: lc_psf_batch_set_distortion first");
+  return d2h(b, grad, b->ext_grad, (size_t)b->F * b->N * b->N * sizeof(float));
+}
+// one AdaBelief iteration; export_grad: also leave d loss / d B of that iteration on the device for
+// lc_psf_distortion_backward; use_ext_grad: add the external gradient to d loss / d B
+int lc_psf_batch_step_adabelief(lc_psf_batch *b, const lc_adabelief_cfg *cfg, int use_ext_grad, int export_grad) {
+  if (!b) return LC_ERR_INVALID;
+  LC_ENTER(b->ctx);
+  if (use_ext_grad && !b->ext_grad) LC_FAIL(b->ctx, LC_ERR_INVALID, "no external gradient: lc_psf_batch_set_distortion first");
+  int rc = ensure_hist(b, b->iters_done + 2);
+  if (rc) return rc;
+  b->use_ext_grad = use_ext_grad != 0;
+  rc = launch_psf(b, 1, 1, cfg, export_grad != 0, true);
+  if (rc) return rc;
+  b->iters_done += 1;
   return LC_OK;
 }
 int lc_psf_batch_get_moffat(lc_psf_batch *b, float *moffat) {
@@ -614,8 +694,11 @@ int lc_psf_batch_eval(lc_psf_batch *b, float *loss, float *chi2, float *grad_mof
   rc = launch_psf(b, 0, 1, nullptr, true, true);
   if (rc) return rc;
   if (grad_moffat) {
-    hipLaunchKernelGGL(moffat_grad_kernel, dim3(b->F), dim3(256), 0, b->ctx->stream, b->N, b->ss, b->moffat, b->o_gT,
-                       b->o_gmoffat);
+    if (b->moffat_is_q)  // d loss / d (q11, q12, q22, beta) of the quadratic-form Moffat (lc_psf_batch_set_moffat_q)
+      hipLaunchKernelGGL(moffat_q_grad_kernel, dim3(b->F), dim3(256), 0, b->ctx->stream, b->N, b->moffat_q, b->o_gT, b->o_gmoffat);
+    else
+      hipLaunchKernelGGL(moffat_grad_kernel, dim3(b->F), dim3(256), 0, b->ctx->stream, b->N, b->ss, b->moffat, b->o_gT,
+                         b->o_gmoffat);
     LC_HIP(b->ctx, hipGetLastError());
   }
   const size_t NN = (size_t)b->N * b->N, nn = (size_t)b->n * b->n;

@@ -53,6 +53,8 @@ struct PsfArgs {
   int launch_seq, heal, force_abort_it;  // force_abort_it >= 0: test hook, role 1 of frame 0 gives up at that iteration
   const float *bkB, *bkmB, *bksB, *bkstars, *bkstars_m, *bkstars_s;
   int *heal_count;
+  const float *ext_grad;  // [F][N*N] or null: an additional d loss / d B, added to the chi2 part (distortion fit: sum over the
+                          // stars of the adjoint resampling of their gradients, csrc/psf_distort.h)
   const float *sched;     // [>= t0 + n_iter][3]: learning rate and bias corrections by absolute iteration (host-made)
   float *B1, *mB1, *sB1;  // [F][N*N]: role 1's own copy of the pixel state when it does not fit in registers
 };
@@ -833,6 +835,10 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       }
       LC_STAMP(17);
     }  // groups
+    if (A.ext_grad) {
+#pragma unroll
+      for (int p = 0; p < PX; ++p) gB[p] += A.ext_grad[gpix + p];
+    }
     }  // conv_role
     __syncthreads();
     LC_STAMP(40);

@@ -78,7 +78,7 @@ def do_one_star_forward_modelling(data, noisemap, psf, subsampling_factor, n_ite
     optim = Optimizer(loss, pars, method='adabelief')
     optim.minimize(max_iterations=n_iter, min_iterations=None, init_learning_rate=1e-3, schedule_learning_rate=True,
                    restart_from_init=True, stop_at_loss_increase=False, progress_bar=True,
-                   return_param_history=True)
+                   return_param_history=False)  # the reference asks for it (True) and never reads it; False keeps the loop on the device
     k_final = pars.best_fit_values(as_kwargs=True)
 
     residuals = data - np.array(model.model(k_final))

@@ -41,6 +41,33 @@ class PsfBatch:
         self._chk(self._l.lc_psf_batch_get_moffat(self.h, ptr(m)), 'get_moffat')
         return m
 
+    # -- field distortion (include/lcmi.h, "build_psf(field_distortion=True)") -----------------------------------
+    def set_moffat_q(self, q):
+        """Moffat of every frame by its quadratic form: q [F][4] = q11, q12, q22, beta."""
+        q = f32(q).reshape(self.F, 4)
+        self._chk(self._l.lc_psf_batch_set_moffat_q(self.h, ptr(q)), 'set_moffat_q')
+
+    def set_distortion(self, S_stars, coeffs, xy):
+        c = f32(coeffs).reshape(self.F, 9)
+        p = f32(xy).reshape(self.F, int(S_stars), 2)
+        self._chk(self._l.lc_psf_batch_set_distortion(self.h, int(S_stars), ptr(c), ptr(p)), 'set_distortion')
+
+    def distortion_forward(self, stars):
+        self._chk(self._l.lc_psf_distortion_forward(self.h, stars.h), 'distortion_forward')
+
+    def distortion_backward(self, stars):
+        self._chk(self._l.lc_psf_distortion_backward(self.h, stars.h), 'distortion_backward')
+
+    def get_ext_grad(self):
+        g = np.empty((self.F, self.N, self.N), np.float32)
+        self._chk(self._l.lc_psf_batch_get_ext_grad(self.h, ptr(g)), 'get_ext_grad')
+        return g
+
+    def step_adabelief(self, use_ext_grad=False, export_grad=False, **cfg):
+        c = _lib.adabelief_cfg(**cfg)
+        self._chk(self._l.lc_psf_batch_step_adabelief(self.h, C.byref(c), int(bool(use_ext_grad)), int(bool(export_grad))),
+                  'step_adabelief')
+
     def set_stars(self, stars):
         s = f32(stars).reshape(self.F, self.S, 4)
         self._chk(self._l.lc_psf_batch_set_stars(self.h, ptr(s)), 'set_stars')

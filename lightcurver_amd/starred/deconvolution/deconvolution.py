@@ -1,6 +1,8 @@
 """``Deconv`` / ``setup_model``: the joint multi-epoch forward model STARRED exposes and
 lightcurver drives (reference call sites: lightcurver/processes/star_photometry.py:66-69,124,137;
 roi_modelling.py:213-219,387,470).  The arithmetic runs in liblcmi.so (lc_joint_*)."""
+import hashlib
+
 import numpy as np
 
 from ...joint import JointFit
@@ -45,6 +47,7 @@ class Deconv:
         self._ctx = ctx
         self._fit = None
         self._fit_key = None
+        self._sigma2_f32 = None
 
     # -- device object management -------------------------------------------------------------------
     def _ensure_fit(self, data=None, sigma_2=None):
@@ -55,12 +58,15 @@ class Deconv:
             return self._fit
         data = np.asarray(data)
         sigma_2 = np.asarray(sigma_2)
-        key = (data.shape, float(np.nansum(data[..., ::3, ::3])), float(np.nansum(sigma_2[..., ::3, ::3])))
+        # every byte counts: the reference masks / boosts single pixels between calls (star_photometry.py:309-316)
+        key = (data.shape, str(data.dtype), hashlib.blake2b(np.ascontiguousarray(data).tobytes(), digest_size=16).digest(),
+               hashlib.blake2b(np.ascontiguousarray(sigma_2).tobytes(), digest_size=16).digest())
         if self._fit is None or key != self._fit_key:
             if self._fit is not None:
                 self._fit.close()
             self._fit = JointFit(data, sigma_2, self.psf, self.upsampling_factor, self.M, self._ctx)
             self._fit_key = key
+            self._sigma2_f32 = np.asarray(sigma_2, dtype=np.float32).copy()  # what propagate_noise compares with
         return self._fit
 
     def _push(self, kwargs):

@@ -30,27 +30,46 @@ class Optimizer:
     def _run_adabelief(self, max_iterations=100, min_iterations=None, init_learning_rate=1e-2,
                        schedule_learning_rate=True, restart_from_init=False, stop_at_loss_increase=False,
                        progress_bar=False, return_param_history=False, decay_rate=0.99, transition_steps=10):
-        if stop_at_loss_increase:
-            raise NotImplementedError('stop_at_loss_increase=True (lightcurver always passes False)')
         p = self._param
         start = p._start if restart_from_init else p._current
         fit = self._loss.configure()
         fit.set_params(**start)
         fit.set_free(p.free)
         n_iter = int(max_iterations)
-        if n_iter > 0:
-            fit.run_adabelief(n_iter, init_learning_rate=init_learning_rate,
-                              schedule_learning_rate=bool(schedule_learning_rate), decay_rate=decay_rate,
-                              transition_steps=transition_steps)
+        cfg = dict(init_learning_rate=init_learning_rate, schedule_learning_rate=bool(schedule_learning_rate),
+                   decay_rate=decay_rate, transition_steps=transition_steps)
+        param_history = []
+        if n_iter > 0 and not stop_at_loss_increase and not return_param_history:
+            fit.run_adabelief(n_iter, **cfg)       # one call: the whole loop stays on the device
+        elif n_iter > 0:
+            # the parameter vector after every update (return_param_history) and / or the early stop need the host in
+            # the loop: the iterations run in chunks (1 for the history, 10 for the early stop alone); the optimiser
+            # state and the iteration count live on the device, so chunking does not change the trajectory
+            chunk = 1 if return_param_history else 10
+            min_it = 0 if min_iterations is None else int(min_iterations)
+            done = 0
+            while done < n_iter:
+                k = min(chunk, n_iter - done)
+                fit.run_adabelief(k, **cfg)
+                if return_param_history:
+                    flat_now = {kk: np.asarray(v, dtype=np.float64) for kk, v in fit.get_params().items()}
+                    param_history.append(p.kwargs2args(_nest(flat_now)))
+                if stop_at_loss_increase:
+                    h = np.asarray(fit.loss_history(), dtype=np.float64)   # loss at theta_0 .. theta_(done + k)
+                    t = np.arange(max(done, 1), done + k + 1)
+                    if np.any((h[t] > h[t - 1]) & (t >= max(min_it, 1))):    # an update made the loss go up
+                        done += k
+                        break
+                done += k
         hist = fit.loss_history()
         final = fit.get_params()
         flat = {k: np.asarray(v, dtype=np.float64) for k, v in final.items()}
         p.set_best_fit(flat)
-        # loss_history[t] = loss after update t (len == max_iterations, no early stop)
+        # loss_history[t] = loss after update t (len == the number of iterations run: max_iterations without early stop)
         self.loss_history = [float(v) for v in hist[1:]]
         extra = {'loss_history': np.array(self.loss_history), 'initial_loss': float(hist[0])}
         if return_param_history:
-            extra['param_history'] = [p.kwargs2args(_nest(start)), p.best_fit_values()]
+            extra['param_history'] = param_history
         return p.best_fit_values(), -float(hist[-1]), extra
 
     # -- L-BFGS-B: scipy on the host, loss + gradient on the device ------------------------------------
@@ -62,17 +81,22 @@ class Optimizer:
         fit.set_free(p.free)
         x0 = p.kwargs2args(_nest(start))
         lo, hi = p.bounds()
-        hist = []
+        hist, last = [], {}
 
         def fun(x):
-            return self._loss.value_and_grad(x)
+            val, grad = self._loss.value_and_grad(x)
+            last['x'], last['val'] = np.array(x, copy=True), val   # scipy's callback gets the accepted point: its loss
+            return val, grad                                       # was the most recent evaluation, no second one needed
+
+        def record(xk):
+            hist.append(last['val'] if 'x' in last and np.array_equal(last['x'], xk) else fun(xk)[0])
 
         if x0.size == 0:
             val, _ = fun(x0)
             self.loss_history = [val]
             return x0, -val, {'loss_history': np.array([val])}
         res = _scipy_minimize(fun, x0, jac=True, method='L-BFGS-B', bounds=list(zip(lo, hi)),
-                              options={'maxiter': int(maxiter)}, callback=lambda xk: hist.append(fun(xk)[0]))
+                              options={'maxiter': int(maxiter)}, callback=record)
         flat = p.args2flat(res.x)
         fit.set_params(**flat)
         p.set_best_fit(flat)

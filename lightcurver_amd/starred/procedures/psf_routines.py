@@ -46,8 +46,6 @@ def build_psf_batch(images, noisemaps, subsampling_factor, masks=None, n_iter_an
 
     Returns one result dict per frame with the keys of STARRED's ``build_psf``.
     """
-    if field_distortion:
-        raise NotImplementedError('field_distortion=True is not built yet (DESIGN.md, out-of-scope list)')
     F = len(images)
     if F == 0:
         return []
@@ -89,6 +87,13 @@ def build_psf_batch(images, noisemaps, subsampling_factor, masks=None, n_iter_an
         moffat[f] = (f0, f0, 0.0, 2.5)
 
     ctx = ctx or _lib.default_context(device)
+    if field_distortion:
+        if stamp_coordinates is None:
+            raise ValueError('field_distortion=True needs stamp_coordinates (rescaled frame positions of the stamps)')
+        coords = stamp_coordinates if F > 1 or np.asarray(stamp_coordinates[0]).ndim == 2 else [stamp_coordinates]
+        return _fit_with_distortion(images, data, weight, norms, stars, moffat, S_list, coords, ss, n, ctx,
+                                    int(n_iter_analytic), int(n_iter_adabelief), float(regularization_strength_scales),
+                                    float(regularization_strength_hf), init_learning_rate, schedule_learning_rate)
     b = PsfBatch(data, weight, ss, ctx)
     try:
         b.set_moffat(moffat)
@@ -132,6 +137,162 @@ def build_psf_batch(images, noisemaps, subsampling_factor, masks=None, n_iter_an
             'analytic_extra_fields': {'final_loss': None if analytic_loss is None else float(analytic_loss[f])},
             'adabelief_extra_fields': {'loss_history': [float(v) for v in hist[f, 1:]],
                                        'initial_loss': float(hist[f, 0])},
+        })
+    return out
+
+
+DISTORTION_BOUND = 0.2   # |coefficient| <= 0.2: the resampling kernels assume a distortion close to the identity
+
+
+def quadratic_forms(theta, xy, ss):
+    """(fwhm_x, fwhm_y, phi, beta, 9 distortion coefficients) [F][13] and star coordinates [F][S][2] ->
+    q [F][S][4] = (q11, q12, q22, beta) of the Moffat each star sees: Q_i = A_i^-T Q A_i^-1 (csrc/psf_distort.h)."""
+    fx, fy, phi, beta = theta[:, 0, None], theta[:, 1, None], theta[:, 2, None], theta[:, 3, None]
+    c = theta[:, 4:13]
+    x, y = xy[..., 0], xy[..., 1]
+    a00 = 1.0 + c[:, 0, None] + c[:, 1, None] * x + c[:, 2, None] * y
+    a11 = 1.0 + c[:, 3, None] + c[:, 4, None] * x + c[:, 5, None] * y
+    a01 = c[:, 6, None] + c[:, 7, None] * x + c[:, 8, None] * y
+    det = a00 * a11 - a01 * a01
+    i00, i01, i11 = a11 / det, -a01 / det, a00 / det
+    kb = 2.0 * np.sqrt(2.0 ** (1.0 / beta) - 1.0)
+    ax, ay = ss * fx / kb, ss * fy / kb
+    cs, sn = np.cos(phi), np.sin(phi)
+    # Q = R^T diag(1/ax^2, 1/ay^2) R with xr = x cos + y sin, yr = -x sin + y cos
+    dx, dy = 1.0 / ax ** 2, 1.0 / ay ** 2
+    q11, q12, q22 = dx * cs * cs + dy * sn * sn, (dx - dy) * cs * sn, dx * sn * sn + dy * cs * cs
+    # A^-T Q A^-1 (A^-1 symmetric)
+    m11 = i00 * q11 + i01 * q12
+    m12 = i00 * q12 + i01 * q22
+    m21 = i01 * q11 + i11 * q12
+    m22 = i01 * q12 + i11 * q22
+    out = np.stack([m11 * i00 + m12 * i01, m11 * i01 + m12 * i11, m21 * i01 + m22 * i11, np.broadcast_to(beta, x.shape)], axis=-1)
+    return out
+
+
+def _fit_with_distortion(images, data, weight, norms, stars, moffat, S_list, coords, ss, n, ctx, n_iter_analytic,
+                         n_iter_adabelief, lam_scales, lam_hf, init_learning_rate, schedule_learning_rate):
+    """build_psf(field_distortion=True): see include/lcmi.h ("build_psf(field_distortion=True)") for the two-batch scheme."""
+    import ctypes as C
+    F, S = data.shape[0], data.shape[1]
+    N = n * ss
+    xy = np.zeros((F, S, 2))
+    for f in range(F):
+        cf = np.asarray(coords[f], dtype=np.float64).reshape(-1, 2)
+        if cf.shape[0] != S_list[f]:
+            raise ValueError('stamp_coordinates must hold one (x, y) per stamp of the frame')
+        xy[f, :S_list[f]] = cf
+    star_b = PsfBatch(data.reshape(F * S, 1, n, n), weight.reshape(F * S, 1, n, n), ss, ctx)
+    frame_b = PsfBatch(np.zeros((F, 1, n, n)), np.zeros((F, 1, n, n)), ss, ctx)
+    lib = _lib.lib()
+    try:
+        star_b.set_grid(None)
+        # ---- stage A: Moffat + distortion + amplitudes / positions, pixel grid zero (batched bounded L-BFGS) ------
+        D = 13 + 3 * S
+        x = np.zeros((F, D))
+        x[:, 0:4] = moffat
+        x[:, 13:13 + S] = stars[..., 0]
+        x[:, 13 + S:13 + 2 * S] = stars[..., 1]
+        x[:, 13 + 2 * S:] = stars[..., 2]
+        lo, hi = np.empty((F, D)), np.empty((F, D))
+        lo[:, 0:2], hi[:, 0:2] = 0.5 / ss, n / 2.0
+        lo[:, 2], hi[:, 2] = -math.pi, math.pi
+        lo[:, 3], hi[:, 3] = 1.1, 50.0
+        lo[:, 4:13], hi[:, 4:13] = -DISTORTION_BOUND, DISTORTION_BOUND
+        lo[:, 13:13 + S], hi[:, 13:13 + S] = 0.0, np.inf
+        lo[:, 13 + S:], hi[:, 13 + S:] = -n / 4.0, n / 4.0
+        sky = stars[..., 3].copy()
+
+        def push(X):
+            q = quadratic_forms(X[:, :13], xy, ss)
+            star_b.set_moffat_q(q.reshape(F * S, 4))
+            st = np.stack([X[:, 13:13 + S], X[:, 13 + S:13 + 2 * S], X[:, 13 + 2 * S:], sky], axis=-1)
+            star_b.set_stars(st.reshape(F * S, 1, 4))
+            return q
+
+        def evaluate(_user, Xp, Fp, Gp):
+            X = np.ctypeslib.as_array(Xp, shape=(F, D)).copy()
+            q = push(X)
+            out = star_b.evaluate()
+            gq = out['grad_moffat'].astype(np.float64).reshape(F, S, 4)
+            gs = out['grad_stars'].astype(np.float64).reshape(F, S, 4)
+            G = np.zeros((F, D))
+            # chain rule through the (smooth) map theta -> q by central differences in double
+            for k in range(13):
+                h = 1e-6 * max(1.0, float(np.abs(X[:, k]).max()))
+                Xp_, Xm_ = X[:, :13].copy(), X[:, :13].copy()
+                Xp_[:, k] += h
+                Xm_[:, k] -= h
+                dq = (quadratic_forms(Xp_, xy, ss) - quadratic_forms(Xm_, xy, ss)) / (2.0 * h)
+                G[:, k] = (gq * dq).sum(axis=(1, 2))
+            G[:, 13:13 + S], G[:, 13 + S:13 + 2 * S], G[:, 13 + 2 * S:] = gs[..., 0], gs[..., 1], gs[..., 2]
+            np.ctypeslib.as_array(Fp, shape=(F,))[:] = out['loss'].astype(np.float64).reshape(F, S).sum(axis=1)
+            np.ctypeslib.as_array(Gp, shape=(F, D))[:] = G
+            return 0
+
+        cb = _lib.LBFGS_EVAL(evaluate)
+        dp = _lib.dp
+        xf = np.ascontiguousarray(x)
+        fl = np.zeros(F)
+        nev = C.c_int()
+        rc = lib.lc_batched_lbfgs(F, D, xf.ctypes.data_as(dp), np.ascontiguousarray(lo).ctypes.data_as(dp),
+                                  np.ascontiguousarray(hi).ctypes.data_as(dp), n_iter_analytic, cb, None,
+                                  fl.ctypes.data_as(dp), C.byref(nev))
+        if rc:
+            raise _lib.LcError(f'lc_batched_lbfgs failed with status {rc}')
+        push(xf)
+        theta = xf[:, :13]
+        # ---- stage B: free the pixel grid; l1-starlet weights from the noise propagation of the undistorted stars ------
+        frame_b.set_moffat(theta[:, 0:4])
+        frame_b.set_grid(None)
+        st_now = star_b.get_stars().reshape(F, S, 4)
+        tmp = PsfBatch(data, weight, ss, ctx)
+        try:
+            tmp.set_moffat(theta[:, 0:4])
+            tmp.set_stars(st_now)
+            tmp.propagate_noise()
+            W = tmp.get_weights()
+        finally:
+            tmp.close()
+        frame_b.set_regularization(W, lam_scales, lam_hf)
+        frame_b.set_distortion(S, theta[:, 4:13], xy)
+        star_b.set_regularization(None, 0.0, 0.0)
+        cfg = dict(init_learning_rate=init_learning_rate, schedule_learning_rate=schedule_learning_rate)
+        for _ in range(n_iter_adabelief):
+            frame_b.distortion_forward(star_b)                       # B seen by every star
+            star_b.step_adabelief(export_grad=True, **cfg)           # chi2, its gradients, step of a, x0, y0
+            frame_b.distortion_backward(star_b)                      # d chi2 / d B summed over the stars
+            frame_b.step_adabelief(use_ext_grad=True, **cfg)         # starlet term + step of B
+        frame_b.distortion_forward(star_b)
+        hist = frame_b.loss_history() + star_b.loss_history().reshape(F, S, -1).sum(axis=1)
+        res_f = frame_b.results()
+        res_s = star_b.results()
+        st = star_b.get_stars().astype(np.float64).reshape(F, S, 4)
+        grid = frame_b.get_grid()
+    finally:
+        star_b.close()
+        frame_b.close()
+
+    out = []
+    resid_all = res_s['residuals'].reshape(F, S, n, n)
+    for f in range(F):
+        Sf = S_list[f]
+        wf = weight[f, :Sf]
+        chi2 = float((wf * resid_all[f, :Sf].astype(np.float64) ** 2).sum() / max((wf > 0).sum(), 1))
+        resid = resid_all[f, :Sf].astype(np.float64) * norms[f]
+        kwargs_psf = {
+            'kwargs_moffat': {'fwhm_x': np.array([theta[f, 0]]), 'fwhm_y': np.array([theta[f, 1]]),
+                              'phi': np.array([theta[f, 2]]), 'beta': np.array([theta[f, 3]]), 'C': np.array([1.0])},
+            'kwargs_gaussian': {'a': st[f, :Sf, 0] * norms[f], 'x0': st[f, :Sf, 1], 'y0': st[f, :Sf, 2]},
+            'kwargs_background': {'background': grid[f].reshape(N * N), 'mean': st[f, :Sf, 3] * norms[f]},
+            'kwargs_distortion': {'dilation_x': theta[f, 4:7].copy(), 'dilation_y': theta[f, 7:10].copy(),
+                                  'shear': theta[f, 10:13].copy()},
+        }
+        out.append({
+            'full_psf': res_f['full_psf'][f], 'narrow_psf': res_f['narrow_psf'][f],
+            'models': np.asarray(images[f], dtype=np.float64) - resid, 'residuals': resid, 'kwargs_psf': kwargs_psf,
+            'chi2': chi2, 'norm': norms[f], 'analytic_extra_fields': {'final_loss': float(fl[f])},
+            'adabelief_extra_fields': {'loss_history': [float(v) for v in hist[f, 1:]], 'initial_loss': float(hist[f, 0])},
         })
     return out
 

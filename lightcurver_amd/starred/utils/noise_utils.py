@@ -23,8 +23,10 @@ def propagate_noise(model, noise_maps, kwargs=None, masks=None, wavelet_type_lis
     sigma2 = noise_maps ** 2
     fit = model._fit
     temp = None
-    if fit is None or fit.E != noise_maps.shape[0] or model._fit_key is None or \
-            abs(model._fit_key[2] - float(np.nansum(sigma2[..., ::3, ::3]))) > 1e-6 * abs(model._fit_key[2]):
+    # the model's device object can serve when it was built on these very variances (the fp32 values the device holds)
+    same = (fit is not None and fit.E == noise_maps.shape[0] and getattr(model, '_sigma2_f32', None) is not None
+            and model._sigma2_f32.shape == sigma2.shape and np.array_equal(model._sigma2_f32, sigma2.astype(np.float32)))
+    if not same:
         temp = fit = JointFit(np.zeros_like(sigma2), sigma2, model.psf, model.upsampling_factor, model.M, model._ctx)
     try:
         W = fit.propagate_noise()

@@ -398,5 +398,71 @@ def apply_distortion(narrow_psf, coef, x, y):
     return out / out.sum()
 
 
+def moffat_distorted(N, ss, fwhm_x, fwhm_y, phi, beta, A):
+    """The elliptical Moffat seen through the distortion A: M(A^-1 (u - c)), unit sum on the grid."""
+    c = cref(N)
+    idx = torch.arange(N, dtype=fwhm_x.dtype) - c
+    x, y = idx[None, :], idx[:, None]
+    Ai = torch.linalg.inv(A)
+    qx, qy = Ai[0, 0] * x + Ai[0, 1] * y, Ai[1, 0] * x + Ai[1, 1] * y
+    k = 2.0 * torch.sqrt(2.0 ** (1.0 / beta) - 1.0)
+    ax, ay = ss * fwhm_x / k, ss * fwhm_y / k
+    xr = qx * torch.cos(phi) + qy * torch.sin(phi)
+    yr = -qx * torch.sin(phi) + qy * torch.cos(phi)
+    m = (1.0 + (xr / ax) ** 2 + (yr / ay) ** 2) ** (-beta)
+    return m / m.sum()
+
+
+def warp_grid(B, A):
+    """W_A[B](u) = bilinear_0(B, c + A^-1 (u - c)) / det A: the pixel grid resampled through the distortion."""
+    N = B.shape[-1]
+    c = float(cref(N))
+    Ai = torch.linalg.inv(A)
+    idx = torch.arange(N, dtype=DT) - c
+    qx, qy = idx[None, :], idx[:, None]
+    X = c + Ai[0, 0] * qx + Ai[0, 1] * qy
+    Y = c + Ai[1, 0] * qx + Ai[1, 1] * qy
+    x0, y0 = torch.floor(X).detach(), torch.floor(Y).detach()
+    fx, fy = X - x0, Y - y0
+    x0, y0 = x0.long(), y0.long()
+
+    def at(yy, xx):
+        ok = (yy >= 0) & (yy < N) & (xx >= 0) & (xx < N)
+        return torch.where(ok, B[yy.clamp(0, N - 1), xx.clamp(0, N - 1)], torch.zeros((), dtype=DT))
+
+    top = (1 - fx) * at(y0, x0) + fx * at(y0, x0 + 1)
+    bot = (1 - fx) * at(y0 + 1, x0) + fx * at(y0 + 1, x0 + 1)
+    return ((1 - fy) * top + fy * bot) / torch.linalg.det(A)
+
+
+def psf_model_distorted(p, xy, ss, n):
+    """build_psf(field_distortion=True) as frozen in DESIGN.md section 3: star i at the rescaled frame coordinates
+    xy[i] sees T_i = Moffat seen through A_i + W_{A_i}[B];  p['dist']: the 9 distortion coefficients."""
+    N = ss * n
+    c0 = (N - 1) / 2.0
+    S = p['a'].shape[0]
+    B = p['B'].reshape(N, N)
+    out = []
+    for i in range(S):
+        A = distortion_matrix(p['dist'], T(xy[i][0]), T(xy[i][1]))
+        Ti = moffat_distorted(N, ss, p['fwhm_x'], p['fwhm_y'], p['phi'], p['beta'], A) + warp_grid(B, A)
+        G = gaussian_stack(N, (c0 + ss * p['x0'][i]).reshape(1), (c0 + ss * p['y0'][i]).reshape(1), torch.ones(1, dtype=DT))
+        out.append(p['a'][i] * blocksum(conv_same(G, Ti), ss) + p['sky'][i])
+    return torch.stack(out)
+
+
+def psf_loss_distorted(p, xy, data, sigma2, mask, ss, W=None, lam_scales=0.0, lam_hf=0.0):
+    S, n, _ = data.shape
+    N = ss * n
+    J = n_scales(N)
+    m = psf_model_distorted(p, xy, ss, n)
+    total = 0.5 * (mask * (data - m) ** 2 / sigma2).sum()
+    if lam_scales != 0.0 or lam_hf != 0.0:
+        if W is None:
+            W = default_W(N, J, m.dtype)
+        total = total + l1_starlet(p['B'].reshape(N, N), W, lam_scales, lam_hf, J)
+    return total
+
+
 def reduced_chi2(data, model, sigma2, mask):
     return float((mask * (data - model) ** 2 / sigma2).sum() / mask.sum())

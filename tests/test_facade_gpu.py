@@ -112,3 +112,85 @@ def test_kwargs_manipulations_and_two_stage_fit():
     assert sig.shape == (E * M,) and np.all(sig > 0)
     # de-interleave per source as roi_modelling.py:462 does
     assert sig[0::M].shape == (E,)
+
+
+def _small_fit(n_free=('a', 'dx', 'dy')):
+    from lightcurver_amd.starred.deconvolution.deconvolution import setup_model
+    from lightcurver_amd.starred.deconvolution.loss import Loss
+    from lightcurver_amd.starred.deconvolution.parameters import ParametersDeconv
+    from lightcurver_amd.synthetic import make_roi_dataset
+    ds = make_roi_dataset(E=5, M=1, n=16, ss=2, seed=9, with_background=False)
+    data, noise, s = ds['data'].astype(np.float64), ds['noisemap'].astype(np.float64), ds['psf']
+    a0 = list(0.8 * np.asarray(ds['truth']['a']))
+    model, k_init, k_up, k_down, _ = setup_model(data, noise ** 2, s, np.array([0.]), np.array([0.]), 2, a0)
+    fixed = deepcopy(k_init)
+    for name in n_free:
+        del fixed['kwargs_analytic'][name]
+    pars = ParametersDeconv(kwargs_init=k_init, kwargs_fixed=fixed, kwargs_up=k_up, kwargs_down=k_down)
+    return model, pars, Loss(data, model, pars, noise ** 2), data, noise, s, k_init
+
+
+def test_param_history_and_early_stop():
+    """return_param_history=True (the reference passes it: star_photometry.py:119, roi_modelling.py:331) returns the
+    parameter vector after EVERY update; the chunked drive it needs must not change the trajectory.
+    stop_at_loss_increase=True stops at the first increase of the loss after min_iterations."""
+    from lightcurver_amd.starred.optim.optimization import Optimizer
+    T = 25
+    model, pars, loss, *_ = _small_fit()
+    opt = Optimizer(loss, pars, method='adabelief')
+    best, logL, extra, _ = opt.minimize(max_iterations=T, init_learning_rate=1e-3, schedule_learning_rate=True,
+                                        restart_from_init=True, return_param_history=True)
+    ph = extra['param_history']
+    assert len(ph) == T and all(np.asarray(v).shape == np.asarray(best).shape for v in ph)
+    assert np.array_equal(np.asarray(ph[-1]), np.asarray(best))
+    assert np.any(np.asarray(ph[0]) != np.asarray(ph[5]))
+    hist_chunked = list(opt.loss_history)
+    model2, pars2, loss2, *_ = _small_fit()
+    opt2 = Optimizer(loss2, pars2, method='adabelief')
+    best2, *_ = opt2.minimize(max_iterations=T, init_learning_rate=1e-3, schedule_learning_rate=True, restart_from_init=True)
+    assert hist_chunked == list(opt2.loss_history) and np.array_equal(np.asarray(best), np.asarray(best2))  # same bits
+    # early stop: a learning rate of 0.3 (fluxes ~10, shifts in pixels) overshoots within a few steps
+    model3, pars3, loss3, *_ = _small_fit()
+    opt3 = Optimizer(loss3, pars3, method='adabelief')
+    opt3.minimize(max_iterations=400, min_iterations=5, init_learning_rate=0.3, schedule_learning_rate=False,
+                  restart_from_init=True, stop_at_loss_increase=True)
+    lh = np.array(opt3.loss_history)
+    assert 10 <= lh.size < 400 and lh.size % 10 == 0 and np.any(np.diff(lh) > 0)
+
+
+def test_edited_pixels_are_seen_by_the_device_object():
+    """Deconv re-uploads its inputs whenever ANY byte of data / variance changed (full hash), e.g. after masking a
+    single pixel between two calls as star_photometry.py:309-316 does."""
+    model, pars, loss, data, noise, s, k_init = _small_fit()
+    m0 = np.array(model.model(k_init))
+    fit0 = model._ensure_fit(data, noise ** 2)
+    assert model._ensure_fit(data, noise ** 2) is fit0          # unchanged inputs: same device object
+    noise2 = noise.copy()
+    noise2[2, 5, 7] *= 1000.0                                    # one pixel, off any sub-sampling grid
+    fit1 = model._ensure_fit(data, noise2 ** 2)
+    assert fit1 is not fit0
+    _, chi2_a = fit1.model()
+    fit2 = model._ensure_fit(data, noise ** 2)
+    _, chi2_b = fit2.model()
+    assert chi2_a[2] != chi2_b[2] and np.array_equal(np.delete(chi2_a, 2), np.delete(chi2_b, 2))
+    assert np.array_equal(np.array(model.model(k_init)), m0)
+
+
+def test_outputs_have_the_shapes_the_plotting_modules_index():
+    """lightcurver/plotting/psf_plotting.py:36-105 indexes residuals[i] (2-D per star) and full_psf (2-D) and plots
+    loss_curve; joint_modelling_plotting.py:30-95 broadcasts residuals / noisemaps as (E, n, n) and shows a 2-D
+    starlet_background and deconvolved_image.  The restated step functions must hand over exactly that."""
+    from lightcurver_amd.processes.star_photometry import do_one_star_forward_modelling
+    from lightcurver_amd.starred.procedures.psf_routines import build_psf
+    from lightcurver_amd.synthetic import make_psf_dataset
+    ds = make_psf_dataset(F=1, S=4, n=16, ss=2, seed=12)
+    res = build_psf(image=ds['data'][0], noisemap=ds['noisemap'][0], subsampling_factor=2, masks=ds['masks'][0],
+                    n_iter_analytic=20, n_iter_adabelief=30, guess_method_star_position='center', guess_fwhm_pixels=3.0)
+    assert res['full_psf'].ndim == 2 and res['narrow_psf'].shape == (32, 32)
+    assert len(res['residuals']) == 4 and all(np.asarray(r).shape == (16, 16) for r in res['residuals'])
+    assert np.asarray(res['adabelief_extra_fields']['loss_history']).shape == (30,)
+    assert f"{res['chi2']:.02f}"                                  # psf_modelling.py:224 formats it
+    data, noisemap, psf = _fixture()
+    out = do_one_star_forward_modelling(data, noisemap, psf, 1, 20)
+    assert (out['residuals'] / noisemap).shape == data.shape      # joint_modelling_plotting.py:30-32
+    assert out['starlet_background'].ndim == 2 and out['deconvolved_image'].ndim == 2
