@@ -270,7 +270,7 @@ def c3_shard_workload(ctx, iters=200):
             'value': F * S * iters / (ms * 1e-3), 'unit': 'cutouts/sec', 'us_per_iteration': ms * 1e3 / iters,
             'roofline': hbm_roofline(F * S * iters * bytes_per, ms * 1e-3, 'psf_fit_kernel (N = 128)',
                                      {'algorithmic_bytes_per_cutout_iteration': bytes_per,
-                                      'fp32_valu_frac_of_157': F * S * iters * 70.0 * N * N / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}),
+                                      'fp32_valu_frac_of_157': F * S * iters * 58.5 * N * N / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}),
             'loss_finite': bool(np.all(np.isfinite(hist)))}
 
 
@@ -316,7 +316,8 @@ def sharded_joint_fit(ctx, rank, world, iters=500):
     dt = float(t[0])
     hist = j.loss_history()
     j.close()
-    return {'workload': f'C4 sharded: {E} epochs x {n}x{n} ROI over {world} ranks, RCCL all-reduce of the shared block '
+    transport = 'RCCL all-reduce in place in device memory' if opt._dev else 'gloo all-reduce staged through the host (one-GPU rehearsal)'
+    return {'workload': f'C4 sharded: {E} epochs x {n}x{n} ROI over {world} ranks, {transport} of the shared block '
                         f'({n * ss * n * ss + 4 * M + 2} floats) once per iteration, {iters} iterations',
             'value': E * iters / dt, 'unit': 'cutouts/sec', 'us_per_iteration': dt * 1e6 / iters, 'scaling': 'strong',
             'rccl_ranks': world, 'device_collective': bool(opt._dev), 'loss_finite': bool(np.all(np.isfinite(hist)))}
@@ -408,7 +409,7 @@ def main():
         bytes_per = psf_bytes_per_cutout_iteration(n, ss, S)
         launch_s = kernel_ms * 1e-3 / args.steps
         N = n * ss
-        flops_per = 70.0 * N * N  # separable passes: 35 N^2 MAC per stamp-iteration
+        flops_per = 58.5 * N * N  # separable 13-tap passes: 29.25 N^2 multiply-adds per stamp-iteration
         roof = hbm_roofline(F * S * ITERS_PER_STEP * bytes_per, launch_s, 'psf_fit_kernel',
                             {'algorithmic_bytes_per_cutout_iteration': bytes_per,
                              'fp32_valu_tflops': F * S * ITERS_PER_STEP * flops_per / launch_s / 1e12,

@@ -196,16 +196,14 @@ __global__ void gm_pts_inner_kernel(int N, int ss, int M, const float *q, const 
 }
 // ordered final sums -> regs[2] = value of the term, regs[4 + 3 i + q] = the three inner products of source i
 __global__ void gm_pts_final_kernel(int nblocks, int M, const float *part, const float *l1_part, float *regs) {
-  const int t = threadIdx.x;
-  if (t < 3 * M) {
+  // one wave: every quantity is summed by the 64 lanes striding over the blocks (4 independent loads in flight per
+  // lane), then across the lanes in a fixed order - the serial loop of one thread per quantity cost 60 us at 256 blocks
+  const int lane = threadIdx.x;
+  for (int t = 0; t <= 3 * M; ++t) {
     float acc = 0.f;
-    for (int b = 0; b < nblocks; ++b) acc += part[(size_t)b * 3 * kMaxSources + t];
-    regs[4 + t] = acc;
-  }
-  if (t == 63) {
-    float acc = 0.f;
-    for (int b = 0; b < nblocks; ++b) acc += l1_part[b];
-    regs[2] = acc;
+    for (int b = lane; b < nblocks; b += 64) acc += (t < 3 * M) ? part[(size_t)b * 3 * kMaxSources + t] : l1_part[b];
+    acc = wave_sum_shfl(acc);
+    if (lane == 0) regs[(t < 3 * M) ? 4 + t : 2] = acc;
   }
 }
 
