@@ -211,6 +211,13 @@ int lc_joint_model(lc_joint *j, float *model, float *chi2_per_epoch);
 /* Deconv.getDeconvolved(kwargs, epoch) -> high-res scene and background, [N][N] each */
 int lc_joint_deconvolved(lc_joint *j, int epoch, float *scene, float *background);
 int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg);
+/* Optimizer(method='l-bfgs-b').minimize(maxiter=...) (roi_modelling.py:278-280, starred_utilities.py:33-34): bounded
+ * L-BFGS on the free blocks with parameters, gradients, direction and (s, y) history on the device; the host reads a few
+ * scalars per trial point.  lower / upper: per block, length of the block, or NULL (unbounded); may be NULL altogether.
+ * loss_history[i] = loss after accepted iteration i (up to history_capacity entries). */
+int lc_joint_run_lbfgs(lc_joint *j, int maxiter, const float *const lower[LC_P_COUNT],
+                       const float *const upper[LC_P_COUNT], float *loss_history, int history_capacity,
+                       int *n_iterations, int *n_evaluations);
 int lc_joint_get_loss_history(lc_joint *j, float *history, int count);
 int lc_joint_iterations_done(lc_joint *j);
 /* FisherCovariance(diagonal_only=True) with only `a` free -> sigma(a) [E*M]

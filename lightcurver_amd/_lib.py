@@ -94,6 +94,7 @@ SIGNATURES = {
     'lc_joint_model': (C.c_int, [vp, fp, fp]),
     'lc_joint_deconvolved': (C.c_int, [vp, C.c_int, fp, fp]),
     'lc_joint_run_adabelief': (C.c_int, [vp, C.c_int, C.POINTER(AdabeliefCfg)]),
+    'lc_joint_run_lbfgs': (C.c_int, [vp, C.c_int, C.POINTER(fp), C.POINTER(fp), fp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'lc_joint_get_loss_history': (C.c_int, [vp, fp, C.c_int]),
     'lc_joint_iterations_done': (C.c_int, [vp]),
     'lc_joint_fisher_flux_sigma': (C.c_int, [vp, fp]),

@@ -1,6 +1,8 @@
 // Joint multi-epoch forward-model object behind the C ABI (include/lcmi.h, "joint" section).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <limits>
 #include <complex>
 #include <thread>
 #include <cstring>
@@ -9,6 +11,7 @@
 #include "joint_gm.h"
 #include "joint_ps.h"
 #include "joint_noise.h"
+#include "joint_lbfgs.h"
 #include "noise_host.h"
 #include "starlet_norms.h"
 
@@ -882,6 +885,165 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
   return rc;
 }
 int lc_joint_iterations_done(lc_joint *j) { return j ? j->iters_done : LC_ERR_INVALID; }
+
+// ---- bounded L-BFGS with the vectors on the device (csrc/joint_lbfgs.h) ------------------------------------------------
+int lc_joint_run_lbfgs(lc_joint *j, int maxiter, const float *const lower[LC_P_COUNT], const float *const upper[LC_P_COUNT],
+                       float *loss_history, int history_capacity, int *n_iterations, int *n_evaluations) {
+  if (!j || maxiter < 0) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
+  int D = 0, off[LC_P_COUNT] = {};
+  for (int k = 0; k < LC_P_COUNT; ++k) {
+    off[k] = D;
+    if (j->free_mask[k]) D += j->psize[k];
+  }
+  if (n_iterations) *n_iterations = 0;
+  if (n_evaluations) *n_evaluations = 0;
+  if (D == 0) return LC_OK;
+  hipStream_t q = j->ctx->stream;
+  const float inf = std::numeric_limits<float>::infinity();
+  std::vector<float> lo((size_t)D, -inf), hi((size_t)D, inf);
+  for (int k = 0; k < LC_P_COUNT; ++k) {
+    if (!j->free_mask[k]) continue;
+    for (int i = 0; i < j->psize[k]; ++i) {
+      if (lower && lower[k]) lo[off[k] + i] = lower[k][i];
+      if (upper && upper[k]) hi[off[k] + i] = upper[k][i];
+    }
+  }
+  // device work space (freed on every exit path)
+  float *buf = nullptr;
+  int *order_dev = nullptr;
+  const size_t nvec = 7 + 2 * (size_t)kLbMem;
+  LC_HIP(j->ctx, hipMalloc((void **)&buf, (nvec * D + kLbMem + 8) * sizeof(float)));
+  struct Guard {
+    float *b;
+    int **o;
+    ~Guard() {
+      (void)hipFree(b);
+      if (*o) (void)hipFree(*o);
+    }
+  } guard{buf, &order_dev};
+  LC_HIP(j->ctx, hipMalloc((void **)&order_dev, kLbMem * sizeof(int)));
+  LbfgsDev L;
+  L.D = D;
+  L.x = buf;
+  L.g = buf + (size_t)D;
+  L.xt = buf + 2 * (size_t)D;
+  L.gt = buf + 3 * (size_t)D;
+  L.dir = buf + 4 * (size_t)D;
+  float *dlo = buf + 5 * (size_t)D, *dhi = buf + 6 * (size_t)D;
+  L.lo = dlo;
+  L.hi = dhi;
+  L.S = buf + 7 * (size_t)D;
+  L.Y = L.S + (size_t)kLbMem * D;
+  L.rho = L.Y + (size_t)kLbMem * D;
+  L.scal = L.rho + kLbMem;
+  LC_HIP(j->ctx, hipMemcpyAsync(dlo, lo.data(), (size_t)D * sizeof(float), hipMemcpyHostToDevice, q));
+  LC_HIP(j->ctx, hipMemcpyAsync(dhi, hi.data(), (size_t)D * sizeof(float), hipMemcpyHostToDevice, q));
+  auto pack = [&](float *const src[LC_P_COUNT], float *vec) -> int {   // parameter blocks -> flat vector
+    for (int k = 0; k < LC_P_COUNT; ++k)
+      if (j->free_mask[k])
+        LC_HIP(j->ctx, hipMemcpyAsync(vec + off[k], src[k], (size_t)j->psize[k] * sizeof(float), hipMemcpyDeviceToDevice, q));
+    return LC_OK;
+  };
+  auto unpack = [&](const float *vec) -> int {                          // flat vector -> parameter blocks
+    for (int k = 0; k < LC_P_COUNT; ++k)
+      if (j->free_mask[k])
+        LC_HIP(j->ctx, hipMemcpyAsync(j->par[k], vec + off[k], (size_t)j->psize[k] * sizeof(float), hipMemcpyDeviceToDevice, q));
+    return LC_OK;
+  };
+  const bool want_h = j->free_mask[LC_P_H] != 0;
+  float host[8];
+  int evals = 0;
+  // loss and gradient at the parameters now on the device -> (out_loss, gout); gradient packed into `gvec`
+  auto evaluate = [&](float *gvec, float &loss) -> int {
+    int need = launch_epochs(j, 0, 0, want_h, nullptr);
+    if (need < 0) return need;
+    int rc = launch_reduce(j, need);
+    if (rc) return rc;
+    if ((rc = launch_update(j, 0, 0, nullptr, false, true))) return rc;
+    if ((rc = pack(j->gout, gvec))) return rc;
+    LC_HIP(j->ctx, hipMemcpyAsync(host, j->out_loss, sizeof(float), hipMemcpyDeviceToHost, q));
+    LC_HIP(j->ctx, hipStreamSynchronize(q));
+    loss = host[0];
+    ++evals;
+    return LC_OK;
+  };
+  int rc;
+  if ((rc = pack(j->par, L.x))) return rc;
+  // start inside the box
+  hipLaunchKernelGGL(lb_trial_kernel, dim3(1), dim3(kLbThreads), 0, q, L, 0.f);
+  LC_HIP(j->ctx, hipMemcpyAsync(L.x, L.xt, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, q));
+  if ((rc = unpack(L.x))) return rc;
+  float f = 0.f;
+  if ((rc = evaluate(L.g, f))) return rc;
+  int n_hist = 0;
+  auto record = [&](float v) {
+    if (loss_history && n_hist < history_capacity) loss_history[n_hist] = v;
+    ++n_hist;
+  };
+  int m = 0, head = 0, iters = 0;  // m pairs stored, next slot = head
+  const float c1 = 1e-4f, gtol = 1e-6f, ftol = 2.2e-9f;
+  bool finite = std::isfinite(f);
+  while (finite && iters < maxiter) {
+    int order[kLbMem];
+    for (int k = 0; k < m; ++k) order[k] = (head - m + k + 2 * kLbMem) % kLbMem;  // oldest .. newest
+    LC_HIP(j->ctx, hipMemcpyAsync(order_dev, order, sizeof(order), hipMemcpyHostToDevice, q));
+    hipLaunchKernelGGL(lb_direction_kernel, dim3(1), dim3(kLbThreads), 0, q, L, m, order_dev);
+    LC_HIP(j->ctx, hipMemcpyAsync(host, L.scal, 3 * sizeof(float), hipMemcpyDeviceToHost, q));
+    LC_HIP(j->ctx, hipStreamSynchronize(q));
+    float gd = host[0], dd = host[1];
+    const float pgmax = host[2];
+    if (pgmax < gtol * std::max(1.f, std::fabs(f))) break;
+    if (!(gd < 0.f)) {  // not a descent direction: restart from steepest descent
+      m = 0;
+      hipLaunchKernelGGL(lb_steepest_kernel, dim3(1), dim3(kLbThreads), 0, q, L);
+      LC_HIP(j->ctx, hipMemcpyAsync(host, L.scal, 2 * sizeof(float), hipMemcpyDeviceToHost, q));
+      LC_HIP(j->ctx, hipStreamSynchronize(q));
+      gd = host[0];
+      dd = host[1];
+      if (!(gd < 0.f)) break;
+    }
+    float alpha = (m == 0) ? std::min(1.f, 1.f / std::sqrt(std::max(dd, 1e-30f))) : 1.f;
+    bool accepted = false;
+    float ft = f;
+    for (int ls = 0; ls < 25; ++ls) {
+      hipLaunchKernelGGL(lb_trial_kernel, dim3(1), dim3(kLbThreads), 0, q, L, alpha);
+      if ((rc = unpack(L.xt))) return rc;
+      if ((rc = evaluate(L.gt, ft))) return rc;
+      LC_HIP(j->ctx, hipMemcpyAsync(host, L.scal + 3, sizeof(float), hipMemcpyDeviceToHost, q));
+      LC_HIP(j->ctx, hipStreamSynchronize(q));
+      const float dec = host[0];
+      if (std::isfinite(ft) && ft <= f + c1 * dec) {
+        accepted = true;
+        break;
+      }
+      alpha *= 0.5f;
+    }
+    if (!accepted) {  // line search failed: back to the last accepted point
+      if ((rc = unpack(L.x))) return rc;
+      break;
+    }
+    hipLaunchKernelGGL(lb_accept_kernel, dim3(1), dim3(kLbThreads), 0, q, L, head);
+    LC_HIP(j->ctx, hipMemcpyAsync(host, L.scal + 4, 3 * sizeof(float), hipMemcpyDeviceToHost, q));
+    LC_HIP(j->ctx, hipStreamSynchronize(q));
+    const float sy = host[0], ss = host[1], yy = host[2];
+    if (sy > 1e-10f * std::sqrt(ss * yy) && sy > 0.f) {  // keep the pair (the slot was written by the kernel)
+      head = (head + 1) % kLbMem;
+      m = std::min(m + 1, kLbMem);
+    }
+    const float fold = f;
+    f = ft;
+    ++iters;
+    record(f);
+    if (std::fabs(fold - f) <= ftol * std::max({std::fabs(fold), std::fabs(f), 1.f})) break;
+  }
+  LC_HIP(j->ctx, hipGetLastError());
+  LC_HIP(j->ctx, hipStreamSynchronize(q));
+  if (n_iterations) *n_iterations = iters;
+  if (n_evaluations) *n_evaluations = evals;
+  if (n_hist == 0) record(f);
+  return finite ? LC_OK : LC_ERR_NONFINITE;
+}
 
 int lc_joint_get_loss_history(lc_joint *j, float *history, int count) {
   if (!j || !history || count < j->iters_done + 1) return LC_ERR_INVALID;

@@ -114,6 +114,24 @@ class JointFit:
         c = _lib.adabelief_cfg(**cfg)
         self._chk(self._l.lc_joint_run_adabelief(self.h, int(n_iter), C.byref(c)), 'run_adabelief')
 
+    def run_lbfgs(self, maxiter, lower=None, upper=None):
+        """Bounded L-BFGS on the free blocks, vectors on the device (lc_joint_run_lbfgs).  lower / upper: dicts
+        name -> array (missing = unbounded).  Returns (loss history per accepted iteration, iterations, evaluations)."""
+        keep = []
+        def table(d):
+            arr = (_lib.fp * P_COUNT)()
+            for k, v in (d or {}).items():
+                a = f32(np.broadcast_to(np.asarray(v, dtype=np.float64), (self.sizes[k],)))
+                keep.append(a)
+                arr[PARAM_INDEX[k]] = ptr(a)
+            return arr
+        lo, hi = table(lower), table(upper)
+        cap = max(int(maxiter), 1) + 1
+        hist = np.zeros(cap, np.float32)
+        nit, nev = C.c_int(), C.c_int()
+        self._chk(self._l.lc_joint_run_lbfgs(self.h, int(maxiter), lo, hi, ptr(hist), cap, C.byref(nit), C.byref(nev)), 'run_lbfgs')
+        return hist[:max(nit.value, 1)].copy(), nit.value, nev.value
+
     @property
     def iterations_done(self):
         return self._l.lc_joint_iterations_done(self.h)

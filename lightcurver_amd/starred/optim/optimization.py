@@ -72,8 +72,12 @@ class Optimizer:
             extra['param_history'] = param_history
         return p.best_fit_values(), -float(hist[-1]), extra
 
-    # -- L-BFGS-B: scipy on the host, loss + gradient on the device ------------------------------------
+    # -- L-BFGS-B ----------------------------------------------------------------------------------------
+    # default: the library's bounded L-BFGS with parameters, gradients, direction and history on the device
+    # (lc_joint_run_lbfgs); LCMI_LBFGS_SCIPY=1: scipy's L-BFGS-B on the host driving device loss / gradient evaluations,
+    # the split the reference has, kept as a cross-check.  Both reach the same optimum; the iterates differ.
     def _run_lbfgsb(self, maxiter=100, restart_from_init=False, **_ignored):
+        import os
         p = self._param
         start = p._start if restart_from_init else p._current
         fit = self._loss.configure()
@@ -81,6 +85,15 @@ class Optimizer:
         fit.set_free(p.free)
         x0 = p.kwargs2args(_nest(start))
         lo, hi = p.bounds()
+        if x0.size and not os.environ.get('LCMI_LBFGS_SCIPY'):
+            lower = {k: p._down[k] for k in p.free if k in p._down}
+            upper = {k: p._up[k] for k in p.free if k in p._up}
+            hist, nit, nev = fit.run_lbfgs(int(maxiter), lower, upper)
+            flat = {k: np.asarray(v, dtype=np.float64) for k, v in fit.get_params().items()}
+            p.set_best_fit(flat)
+            self.loss_history = [float(v) for v in hist]
+            return p.best_fit_values(), -float(hist[-1]), {'loss_history': np.array(self.loss_history),
+                                                           'iterations': nit, 'evaluations': nev}
         hist, last = [], {}
 
         def fun(x):
