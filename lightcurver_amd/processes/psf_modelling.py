@@ -1,43 +1,30 @@
 """Array-level restatement of the per-frame work of the reference's ``model_all_psfs``
 (lightcurver/processes/psf_modelling.py:126-160 stamp preparation, :164-171 PSF build, :177-180 and
 :205-208 quality numbers) with the whole list of frames fitted in one device batch.  Reading the stamps
-from regions.h5, source masking with ``sep`` (:35-61), plots and the sqlite bookkeeping stay with the
-caller (out of scope)."""
+from regions.h5 is in ``lightcurver_amd/io/regions.py``, the source masking of :35-61 in ``source_masking.py``; plots
+and the sqlite bookkeeping stay with the caller (out of scope)."""
 import numpy as np
 
 from ..starred.procedures.psf_routines import build_psf_batch
 
 
-def mask_surrounding_stars(data, noisemap, thresh=3.0, minarea=15):
-    """Mask (False) every detected object of a stamp except the one closest to the stamp centre.
-
-    The reference does this with ``sep.extract(data, thresh=3, err=noisemap, minarea=15, deblend_cont=0.001)``
-    (psf_modelling.py:35-61); ``sep`` is a C extension that is not a dependency here, so the segmentation is
-    the SExtractor core without de-blending: 8-connected regions of pixels above ``thresh`` sigma with at
-    least ``minarea`` pixels, object position = flux-weighted barycentre.  Blended neighbours that ``sep``
-    would split stay attached to the central object and are therefore not masked (conservative).
-    """
-    from scipy import ndimage
-    data = np.asarray(data, dtype=np.float64)
-    noisemap = np.asarray(noisemap, dtype=np.float64)
-    mask = np.ones(data.shape, dtype=bool)
-    with np.errstate(invalid='ignore', divide='ignore'):
-        above = np.nan_to_num(data / noisemap, nan=0.0, posinf=0.0, neginf=0.0) > thresh
-    labels, n_obj = ndimage.label(above, structure=np.ones((3, 3), dtype=int))
-    if n_obj == 0:
+def mask_surrounding_stars(data, noisemap, thresh=3.0, minarea=15, deblend_cont=0.001):
+    """Mask (False) every detected object of a stamp except the one closest to the stamp centre
+    (psf_modelling.py:35-61).  The reference segments the stamp with ``sep.extract(data, thresh=3, err=noisemap,
+    minarea=15, segmentation_map=True, deblend_cont=0.001)``; ``sep`` is not a dependency here, the detection /
+    multi-threshold de-blending / segmentation are restated in ``processes/source_masking.py``."""
+    from .source_masking import extract
+    objects, seg_map = extract(data, noisemap, thresh=thresh, minarea=minarea, deblend_cont=deblend_cont)
+    mask = np.ones(seg_map.shape, dtype=bool)
+    if len(objects) == 0:
         return mask
-    idx = np.arange(1, n_obj + 1)
-    areas = ndimage.sum(above, labels, idx)
-    keep = idx[areas >= minarea]
-    if keep.size == 0:
-        return mask
-    flux = np.where(above, np.clip(data, 0, None), 0.0)
-    centres = np.array(ndimage.center_of_mass(flux, labels, keep))  # (y, x)
-    cy, cx = (data.shape[0] - 1) / 2.0, (data.shape[1] - 1) / 2.0
-    central = keep[np.argmin(np.hypot(centres[:, 0] - cy, centres[:, 1] - cx))]
-    for lab in keep:
-        if lab != central:
-            mask[labels == lab] = False
+    center_y = (seg_map.shape[0] - 1) / 2.0
+    center_x = (seg_map.shape[1] - 1) / 2.0
+    distances = np.hypot(objects['x'] - center_x, objects['y'] - center_y)
+    central = int(np.argmin(distances))
+    for i in range(len(objects)):
+        if i != central:
+            mask[seg_map == i + 1] = False
     return mask
 
 

@@ -236,3 +236,32 @@ def test_sharded_optimiser_equals_single_rank_gloo():
         assert np.allclose(got[k], pf[k].numpy(), rtol=1e-7, atol=1e-9), k
     dh = np.abs(got['h'] - pf['h'].numpy())
     assert np.median(dh) < 1e-10 and dh.max() < 2.5e-3  # a sign flip of a ~0 gradient moves one pixel by <= 2 lr
+
+
+def test_blended_neighbour_is_split_off_and_masked():
+    """A neighbour whose wings touch the central star forms ONE connected group with it above 3 sigma; sep's
+    multi-threshold de-blending (deblend_cont = 0.001, psf_modelling.py:51-52) splits the group, so the neighbour is
+    masked while the central star is kept.  Also: a faint bump below the contrast criterion is not split off."""
+    from lightcurver_amd.processes.psf_modelling import mask_surrounding_stars
+    from lightcurver_amd.processes.source_masking import extract
+    n = 32
+    yy, xx = np.mgrid[0:n, 0:n]
+
+    def star(x0, y0, amp, s=1.8):
+        return amp * np.exp(-0.5 * ((xx - x0) ** 2 + (yy - y0) ** 2) / s ** 2)
+
+    rng = np.random.default_rng(5)
+    noise = np.ones((n, n))
+    data = star(15.5, 15.5, 400.0) + star(22.5, 17.0, 150.0) + rng.normal(0, 1.0, (n, n))
+    objects, seg = extract(data, noise)
+    assert len(objects) == 2                                       # one group above threshold, two objects after de-blending
+    lab_c, lab_n = seg[15, 15], seg[17, 22]
+    assert lab_c > 0 and lab_n > 0 and lab_c != lab_n
+    m = mask_surrounding_stars(data, noise)
+    assert m[15, 15] and m[13:18, 13:18].all()                      # central star kept
+    assert not m[17, 22] and not m[16:19, 21:24].any()              # neighbour masked
+    assert 15 <= (~m).sum() <= 120
+    # contrast criterion: a bump carrying less than 0.1 % of the flux stays part of the central object
+    data2 = star(15.5, 15.5, 4000.0, s=2.5) + star(23.0, 15.5, 3.0, s=1.0) + rng.normal(0, 1.0, (n, n))
+    objects2, seg2 = extract(data2, noise)
+    assert len(objects2) == 1 and mask_surrounding_stars(data2, noise).all()
