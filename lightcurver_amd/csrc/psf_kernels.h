@@ -90,7 +90,13 @@ __device__ __forceinline__ float load_sc1_f(const float *p) {
 // issue, so they are written in forms whose operands pair up in aligned 64-bit registers: two taps of one output
 // (row pass, transposed column pass), or value and derivative taps of one sample (column pass, transposed row pass).
 typedef float lc_v2f __attribute__((ext_vector_type(2)));
+// -DLC_SCALAR_FMA -fno-slp-vectorize builds the same passes from v_fma_f32 only: measured slower on gfx950 (C2 16.5 vs 16.0 us
+// per iteration, C4 133 vs 125 us), so the packed form is the default.
+#ifdef LC_SCALAR_FMA
+__device__ __forceinline__ lc_v2f pk_fma(lc_v2f a, lc_v2f b, lc_v2f c) { return (lc_v2f){fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#else
 __device__ __forceinline__ lc_v2f pk_fma(lc_v2f a, lc_v2f b, lc_v2f c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
 __device__ __forceinline__ lc_v2f pk_bcast(float v) { return (lc_v2f){v, v}; }
 
 template <int N_, int SS_, int PX_, int SG_, bool WC_ = false, int JB_ = 8>
@@ -407,13 +413,18 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
                 const float *trow = T + u * TSA + AP + ws;
 #pragma unroll
                 for (int i = 0; i < WL2; ++i) win2[i] = (lc_v2f){trow[2 * i], trow[2 * i + 1]};
+                // tap-major order: the JB accumulators are independent chains, so consecutive packed FMAs never wait
+                // for each other (output-major order made one 7-long dependent chain per output)
+                lc_v2f acc[JB];
 #pragma unroll
-                for (int j = 0; j < JB; ++j) {
-                  lc_v2f acc = (lc_v2f){0.f, 0.f};
+                for (int j = 0; j < JB; ++j) acc[j] = (lc_v2f){0.f, 0.f};
 #pragma unroll
-                  for (int h = 0; h < NP; ++h) acc = pk_fma(tr2[h], win2[j + h], acc);
-                  R2w[j * TSA + u] = acc.x + acc.y;
+                for (int h = 0; h < NP; ++h) {
+#pragma unroll
+                  for (int j = 0; j < JB; ++j) acc[j] = pk_fma(tr2[h], win2[j + h], acc[j]);
                 }
+#pragma unroll
+                for (int j = 0; j < JB; ++j) R2w[j * TSA + u] = acc[j].x + acc[j].y;
               }
             } else {
               constexpr int WL = SS * (JB - 1) + NT;
@@ -456,12 +467,20 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
 #pragma unroll
                 for (int i = 0; i < WL; ++i) win[i] = r2[i];
                 float lgy = 0.f;
+                lc_v2f fvys[LC];  // tap-major order: LC independent chains
+#pragma unroll
+                for (int j = 0; j < LC; ++j) fvys[j] = (lc_v2f){0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+#pragma unroll
+                  for (int j = 0; j < LC; ++j) fvys[j] = pk_fma(tyd[k], pk_bcast(win[SS * j - k + NT - 1]), fvys[j]);
+                  // keeps the scheduler from folding the LC chains back into one (it does, to save registers)
+                  if constexpr (LC == 4) asm volatile("" : "+v"(fvys[0]), "+v"(fvys[1]), "+v"(fvys[2]), "+v"(fvys[3]));
+                  else asm volatile("" : "+v"(fvys[0]), "+v"(fvys[1]));
+                }
 #pragma unroll
                 for (int j = 0; j < LC; ++j) {
-                  lc_v2f fvy = (lc_v2f){0.f, 0.f};
-#pragma unroll
-                  for (int k = 0; k < NT; ++k) fvy = pk_fma(tyd[k], pk_bcast(win[SS * j - k + NT - 1]), fvy);
-                  const float fv = fvy.x, fy = fvy.y;
+                  const float fv = fvys[j].x, fy = fvys[j].y;
                   const float model = fmaf(amp, fv, sky);
                   const float res = model - dpre[i3][j];
                   const float rw = wpre[i3][j] * res;
