@@ -20,7 +20,8 @@ __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) {  // a * conj(b
 //   "stride" layout : lane n1 (0..15), register n2 (0..L/16-1) holds sample  n = n1 + 16 n2
 //   "block"  layout : lane l,          register k2              holds bin     k = k2 + (L/16) * bitrev4(l)
 // forward  = in-lane FFT over n2, twiddle W_L^(n1 k2), 16-point decimation-in-frequency FFT across the lanes
-//            (lane exchanges by xor-shuffles): stride in -> block out;
+//            (lane exchanges by DPP, see fft_index below: "lane" n1 / l above means the lane's transform index);
+//            stride in -> block out;
 // inverse  = 16-point decimation-in-time FFT across the lanes, conjugate twiddle, in-lane inverse FFT:
 //            block in -> stride out (unnormalised).  No bit-reversal pass and no LDS round trip is needed.
 __device__ __forceinline__ int bitrev4(int x) {
@@ -120,56 +121,81 @@ __device__ __forceinline__ void inlane_fft_any(float2 (&x)[N2]) {
 __device__ __forceinline__ float2 shfl2(float2 v, int src) {
   return make_float2(__shfl(v.x, src, 64), __shfl(v.y, src, 64));
 }
-// value of lane (l ^ H) inside the 16-lane row, H in {1, 2, 4, 8}: DPP only, no LDS crossbar
-template <int CTRL, int BANK>
-__device__ __forceinline__ float dpp_take(float old, float src) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
-                                                                CTRL, 0xF, BANK, false));
-}
-template <int H>
-__device__ __forceinline__ float row_xor(float v) {
-  if constexpr (H == 1) return dpp_take<0xB1, 0xF>(v, v);        // quad_perm [1,0,3,2]
-  else if constexpr (H == 2) return dpp_take<0x4E, 0xF>(v, v);   // quad_perm [2,3,0,1]
-  else if constexpr (H == 8) return dpp_take<0x128, 0xF>(v, v);  // row_ror:8
-  else {
-    // lanes with bit 2 set (banks 1, 3) read lane - 4 = row_ror:4, the others lane + 4 = row_ror:12
-    const float t = dpp_take<0x124, 0xA>(v, v);
-    return dpp_take<0x12C, 0x5>(t, v);
+// Lane exchanges of the 16-point transform across a row of 16 lanes.  Every stage pairs a lane with one partner, and
+// the exchange rides on the arithmetic instruction itself (v_fmac_f32_dpp: x += s * x[partner], one instruction per
+// component): the DPP controls that are involutions of a row are quad_perm [1,0,3,2] (lane ^ 1), quad_perm [2,3,0,1]
+// (lane ^ 2), row_half_mirror (lane ^ 7) and row_ror:8 (lane ^ 8) -- there is none for lane ^ 4.  So the transform
+// index of a lane is not its lane number: fft_index(lane) = lane ^ (lane & 4 ? 3 : 0) (an involution), under which the
+// partner across index bit 2 is lane ^ 7.  Callers take their sample / bin positions from fft_index().
+__device__ __forceinline__ int fft_index(int lane16) { return lane16 ^ ((lane16 & 4) ? 3 : 0); }
+// x += s * x[partner] for both components of NE complex registers, in place.  The compiler folds a DPP move into VOP2
+// users but not into a fused multiply-add, hence the assembly; one block covers up to six elements and opens with the two
+// wait states a DPP read needs after a VALU write of the same register (nothing inside a block reads what it wrote).
+#define LC_XF1(a, c) "v_fmac_f32_dpp %" #a ", %" #a ", %" #c " "
+#define LC_DEF_EXCHANGE(NAME, CTL)                                                                                         \
+  __device__ __forceinline__ void NAME##_1(float2 &a, float s) {                                                          \
+    asm("s_nop 1\n\t" LC_XF1(0, 2) CTL "\n\t" LC_XF1(1, 2) CTL : "+v"(a.x), "+v"(a.y) : "v"(s));                           \
+  }                                                                                                                        \
+  __device__ __forceinline__ void NAME##_6(float2 &a, float2 &b, float2 &c, float2 &d, float2 &e, float2 &f, float s) {    \
+    asm("s_nop 1\n\t" LC_XF1(0, 12) CTL "\n\t" LC_XF1(1, 12) CTL "\n\t" LC_XF1(2, 12) CTL "\n\t" LC_XF1(3, 12) CTL "\n\t"     \
+        LC_XF1(4, 12) CTL "\n\t" LC_XF1(5, 12) CTL "\n\t" LC_XF1(6, 12) CTL "\n\t" LC_XF1(7, 12) CTL "\n\t"                   \
+        LC_XF1(8, 12) CTL "\n\t" LC_XF1(9, 12) CTL "\n\t" LC_XF1(10, 12) CTL "\n\t" LC_XF1(11, 12) CTL                        \
+        : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(b.y), "+v"(c.x), "+v"(c.y), "+v"(d.x), "+v"(d.y), "+v"(e.x), "+v"(e.y),   \
+          "+v"(f.x), "+v"(f.y)                                                                                            \
+        : "v"(s));                                                                                                         \
   }
-}
-template <int H>
-__device__ __forceinline__ float2 row_xor2(float2 v) {
-  return make_float2(row_xor<H>(v.x), row_xor<H>(v.y));
+LC_DEF_EXCHANGE(exch_b0, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+LC_DEF_EXCHANGE(exch_b1, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+LC_DEF_EXCHANGE(exch_b2, "row_half_mirror row_mask:0xf bank_mask:0xf")
+LC_DEF_EXCHANGE(exch_b3, "row_ror:8 row_mask:0xf bank_mask:0xf")
+#undef LC_DEF_EXCHANGE
+#undef LC_XF1
+// x[k2] += s * (x[k2] of the lane whose fft_index differs in bit H), all k2
+template <int H, int N2>
+__device__ __forceinline__ void exchange_add(float2 (&x)[N2], float s) {
+  constexpr int N6 = N2 / 6 * 6;
+#pragma unroll
+  for (int k = 0; k < N6; k += 6) {
+    if constexpr (H == 1) exch_b0_6(x[k], x[k + 1], x[k + 2], x[k + 3], x[k + 4], x[k + 5], s);
+    else if constexpr (H == 2) exch_b1_6(x[k], x[k + 1], x[k + 2], x[k + 3], x[k + 4], x[k + 5], s);
+    else if constexpr (H == 4) exch_b2_6(x[k], x[k + 1], x[k + 2], x[k + 3], x[k + 4], x[k + 5], s);
+    else exch_b3_6(x[k], x[k + 1], x[k + 2], x[k + 3], x[k + 4], x[k + 5], s);
+  }
+#pragma unroll
+  for (int k = N6; k < N2; ++k) {
+    if constexpr (H == 1) exch_b0_1(x[k], s);
+    else if constexpr (H == 2) exch_b1_1(x[k], s);
+    else if constexpr (H == 4) exch_b2_1(x[k], s);
+    else exch_b3_1(x[k], s);
+  }
 }
 
 // One decimation-in-frequency stage across the lanes (span H): lower lane a + b, upper lane (a - b) w.
-// Written branch- and select-free: t = p + s x with s = +-1, then a multiplication by w (lower lanes: 1).
+// Branch- and select-free: t = x + s x[partner] with s = +-1 (the upper lane gets b - a, the sign goes into its
+// twiddle), then a multiplication by w (lower lanes: 1).  j16 = fft_index(lane & 15).
 template <int L, int H>
-__device__ __forceinline__ void dif_stage(float2 (&x)[L / 16], int l16, const float2 *tw) {
-  const bool upper = (l16 & H) != 0;
-  const float2 wt = tw[(l16 & (H - 1)) * (L / (2 * H))];
+__device__ __forceinline__ void dif_stage(float2 (&x)[L / 16], int j16, const float2 *tw) {
+  const bool upper = (j16 & H) != 0;
+  float2 wt = tw[(j16 & (H - 1)) * (L / (2 * H))];
+  asm volatile("" : "+v"(wt.x), "+v"(wt.y));  // every lane loads: no branch around the read (it would split the block the exchanges fold in)
   const float sgn = upper ? -1.f : 1.f;
-  const float2 w = upper ? wt : make_float2(1.f, 0.f);
+  const float2 w = upper ? make_float2(-wt.x, -wt.y) : make_float2(1.f, 0.f);
+  exchange_add<H>(x, sgn);
 #pragma unroll
-  for (int k2 = 0; k2 < L / 16; ++k2) {
-    const float2 p = row_xor2<H>(x[k2]);
-    const float2 t = make_float2(fmaf(sgn, x[k2].x, p.x), fmaf(sgn, x[k2].y, p.y));
-    x[k2] = cmul(t, w);
-  }
+  for (int k2 = 0; k2 < L / 16; ++k2) x[k2] = cmul(x[k2], w);
 }
 // One decimation-in-time stage (inverse direction): upper lane pre-multiplied by conj w, then a + b / a - b.
+// The upper lane carries -t through the exchange (sign in its twiddle), so that both lanes do x = t - s t[partner].
 template <int L, int H>
-__device__ __forceinline__ void dit_stage_inv(float2 (&x)[L / 16], int l16, const float2 *tw) {
-  const bool upper = (l16 & H) != 0;
-  const float2 wt = tw[(l16 & (H - 1)) * (L / (2 * H))];
-  const float sgn = upper ? -1.f : 1.f;
-  const float2 w = upper ? make_float2(wt.x, -wt.y) : make_float2(1.f, 0.f);
+__device__ __forceinline__ void dit_stage_inv(float2 (&x)[L / 16], int j16, const float2 *tw) {
+  const bool upper = (j16 & H) != 0;
+  float2 wt = tw[(j16 & (H - 1)) * (L / (2 * H))];
+  asm volatile("" : "+v"(wt.x), "+v"(wt.y));  // every lane loads: no branch around the read (it would split the block the exchanges fold in)
+  const float msg = upper ? 1.f : -1.f;
+  const float2 w = upper ? make_float2(-wt.x, wt.y) : make_float2(1.f, 0.f);
 #pragma unroll
-  for (int k2 = 0; k2 < L / 16; ++k2) {
-    const float2 t = cmul(x[k2], w);
-    const float2 p = row_xor2<H>(t);
-    x[k2] = make_float2(fmaf(sgn, t.x, p.x), fmaf(sgn, t.y, p.y));
-  }
+  for (int k2 = 0; k2 < L / 16; ++k2) x[k2] = cmul(x[k2], w);
+  exchange_add<H>(x, msg);
 }
 // tw[m] = exp(-2 pi i m / L), m < L (LDS)
 template <int L>

@@ -9,6 +9,7 @@
 
 #include "joint_kernels.h"
 #include "joint_gm.h"
+#include "joint_reg_mfma.h"
 #include "joint_ps.h"
 #include "joint_noise.h"
 #include "joint_lbfgs.h"
@@ -27,6 +28,13 @@ struct JointVariant {
   int u_thr, u_lds;
   bool gspec;
   epoch_fn ek_aux;  // plain convolution / spectrum modes of the same pipeline (noise propagation)
+};
+
+typedef void (*mreg_fn)(MregArgs);
+struct MregKernels {
+  int N;
+  mreg_fn fwd, adj;
+  int lds_fwd, lds_adj, nthr;
 };
 
 struct lc_joint {
@@ -56,6 +64,10 @@ struct lc_joint {
   float *gm_c = nullptr, *gm_t = nullptr, *gm_n = nullptr, *gm_y = nullptr, *gm_l1 = nullptr, *gm_pos = nullptr;
   float *gm_edge = nullptr;  // [N][4] end sums of the adjoint passes
   float *gm_pts = nullptr;  // [8] mean fluxes + [blocks][8][3] partial inner products of the point-source term
+  // matrix-core form of the regulariser (joint_reg_mfma.h), N >= 128
+  const struct MregKernels *mreg = nullptr;
+  float *mr_A = nullptr, *mr_AT = nullptr, *mr_C = nullptr, *mr_Z = nullptr, *mr_l1 = nullptr, *mr_pos = nullptr,
+        *mr_part = nullptr, *mr_pbar = nullptr;
   hipStream_t streamB = nullptr;      // the h regulariser runs here, concurrently with the epoch kernel
   hipEvent_t evReg = nullptr, evUpd = nullptr;
   bool reg_pending = false;
@@ -311,11 +323,91 @@ int launch_reg_gm(lc_joint *j, hipStream_t stream, bool with_pts, bool abar_from
   return LC_OK;
 }
 
+template <int N>
+MregKernels make_mreg() {
+  return MregKernels{N, mreg_forward_kernel<N>, mreg_adjoint_kernel<N>, MregCfg<N>::LDS_FWD, MregCfg<N>::LDS_ADJ, MregCfg<N>::NTHR};
+}
+const MregKernels *find_mreg(int N) {
+  static const MregKernels table[] = {make_mreg<128>(), make_mreg<256>()};
+  if (std::getenv("LCMI_REG_CASCADE")) return nullptr;  // the a-trous cascade kernels instead (cross-check)
+  for (const auto &k : table)
+    if (k.N == N) return &k;
+  return nullptr;
+}
+// cumulative 1-D smoothing operators A_0 = I, A_{s+1} = R_s A_s (R_s: edge-replicating B3 filter at dilation 2^s), in
+// double on the host; A and A^T as [J + 1][N][N] floats
+void build_cumulative_operators(int N, int J, std::vector<float> &A, std::vector<float> &AT) {
+  const size_t NN = (size_t)N * N;
+  std::vector<double> cur(NN, 0.0), nxt(NN);
+  for (int r = 0; r < N; ++r) cur[(size_t)r * N + r] = 1.0;
+  A.assign((size_t)(J + 1) * NN, 0.f);
+  AT.assign((size_t)(J + 1) * NN, 0.f);
+  const double b[5] = {0.0625, 0.25, 0.375, 0.25, 0.0625};
+  for (int s = 0; s <= J; ++s) {
+    for (int r = 0; r < N; ++r)
+      for (int c = 0; c < N; ++c) {
+        A[(size_t)s * NN + (size_t)r * N + c] = (float)cur[(size_t)r * N + c];
+        AT[(size_t)s * NN + (size_t)c * N + r] = (float)cur[(size_t)r * N + c];
+      }
+    if (s == J) break;
+    const int d = 1 << s;
+    std::fill(nxt.begin(), nxt.end(), 0.0);
+    for (int r = 0; r < N; ++r)
+      for (int t = -2; t <= 2; ++t) {
+        const int rr = std::min(std::max(r + t * d, 0), N - 1);
+        const double bt = b[t + 2];
+        for (int c = 0; c < N; ++c) nxt[(size_t)r * N + c] += bt * cur[(size_t)rr * N + c];
+      }
+    cur.swap(nxt);
+  }
+}
+
+// starlet l1 + positivity of h (+ the point-source starlet term, mean fluxes from the parameters) on the matrix cores:
+// -> greg, regs (same contract as reg_mode 1 of joint_update_kernel)
+int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
+  const MregKernels *k = j->mreg;
+  const int N = j->N, NN = N * N, J = j->J, nb = (NN + kGmThreads - 1) / kGmThreads;
+  const bool l1_on = (j->cfg.lam_scales != 0.f || j->cfg.lam_hf != 0.f);
+  MregArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.J = J;
+  A.has_pts = with_pts ? 1 : 0;
+  A.s0 = l1_on ? 0 : J;
+  A.A = j->mr_A;
+  A.AT = j->mr_AT;
+  A.X = j->par[LC_P_H];
+  A.P = j->mr_pbar;
+  A.C = j->mr_C;
+  A.W = j->have_W ? j->W : nullptr;
+  A.norms = j->norms;
+  A.lam_sc = j->cfg.lam_scales;
+  A.lam_hf = j->cfg.lam_hf;
+  A.lam_pts = j->cfg.lam_pts_source;
+  A.Z = j->mr_Z;
+  A.l1p = j->mr_l1;
+  if (with_pts)
+    hipLaunchKernelGGL(mreg_pbar_kernel, dim3(nb), dim3(kGmThreads), 0, stream, N, j->ss, j->E, j->M, j->par[LC_P_A],
+                       j->par[LC_P_CX], j->par[LC_P_CY], j->mr_pbar);
+  const int slots = (l1_on ? J : 0) + (with_pts ? 1 : 0);
+  if (slots > 0) {
+    hipLaunchKernelGGL(k->fwd, dim3(N / 32, slots), dim3(k->nthr), k->lds_fwd, stream, A);
+    hipLaunchKernelGGL(k->adj, dim3(N / 32, slots), dim3(k->nthr), k->lds_adj, stream, A);
+  }
+  hipLaunchKernelGGL(mreg_finish_kernel, dim3(nb), dim3(kGmThreads), 0, stream, N, J, l1_on ? 1 : 0, with_pts ? 1 : 0, j->ss,
+                     j->M, j->mr_Z, j->par[LC_P_H], j->cfg.lam_positivity, j->par[LC_P_CX], j->par[LC_P_CY], j->greg,
+                     j->mr_pos, j->mr_part);
+  hipLaunchKernelGGL(mreg_regs_kernel, dim3(1), dim3(64), 0, stream, J, l1_on ? 1 : 0, with_pts ? 1 : 0, nb, j->M, j->mr_l1,
+                     j->mr_pos, j->mr_part, j->regs);
+  LC_HIP(j->ctx, hipGetLastError());
+  return LC_OK;
+}
+
 int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, bool write_hist, bool all_grads,
                   int reg_mode = 0, hipStream_t stream = nullptr) {
   if (!stream) stream = j->ctx->stream;
   const JointVariant *v = j->v;
   bool gm_pts_done = false;
+  if (reg_mode == 1 && j->mreg) return launch_reg_mfma(j, stream, j->pts_pending);
   if (!v->uk) {
     const bool want_pts = j->cfg.lam_pts_source != 0.f && j->M > 0;
     if (reg_mode == 1) return launch_reg_gm(j, stream, j->pts_pending, false);
@@ -508,6 +600,24 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
     TRY(dmalloc(j, &j->gm_pos, nb));
     TRY(dmalloc(j, &j->gm_pts, 8 + nb * 3 * kMaxSources));
     TRY(dmalloc(j, &j->gm_edge, (size_t)N * 4));
+  }
+  j->mreg = find_mreg(N);
+  if (j->mreg) {
+    const size_t nb = (NN + kGmThreads - 1) / kGmThreads;
+    std::vector<float> A, AT;
+    build_cumulative_operators(N, j->J, A, AT);
+    TRY(dmalloc(j, &j->mr_A, A.size()));
+    TRY(dmalloc(j, &j->mr_AT, AT.size()));
+    TRY(h2d(j, j->mr_A, A.data(), A.size() * sizeof(float)));
+    TRY(h2d(j, j->mr_AT, AT.data(), AT.size() * sizeof(float)));
+    TRY(dmalloc(j, &j->mr_C, (size_t)(j->J + 2) * NN));
+    TRY(dmalloc(j, &j->mr_Z, (size_t)(j->J + 1) * NN));
+    TRY(dmalloc(j, &j->mr_l1, j->J + 1));
+    TRY(dmalloc(j, &j->mr_pos, nb));
+    TRY(dmalloc(j, &j->mr_part, nb * 3 * kMaxSources));
+    TRY(dmalloc(j, &j->mr_pbar, NN));
+    LC_HIP(ctx, hipFuncSetAttribute((const void *)j->mreg->fwd, hipFuncAttributeMaxDynamicSharedMemorySize, j->mreg->lds_fwd));
+    LC_HIP(ctx, hipFuncSetAttribute((const void *)j->mreg->adj, hipFuncAttributeMaxDynamicSharedMemorySize, j->mreg->lds_adj));
   }
   LC_HIP(ctx, hipStreamCreate(&j->streamB));
   LC_HIP(ctx, hipEventCreateWithFlags(&j->evReg, hipEventDisableTiming));

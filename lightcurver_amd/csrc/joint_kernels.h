@@ -87,7 +87,15 @@ struct JointCfg {
   static constexpr int SZ_TW = L;
   static constexpr int OFF_RED = OFF_TW + SZ_TW;  // float2 units; reduction scratch as floats
   static constexpr int SZ_RED = ((NW + 1) * (4 + 3 * kMaxSources) + 1) / 2 + 8;
-  static constexpr int LDS_BYTES = (OFF_RED + SZ_RED) * 8;
+  // three rows of h per quarter-wave (translated epochs read the background from LDS): L float2 = 3 N floats, i.e. the
+  // quarter's row buffer where there is one, a region of its own otherwise
+  static constexpr int OFF_HROW = OFF_RED + SZ_RED;
+  static constexpr int SZ_HROW = WSQ ? 0 : NW * 4 * ((3 * N + 1) / 2);
+  // separable Gaussian factors of the point sources: GX[i][N], GY[i][N] floats, then their centres X_i, Y_i
+  static constexpr int OFF_TAB = OFF_HROW + SZ_HROW;
+  static constexpr int SZ_TAB = kMaxSources * N + kMaxSources;
+  static constexpr int LDS_BYTES = (OFF_TAB + SZ_TAB) * 8;
+  static_assert(!WSQ || 2 * L >= 3 * N, "row buffer holds three rows of h");
   static constexpr int CREF = (N - 1) / 2;
   static_assert(N % 2 == 0, "row pairs");
   static_assert(L >= 2 * N - 1 - CREF, "FFT length too short for an alias-free 'same' window");
@@ -109,23 +117,26 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   const float dxe = A.dx[e], dye = A.dy[e];
   const float sdx = SS * dxe, sdy = SS * dye;
   const float meane = A.mean[e];
-  float *tab = A.tabs + (size_t)e * 4 * M * N;
+  float *GX = (float *)(lds2 + C::OFF_TAB), *GY = GX + kMaxSources * N, *PSX = GY + kMaxSources * N, *PSY = PSX + kMaxSources;
+  constexpr float inv_s2 = 1.0f / (kSigmaG * kSigmaG);
 
   LC_JSTAMP(0);
   for (int k = tid; k < L; k += C::NTHR) TW[k] = A.twid[k];
-  // separable Gaussian factors of every point source (full grid, as the oracle evaluates them)
+  // separable Gaussian factors of every point source (full grid, as the oracle evaluates them), in LDS: the scene and
+  // gradient loops read them per pixel, and a global table put a load latency into every one of those reads
   {
-    const float inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm = 0.3989422804014327f / kSigmaG;
+    const float nrm = 0.3989422804014327f / kSigmaG;
     for (int idx = tid; idx < M * N; idx += C::NTHR) {
       const int i = idx / N, p = idx % N;
       const float X = c0 + SS * (ca * A.cx[i] - sa * A.cy[i] + dxe);
       const float Y = c0 + SS * (sa * A.cx[i] + ca * A.cy[i] + dye);
       const float tx = (float)p - X, ty = (float)p - Y;
-      const float gx = nrm * expf(-0.5f * tx * tx * inv_s2), gy = nrm * expf(-0.5f * ty * ty * inv_s2);
-      tab[(0 * M + i) * N + p] = gx;
-      tab[(1 * M + i) * N + p] = gx * tx * inv_s2;
-      tab[(2 * M + i) * N + p] = gy;
-      tab[(3 * M + i) * N + p] = gy * ty * inv_s2;
+      GX[i * N + p] = nrm * expf(-0.5f * tx * tx * inv_s2);
+      GY[i * N + p] = nrm * expf(-0.5f * ty * ty * inv_s2);
+      if (p == 0) {
+        PSX[i] = X;
+        PSY[i] = Y;
+      }
     }
   }
   __syncthreads();
@@ -138,11 +149,59 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   // Every FFT below is a quarter-wave register transform (fft_device.h): each group of 16 lanes owns one row pair
   // or one spectrum column, so a wave works on four of them side by side.
   constexpr int N2 = L / 16;
-  const int l16 = lane & 15, qid = lane >> 4, qbase = lane & 48;
+  // l16: the lane's index inside its transform (fft_device.h: not the lane number, the exchanges are DPP involutions)
+  const int l16 = fft_index(lane & 15), qid = lane >> 4, qbase = lane & 48;
   const int kbase = N2 * bitrev4(l16);                       // first bin of this lane in the block layout
-  const int lane_mirror = qbase | (15 - l16);                // holds bins L - k for k2 != 0
-  const int lane_neg = qbase | bitrev4((16 - bitrev4(l16)) & 15);  // holds bin (L - k) mod L for k2 == 0
+  const int lane_mirror = qbase | fft_index(15 - l16);       // holds bins L - k for k2 != 0
+  const int lane_neg = qbase | fft_index(bitrev4((16 - bitrev4(l16)) & 15));  // holds bin (L - k) mod L for k2 == 0
   float2 *wsq = lds2 + C::OFF_WS + (C::WSQ ? (wid * 4 + qid) : wid) * L;  // linear workspace (L samples)
+
+  // Translated epochs (alpha = 0: every fit of the reference): scene pixel (u, v) samples h at (u + iyc + fyc, v + ixc + fxc)
+  // with ONE integer offset and ONE pair of fractional weights for the whole epoch, so scene rows u0, u0 + 1 read the
+  // three rows clamp(u0 + iyc + {0, 1, 2}) of h.  The quarter-wave copies those into LDS (coalesced 16-byte loads) and
+  // interpolates from there: 6 LDS reads and 10 multiply-adds per pixel pair instead of the general path's two floor /
+  // clamp / gather sequences (the scene phases are bound by instruction issue, not by memory).  Phase D's adjoint
+  // stencil uses the same constants, which makes it the exact transpose of this interpolation.
+  const bool translated = (sa == 0.f);
+  const float t_nsx = -sdx, t_nsy = -sdy;
+  const float t_ixf = floorf(t_nsx), t_iyf = floorf(t_nsy);
+  const float fxc = t_nsx - t_ixf, fyc = t_nsy - t_iyf;
+  const int ixc = (int)t_ixf, iyc = (int)t_iyf;
+  float *hrow = C::WSQ ? (float *)wsq : (float *)(lds2 + C::OFF_HROW) + (wid * 4 + qid) * 3 * N;
+  constexpr int HMASK = ((N & (N - 1)) == 0) ? N - 1 : -1;
+  const int hskew = ((N & (N - 1)) == 0) ? 16 * qid : 0;  // the four quarters of a wave on different banks
+  auto stage_rows = [&](int u0, bool active) {
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float *src = A.h + (size_t)min(max(u0 + iyc + r, 0), N - 1) * N;
+        if constexpr (N % 64 == 0) {
+#pragma unroll
+          for (int t = 0; t < N / 64; ++t) {
+            const int x = 4 * (l16 + 16 * t);
+            *(float4 *)&hrow[r * N + ((x + hskew) & HMASK)] = *(const float4 *)&src[x];
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < N / 16; ++t) {
+            const int x = l16 + 16 * t;
+            hrow[r * N + ((x + hskew) & HMASK)] = src[x];
+          }
+        }
+      }
+    }
+  };
+  // x-interpolated samples of the three staged rows at scene column v, and their x-differences
+  auto rows_at = [&](int v, float (&top)[3], float (&dif)[3]) {
+    const int x0 = v + ixc;
+    const int xa = (min(max(x0, 0), N - 1) + hskew) & HMASK, xb = (min(max(x0 + 1, 0), N - 1) + hskew) & HMASK;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float ha = hrow[r * N + xa], hb = hrow[r * N + xb];
+      dif[r] = hb - ha;
+      top[r] = fmaf(fxc, dif[r], ha);
+    }
+  };
 
   // two real rows -> two half spectra (2-for-1): Z = FFT(x1 + i x2), X1 = (Z[k] + conj Z[L-k]) / 2, X2 = (Z[k] - conj Z[L-k]) / 2i
   auto unpack_rows = [&](float2 (&x)[N2], int u0, bool active) {
@@ -243,6 +302,15 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
     float2 x[N2];
+    LC_JSTAMP(9);
+    if constexpr (!AUX) {
+      if (use_h && translated) {
+        wave_lds_sync();  // the previous sweep's readers are done with the buffer
+        stage_rows(u0, active);
+        wave_lds_sync();
+      }
+    }
+    LC_JSTAMP(10);
 #pragma unroll
     for (int n2 = 0; n2 < N2; ++n2) {
       const int v = l16 + 16 * n2;
@@ -254,12 +322,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         }
       } else if (active && v < N) {
         float s0 = 0.f, s1 = 0.f;
-        for (int i = 0; i < M; ++i) {
-          const float gx = tab[(0 * M + i) * N + v];
-          s0 = fmaf(amp[i] * tab[(2 * M + i) * N + u0], gx, s0);
-          s1 = fmaf(amp[i] * tab[(2 * M + i) * N + u0 + 1], gx, s1);
-        }
-        if (use_h) {
+        if (use_h && translated) {
+          float top[3], dif[3];
+          rows_at(v, top, dif);
+          s0 += fmaf(fyc, top[1] - top[0], top[0]);
+          s1 += fmaf(fyc, top[2] - top[1], top[1]);
+        } else if (use_h) {
           float Xs, Ys, t0, t1;
           sample_coords(u0, v, c0, ca, sa, sdx, sdy, Xs, Ys);
           s0 += bilinear_h<N>(A.h, Xs, Ys, t0, t1);
@@ -270,8 +338,26 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       }
       x[n2] = z;
     }
+    if constexpr (!AUX) {
+      // point sources: flux times the row factor of the quarter's two rows, then one LDS read per pixel pair
+#pragma unroll
+      for (int i = 0; i < kMaxSources; ++i) {
+        if (i < M && active) {
+          const float ay0 = amp[i] * GY[i * N + u0], ay1 = amp[i] * GY[i * N + u0 + 1];
+#pragma unroll
+          for (int n2 = 0; n2 < N / 16; ++n2) {
+            const float gx = GX[i * N + l16 + 16 * n2];
+            x[n2].x = fmaf(ay0, gx, x[n2].x);
+            x[n2].y = fmaf(ay1, gx, x[n2].y);
+          }
+        }
+      }
+    }
+    LC_JSTAMP(11);
     quarter_fft_fwd<L>(x, l16, TW);
+    LC_JSTAMP(12);
     unpack_rows(x, u0, active);
+    LC_JSTAMP(13);
   }
   __syncthreads();
   LC_JSTAMP(2);
@@ -469,7 +555,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   float pa[kMaxSources], pX[kMaxSources], pY[kMaxSources];
 #pragma unroll
   for (int i = 0; i < kMaxSources; ++i) pa[i] = pX[i] = pY[i] = 0.f;
-  float acc_dx = 0.f, acc_dy = 0.f;
+  float acc_dx = 0.f, acc_dy = 0.f, acc_hx = 0.f, acc_hy = 0.f;
   // scene-gradient rows overwrite the spectrum rows they were computed from (row u: N floats inside the
   // KH float2 of spectrum row u), so the T^T gather below reads LDS, not global memory
   float *GSl = (float *)SPEC;
@@ -478,26 +564,47 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
     float2 x[N2];
+    if (use_h && translated) {
+      wave_lds_sync();
+      stage_rows(u0, active);
+    }
     pack_rows(x, u0, active);
     quarter_fft_inv<L>(x, l16, TW);
+    if (use_h && translated) wave_lds_sync();
+    // point sources: per source the row factors of the quarter's two rows, then one LDS read and seven multiply-adds
+    // per pixel pair
+#pragma unroll
+    for (int i = 0; i < kMaxSources; ++i) {
+      if (i < M && active) {
+        const float Xi = PSX[i], Yi = PSY[i];
+        const float gy0 = GY[i * N + u0], gy1 = GY[i * N + u0 + 1];
+        const float dgy0 = gy0 * (((float)u0 - Yi) * inv_s2), dgy1 = gy1 * (((float)(u0 + 1) - Yi) * inv_s2);
+#pragma unroll
+        for (int n2 = 0; n2 < N / 16; ++n2) {
+          const int v = l16 + 16 * n2;
+          const float2 g = x[n2];
+          const float gx = GX[i * N + v], dgx = gx * (((float)v - Xi) * inv_s2);
+          const float gg = g.x * gy0 + g.y * gy1;
+          pa[i] = fmaf(gg, gx, pa[i]);
+          pX[i] = fmaf(gg, dgx, pX[i]);
+          pY[i] = fmaf(g.x * dgy0 + g.y * dgy1, gx, pY[i]);
+        }
+      }
+    }
 #pragma unroll
     for (int n2 = 0; n2 < N2; ++n2) {
       const int v = l16 + 16 * n2;
       if (active && v < N) {
         const float2 g = x[n2];
-#pragma unroll
-        for (int i = 0; i < kMaxSources; ++i) {
-          if (i < M) {
-            const float gx = tab[(0 * M + i) * N + v], dgx = tab[(1 * M + i) * N + v];
-            const float gy0 = tab[(2 * M + i) * N + u0], gy1 = tab[(2 * M + i) * N + u0 + 1];
-            const float dgy0 = tab[(3 * M + i) * N + u0], dgy1 = tab[(3 * M + i) * N + u0 + 1];
-            const float gg = g.x * gy0 + g.y * gy1;
-            pa[i] = fmaf(gg, gx, pa[i]);
-            pX[i] = fmaf(gg, dgx, pX[i]);
-            pY[i] = fmaf(g.x * dgy0 + g.y * dgy1, gx, pY[i]);
-          }
-        }
-        if (use_h) {
+        if (use_h && translated) {
+          // d scene / d dx = -SS dH/dx, d scene / d dy = -SS dH/dy (the factor joins after the loop)
+          float top[3], dif[3];
+          rows_at(v, top, dif);
+          acc_hx = fmaf(g.x, fmaf(fyc, dif[1] - dif[0], dif[0]), acc_hx);
+          acc_hx = fmaf(g.y, fmaf(fyc, dif[2] - dif[1], dif[1]), acc_hx);
+          acc_hy = fmaf(g.x, top[1] - top[0], acc_hy);
+          acc_hy = fmaf(g.y, top[2] - top[1], acc_hy);
+        } else if (use_h) {
           float Xs, Ys, hx, hy;
           sample_coords(u0, v, c0, ca, sa, sdx, sdy, Xs, Ys);
           bilinear_h<N>(A.h, Xs, Ys, hx, hy);
@@ -507,6 +614,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
           bilinear_h<N>(A.h, Xs, Ys, hx, hy);
           acc_dx = fmaf(g.y, SS * (sa * hy - ca * hx), acc_dx);
           acc_dy = fmaf(g.y, -SS * (sa * hx + ca * hy), acc_dy);
+        }
+        if (use_h) {
           if (A.need_hgrad) {
             GSl[u0 * GST + v] = g.x;
             GSl[(u0 + 1) * GST + v] = g.y;
@@ -516,6 +625,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     }
   }
   LC_JSTAMP(6);
+  acc_dx = fmaf(-(float)SS, acc_hx, acc_dx);
+  acc_dy = fmaf(-(float)SS, acc_hy, acc_dy);
   // reductions: lanes by shuffles, the four waves in fixed order
   {
     constexpr int NQ = 4 + 3 * kMaxSources;
@@ -552,7 +663,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       A.g_mean[e] = t[1];
       float gdx = t[2], gdy = t[3];
       for (int i = 0; i < M; ++i) {
-        const float ai = A.a[e * M + i];
+        const float ai = amp[i];  // = a[e][i] in this mode
         const float gX = ai * t[5 + 3 * i], gY = ai * t[6 + 3 * i];
         A.g_a[e * M + i] = t[4 + 3 * i];
         gdx += SS * gX;
@@ -576,22 +687,38 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     // h collects exactly four scene pixels with constant weights (the adjoint of a 2 x 2 interpolation stencil).
     // Border pixels (and every pixel when the epoch is rotated) take the exact ordered gather instead; the two
     // sets are walked by separate loops so that no wave mixes the cheap and the expensive path.
-    const float nsx = -sdx, nsy = -sdy;
-    const float ixf = floorf(nsx), iyf = floorf(nsy);
-    const float fxc = nsx - ixf, fyc = nsy - iyf;
-    const int ixc = (int)ixf, iyc = (int)iyf;
     // Only the outermost ring of h collects clamped (edge-replicated) samples; every other pixel of a translated
     // epoch is served by the four-tap stencil, whose taps simply drop out where they leave the scene grid.
-    const int marg = (sa == 0.f) ? 1 : N / 2;
+    const int marg = translated ? 1 : N / 2;
     const int NI = N - 2 * marg;
-    for (int q = tid; q < NI * NI; q += C::NTHR) {
-      const int ky = marg + q / NI, kx = marg + q % NI;
-      const int r0 = ky - iyc, q0 = kx - ixc;
-      const bool ra = (r0 >= 0 && r0 < N), rb = (r0 >= 1 && r0 <= N), qa = (q0 >= 0 && q0 < N), qb = (q0 >= 1 && q0 <= N);
-      const float *g0 = GSl + r0 * GST + q0;
-      const float g00 = (ra && qa) ? g0[0] : 0.f, g01 = (ra && qb) ? g0[-1] : 0.f;
-      const float g10 = (rb && qa) ? g0[-GST] : 0.f, g11 = (rb && qb) ? g0[-GST - 1] : 0.f;
-      HGe[ky * N + kx] = (1.f - fyc) * ((1.f - fxc) * g00 + fxc * g01) + fyc * ((1.f - fxc) * g10 + fxc * g11);
+    if (translated) {
+      // four consecutive pixels of a row per thread: two rows of five scene-gradient samples, one 16-byte store
+      const float w00 = (1.f - fyc) * (1.f - fxc), w01 = (1.f - fyc) * fxc, w10 = fyc * (1.f - fxc), w11 = fyc * fxc;
+      for (int c = tid; c < N * (N / 4); c += C::NTHR) {
+        const int ky = c / (N / 4), kx0 = 4 * (c % (N / 4));
+        if (ky == 0 || ky == N - 1) continue;
+        const int r0 = ky - iyc, q0 = kx0 - ixc;
+        const bool ra = (r0 >= 0 && r0 < N), rb = (r0 >= 1 && r0 <= N);
+        float ga[5], gb[5];  // rows r0 and r0 - 1 at columns q0 - 1 .. q0 + 3
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          const int qq = q0 - 1 + t;
+          const bool qin = (qq >= 0 && qq < N);
+          ga[t] = (ra && qin) ? GSl[r0 * GST + qq] : 0.f;
+          gb[t] = (rb && qin) ? GSl[(r0 - 1) * GST + qq] : 0.f;
+        }
+        float o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = fmaf(w00, ga[t + 1], fmaf(w01, ga[t], fmaf(w10, gb[t + 1], w11 * gb[t])));
+        float *dst = HGe + ky * N + kx0;
+        if (kx0 > 0 && kx0 + 4 < N) {
+          *(float4 *)dst = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (kx0 + t > 0 && kx0 + t < N - 1) dst[t] = o[t];
+        }
+      }
     }
     const int n_rows = 2 * marg * N, n_cols = 2 * marg * NI;
     for (int q = tid; q < n_rows + n_cols; q += C::NTHR) {
@@ -623,11 +750,17 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       float acc = 0.f;
       for (int u = ulo; u <= uhi; ++u) {
         for (int v = vlo; v <= vhi; ++v) {
-          float Xs, Ys;
-          sample_coords(u, v, c0, ca, sa, sdx, sdy, Xs, Ys);
-          const float x0f = floorf(Xs), y0f = floorf(Ys);
-          const float fx = Xs - x0f, fy = Ys - y0f;
-          const int x0 = (int)x0f, y0 = (int)y0f;
+          float fx = fxc, fy = fyc;
+          int x0 = v + ixc, y0 = u + iyc;
+          if (!translated) {
+            float Xs, Ys;
+            sample_coords(u, v, c0, ca, sa, sdx, sdy, Xs, Ys);
+            const float x0f = floorf(Xs), y0f = floorf(Ys);
+            fx = Xs - x0f;
+            fy = Ys - y0f;
+            x0 = (int)x0f;
+            y0 = (int)y0f;
+          }
           const int xa = min(max(x0, 0), N - 1), xb = min(max(x0 + 1, 0), N - 1);
           const int ya = min(max(y0, 0), N - 1), yb = min(max(y0 + 1, 0), N - 1);
           const float wx = ((xa == kx) ? (1.f - fx) : 0.f) + ((xb == kx) ? fx : 0.f);

@@ -1,0 +1,284 @@
+// Starlet l1 regulariser of the background grid (and the point-source starlet term) as dense two-sided products on the
+// fp32 matrix cores, for the grids whose cascade was the longest single-workgroup job of an iteration (N >= 128).
+//
+// The a-trous cascade c_{j+1} = Col_j Row_j c_j (STARRED's starlet as used by Loss: reference call sites
+// lightcurver/processes/roi_modelling.py:313-322) is sequential in j and global in space, so one workgroup ran 2 J
+// barrier-separated 5-tap sweeps (94 us at N = 128, longer than the epoch kernel it is meant to hide behind).  The same
+// numbers follow from the cumulative 1-D operators A_j = R_{j-1} ... R_0 (R_s: edge-replicating B3 filter at dilation
+// 2^s, an N x N matrix; A_0 = I):
+//     c_j = A_j X A_j^T,   w_j = c_j - c_{j+1},   l1 = sum_j lam_j sum W_j |w_j|,   q_j = lam_j W_j sign(w_j)
+//     d l1 / d X = sum_j ( A_j^T q_j A_j - A_{j+1}^T q_j A_{j+1} )
+// Every scale is independent of the others, and so is every block of 32 columns of a product: a workgroup (column block b,
+// scale j) computes  M ( S M[blk]^T )  with v_mfma_f32_32x32x2_f32 (exact fp32 multiply-adds), wave w owning output rows
+// 32 w .. 32 w + 31.  Three launches replace the cascade: forward (c_j for all j), adjoint (q_j on the fly, the two
+// products per scale), and a small kernel that sums the J partial sub-gradients, adds positivity and the inner products
+// of the point-source term.  Fixed summation orders throughout: results do not depend on scheduling.
+#pragma once
+#include "joint_gm.h"
+
+namespace lc {
+
+typedef float mr_acc __attribute__((ext_vector_type(16)));
+
+struct MregArgs {
+  int J, has_pts;
+  int s0;                // first slot of the launch (0, or J when only the point-source term is on)
+  const float *A, *AT;  // [J + 1][N][N] cumulative smoothing operators and their transposes (row-major)
+  const float *X;       // h
+  const float *P;       // mean point-source channel Pbar (has_pts)
+  float *C;             // [J + 2][N][N]: slot j = c_j(h) for j = 1 .. J; slot J + 1 = c_1(Pbar)
+  const float *W;       // [J][N][N] or null (then norms[j])
+  const float *norms;   // [J]
+  float lam_sc, lam_hf, lam_pts;
+  float *Z;             // [J + 1][N][N] partial sub-gradients per scale; slot J: d term / d Pbar
+  float *l1p;           // [J + 1] value of the term per scale; slot J: the point-source term
+};
+
+// row of output element `reg` of a 32 x 32 accumulator tile held by lane half h (the column is lane & 31)
+__device__ __forceinline__ int mr_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// acc[p] (rows 32 wid .., columns b0 ..) = M[p] ( S M[p][b0 .. b0 + 31, :]^T ),  p < NP products sharing S.
+// srow(q) returns elements [32 wid + (lane & 31)][h HK + 4 q .. + 3] of S, h = lane >> 5, HK = N / 2: lane half h feeds
+// the k range [h HK, (h + 1) HK) of every product (one k per half and MFMA step), so that all operands are contiguous
+// per lane.  The intermediate S M^T passes through LDS once ([HK][64] image per product: step s reads 64 consecutive
+// floats).  All 64 * N / 32 threads must call.
+template <int N, int NP, class SRow>
+__device__ __forceinline__ void mr_two_sided(SRow &&srow, const float *const (&M)[NP], int b0, float *ylds, int lane, int wid,
+                                             mr_acc (&acc)[NP]) {
+  constexpr int HK = N / 2;
+  const int i = lane & 31, h = lane >> 5;
+  mr_acc y[NP];
+  const float4 *m1[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[p][r] = 0.f;
+    m1[p] = (const float4 *)(M[p] + (size_t)(b0 + i) * N + h * HK);
+  }
+#pragma unroll
+  for (int q = 0; q < HK / 4; ++q) {
+    const float4 a4 = srow(q);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const float4 b4 = m1[p][q];
+      y[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, y[p], 0, 0, 0);
+      y[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, y[p], 0, 0, 0);
+      y[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, y[p], 0, 0, 0);
+      y[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, y[p], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = 32 * wid + mr_row(r, h);
+      ylds[p * HK * 64 + (k % HK) * 64 + i + 32 * (k / HK)] = y[p][r];
+    }
+  __syncthreads();
+  const float4 *m2[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    m2[p] = (const float4 *)(M[p] + (size_t)(32 * wid + i) * N + h * HK);
+  }
+#pragma unroll
+  for (int q = 0; q < HK / 4; ++q) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const float4 a4 = m2[p][q];
+      const float *yp = ylds + p * HK * 64 + (4 * q) * 64 + lane;
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, yp[0], acc[p], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, yp[64], acc[p], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, yp[128], acc[p], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, yp[192], acc[p], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+}
+
+template <int N>
+struct MregCfg {
+  static constexpr int NT = N / 32, NTHR = 64 * NT, HK = N / 2;
+  static constexpr int LDS_FWD = HK * 64 * 4, LDS_ADJ = 2 * HK * 64 * 4;
+  static_assert(N % 64 == 0 && LDS_ADJ <= 163840 - 1024, "grid size");
+};
+
+// forward: grid (N / 32, J + has_pts); block (b, s): c_{s+1}(h)[:, blk] -> C[s + 1], or (s == J) c_1(Pbar)[:, blk] -> C[J + 1]
+template <int N>
+__global__ __launch_bounds__(MregCfg<N>::NTHR) void mreg_forward_kernel(MregArgs A) {
+  extern __shared__ __align__(16) float mr_lds[];
+  constexpr int HK = N / 2;
+  const int b0 = blockIdx.x * 32, s = blockIdx.y + A.s0, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const bool pts = (s == A.J);
+  const int j = pts ? 1 : s + 1;
+  const float *S = pts ? A.P : A.X;
+  float *dst = A.C + (size_t)(pts ? A.J + 1 : j) * N * N;
+  const float *const M[1] = {A.A + (size_t)j * N * N};
+  const float4 *sp = (const float4 *)(S + (size_t)(32 * wid + i) * N + h * HK);
+  mr_acc acc[1];
+  mr_two_sided<N, 1>([&](int q) { return sp[q]; }, M, b0, mr_lds, lane, wid, acc);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dst[(size_t)(32 * wid + mr_row(r, h)) * N + b0 + i] = acc[0][r];
+}
+
+// adjoint: grid (N / 32, J + has_pts); block (b, s): Z[s][:, blk] = A_s^T q_s A_s[:, blk] - A_{s+1}^T q_s A_{s+1}[:, blk]
+// (s == J: the point-source term, q from Pbar - c_1(Pbar) with the scale-0 weights);  l1p[s] from the blocks b == 0
+template <int N>
+__global__ __launch_bounds__(MregCfg<N>::NTHR) void mreg_adjoint_kernel(MregArgs A) {
+  extern __shared__ __align__(16) float mr_lds[];
+  __shared__ float red[MregCfg<N>::NT];
+  constexpr int HK = N / 2, NN = N * N;
+  const int b0 = blockIdx.x * 32, s = blockIdx.y + A.s0, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const bool pts = (s == A.J);
+  const int j = pts ? 0 : s;
+  const float *Cj = pts ? A.P : (j == 0 ? A.X : A.C + (size_t)j * NN);
+  const float *Cj1 = A.C + (size_t)(pts ? A.J + 1 : j + 1) * NN;
+  const float lam = pts ? A.lam_pts : (j == 0 ? A.lam_hf : A.lam_sc);
+  const float *Wj = A.W ? A.W + (size_t)j * NN : nullptr;
+  const float lwc = Wj ? 0.f : lam * A.norms[j];
+  float l1 = 0.f;
+  auto qval = [&](float c, float cn, float wgt) {
+    const float w = c - cn, lw = Wj ? lam * wgt : lwc;
+    l1 = fmaf(lw, fabsf(w), l1);
+    return (w > 0.f) ? lw : ((w < 0.f) ? -lw : 0.f);
+  };
+  const size_t roff = (size_t)(32 * wid + i) * N + h * HK;
+  const float4 *c4 = (const float4 *)(Cj + roff), *n4 = (const float4 *)(Cj1 + roff);
+  const float4 *w4 = Wj ? (const float4 *)(Wj + roff) : nullptr;
+  auto qrow = [&](int q) {
+    const float4 c = c4[q], n = n4[q];
+    const float4 w = Wj ? w4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    return make_float4(qval(c.x, n.x, w.x), qval(c.y, n.y, w.y), qval(c.z, n.z, w.z), qval(c.w, n.w, w.w));
+  };
+  float *Zs = A.Z + (size_t)s * NN;
+  if (j == 0) {  // A_0 = I: the first product is q itself
+    const float *const M[1] = {A.AT + (size_t)NN};
+    mr_acc acc[1];
+    mr_two_sided<N, 1>(qrow, M, b0, mr_lds, lane, wid, acc);
+    const float l1_rows = l1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const size_t k = (size_t)(32 * wid + mr_row(r, h)) * N + b0 + i;
+      Zs[k] = qval(Cj[k], Cj1[k], Wj ? Wj[k] : 0.f) - acc[0][r];
+    }
+    l1 = l1_rows;  // the second pass over this block's own pixels does not count twice
+  } else {
+    const float *const M[2] = {A.AT + (size_t)j * NN, A.AT + (size_t)(j + 1) * NN};
+    mr_acc acc[2];
+    mr_two_sided<N, 2>(qrow, M, b0, mr_lds, lane, wid, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Zs[(size_t)(32 * wid + mr_row(r, h)) * N + b0 + i] = acc[0][r] - acc[1][r];
+  }
+  // the waves of a block cover every pixel of the scale once: value of the term, waves combined in order
+  l1 = wave_sum_shfl(l1);
+  if (lane == 0) red[wid] = l1;
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < MregCfg<N>::NT; ++w) t += red[w];
+    A.l1p[s] = t;
+  }
+}
+
+// Pbar = sum_i abar_i G(c_i) on the grid of h (abar_i = mean over the epochs of a[e][i], summed in a fixed order by every block)
+__global__ __launch_bounds__(kGmThreads) void mreg_pbar_kernel(int N, int ss, int E, int M, const float *a, const float *cx,
+                                                               const float *cy, float *pbar) {
+  __shared__ float abar[kMaxSources];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int i = wid; i < M; i += kGmThreads / 64) {
+    float acc = 0.f;
+    for (int e = lane; e < E; e += 64) acc += a[e * M + i];
+    acc = wave_sum_shfl(acc);
+    if (lane == 0) abar[i] = acc / (float)E;
+  }
+  __syncthreads();
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N * N) return;
+  const float c0 = (N - 1) * 0.5f, inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm2 = 0.15915494309189535f * inv_s2;
+  const int u = k / N, v = k % N;
+  float acc = 0.f;
+  for (int i = 0; i < M; ++i) {
+    const float tx = (float)v - (c0 + ss * cx[i]), ty = (float)u - (c0 + ss * cy[i]);
+    acc = fmaf(abar[i] * nrm2, expf(-0.5f * (tx * tx + ty * ty) * inv_s2), acc);
+  }
+  pbar[k] = acc;
+}
+
+// greg = sum_j Z[j] + positivity sub-gradient; per-block positivity partials; per-block inner products of Z[J] with
+// G_i and its position derivatives (gm_pts_inner_kernel's contract)
+__global__ __launch_bounds__(kGmThreads) void mreg_finish_kernel(int N, int J, int l1_on, int has_pts, int ss, int M,
+                                                                 const float *Z, const float *h, float lam_pos,
+                                                                 const float *cx, const float *cy, float *greg,
+                                                                 float *pos_part, float *pts_part) {
+  __shared__ float red[kGmThreads / 64][kMaxSources * 3 + 1];
+  const int NN = N * N, k = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool in = k < NN;
+  float g = 0.f, pos = 0.f;
+  if (in) {
+    if (l1_on)
+      for (int s = 0; s < J; ++s) g += Z[(size_t)s * NN + k];
+    const float hv = h[k];
+    if (lam_pos != 0.f && hv < 0.f) {
+      pos = -lam_pos * hv;
+      g -= lam_pos;
+    }
+    greg[k] = g;
+  }
+  pos = wave_sum_shfl(pos);
+  if (lane == 0) red[wid][kMaxSources * 3] = pos;
+  if (has_pts) {
+    const float c0 = (N - 1) * 0.5f, inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm2 = 0.15915494309189535f * inv_s2;
+    const float z = in ? Z[(size_t)J * NN + k] : 0.f;
+    const int u = in ? k / N : 0, v = in ? k % N : 0;
+    for (int i = 0; i < M; ++i) {
+      const float tx = (float)v - (c0 + ss * cx[i]), ty = (float)u - (c0 + ss * cy[i]);
+      const float gq = z * nrm2 * expf(-0.5f * (tx * tx + ty * ty) * inv_s2);
+      const float sa = wave_sum_shfl(gq), sx = wave_sum_shfl(gq * tx * inv_s2), sy = wave_sum_shfl(gq * ty * inv_s2);
+      if (lane == 0) {
+        red[wid][i * 3] = sa;
+        red[wid][i * 3 + 1] = sx;
+        red[wid][i * 3 + 2] = sy;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kGmThreads / 64; ++w) t += red[w][kMaxSources * 3];
+    pos_part[blockIdx.x] = t;
+  }
+  if (has_pts && (int)threadIdx.x < 3 * M) {
+    float acc = 0.f;
+    for (int w = 0; w < kGmThreads / 64; ++w) acc += red[w][threadIdx.x];
+    pts_part[(size_t)blockIdx.x * 3 * kMaxSources + threadIdx.x] = acc;
+  }
+}
+
+// regs[0] = l1, regs[1] = positivity, regs[2] = point-source term, regs[4 + 3 i + q] = its inner products (one wave)
+__global__ void mreg_regs_kernel(int J, int l1_on, int has_pts, int nblocks, int M, const float *l1p, const float *pos_part,
+                                 const float *pts_part, float *regs) {
+  const int lane = threadIdx.x;
+  float b = 0.f;
+  for (int i = lane; i < nblocks; i += 64) b += pos_part[i];
+  b = wave_sum_shfl(b);
+  if (lane == 0) {
+    float a = 0.f;
+    if (l1_on)
+      for (int s = 0; s < J; ++s) a += l1p[s];
+    regs[0] = a;
+    regs[1] = b;
+    if (has_pts) regs[2] = l1p[J];
+  }
+  if (has_pts)
+    for (int t = 0; t < 3 * M; ++t) {
+      float acc = 0.f;
+      for (int blk = lane; blk < nblocks; blk += 64) acc += pts_part[(size_t)blk * 3 * kMaxSources + t];
+      acc = wave_sum_shfl(acc);
+      if (lane == 0) regs[4 + t] = acc;
+    }
+}
+
+}  // namespace lc
