@@ -72,6 +72,7 @@ struct lc_joint {
   hipEvent_t evReg = nullptr, evUpd = nullptr;
   bool reg_pending = false;
   bool in_device_loop = false, fuse_pending = false;
+  bool fuse_full = false;  // lc_joint_run_adabelief, background free: reduction over the epochs and update in one launch
   bool pts_pending = false;  // the point-source starlet term of this iteration was evaluated by the stream-B launch  // lc_joint_run_adabelief: scalar reduction fused into the update
   std::vector<float> h_sigma2, h_psf;  // host copies for the one-time noise propagation
   std::vector<void *> allocs;
@@ -264,8 +265,8 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
 
 int launch_reduce(lc_joint *j, int need_h) {
   const int NN = j->N * j->N;
-  const int nimg = (NN + kRedPix - 1) / kRedPix;
-  hipLaunchKernelGGL(joint_reduce_kernel, dim3(nimg + 1), dim3(kRedPix * kRedParts), 0, j->ctx->stream, j->E, j->M, NN,
+  const int nimg = NN / kRedPix;
+  hipLaunchKernelGGL(joint_reduce_kernel, dim3(nimg + 1), dim3(kRedThreads), 0, j->ctx->stream, j->E, j->M, NN,
                      need_h, j->HG, j->g_cx_e, j->g_cy_e, j->chi2_e, j->par[LC_P_A], j->a_ref, j->shared);
   LC_HIP(j->ctx, hipGetLastError());
   return LC_OK;
@@ -472,6 +473,16 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   if (!v->uk || ((A.lam_pts == 0.f || A.pts_early == 2) && (reg_mode == 2 || !rh))) {
     const int NN = j->N * j->N;
     int nblk = (NN + kGmThreads - 1) / kGmThreads;
+    if (j->fuse_full && mode == 1) {
+      A.g_cx_e = j->g_cx_e;
+      A.g_cy_e = j->g_cy_e;
+      A.chi2_e = j->chi2_e;
+      A.shared_w = j->shared;
+      const int nimg = NN / kRedPix;
+      hipLaunchKernelGGL(joint_reduce_update_kernel, dim3(nimg + 2), dim3(kRedThreads), 0, stream, A, j->N, j->HG);
+      LC_HIP(j->ctx, hipGetLastError());
+      return LC_OK;
+    }
     if (j->fuse_pending && mode == 1) {
       A.fuse_scalar_reduce = 1;
       A.g_cx_e = j->g_cx_e;
@@ -900,9 +911,11 @@ int lc_joint_step_local(lc_joint *j) {
   if (need < 0) return need;
   // inside lc_joint_run_adabelief, with the background fixed, only scalars are reduced: the multi-block update
   // kernel does that itself (one launch less per iteration)
-  j->fuse_pending = j->in_device_loop && need == 0 && !j->free_mask[LC_P_H] &&
-                    (!j->v->uk || ((j->cfg.lam_pts_source == 0.f || j->pts_pending) && (j->reg_pending || !reg_h_on(j))));
-  if (j->fuse_pending) return LC_OK;
+  const bool gm_update = !j->v->uk || ((j->cfg.lam_pts_source == 0.f || j->pts_pending) && (j->reg_pending || !reg_h_on(j)));
+  j->fuse_pending = j->in_device_loop && need == 0 && !j->free_mask[LC_P_H] && gm_update;
+  // with the background free the same holds for the image part: reduction and update share one launch
+  j->fuse_full = j->in_device_loop && need == 1 && j->free_mask[LC_P_H] && gm_update && !std::getenv("LCMI_SPLIT_UPDATE");
+  if (j->fuse_pending || j->fuse_full) return LC_OK;
   return launch_reduce(j, need);
 }
 int lc_joint_shared_buffer_dev(lc_joint *j, void **dev_ptr, int *count) {
@@ -933,6 +946,7 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
   j->reg_pending = false;
   j->fuse_pending = false;
+  j->fuse_full = false;
   j->pts_pending = false;
   j->iters_done += 1;
   return LC_OK;

@@ -207,43 +207,20 @@ __global__ void gm_pts_final_kernel(int nblocks, int M, const float *part, const
   }
 }
 
-// AdaBelief on h (every block) and on the small blocks + loss (block 0).  A.greg / A.regs hold the h regulariser.
-__global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArgs A, int N) {
-  __shared__ float sc[8];
+// AdaBelief on the small parameter blocks and the loss of the iteration (one block of kGmThreads threads; same rules as
+// joint_update_kernel).  A.greg / A.regs hold the h regulariser when A.reg_mode == 2.
+// sc: the scalar part of the reduced block (A.shared + N * N, or a copy in LDS); parts: bit 0 = fluxes, positions and the
+// loss, bit 1 = dx, dy, mean (independent of the reduction: a block of their own in the fused launch)
+__device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, float lr, float bc1, float bc2, const float *sc,
+                                                int parts) {
   __shared__ float red[kGmThreads / 64];
-  __shared__ double lanes[kGmThreads];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int E = A.E, M = A.M, NN = N * N;
-  if (A.fuse_scalar_reduce) {  // grid of one block (the background is not updated)
-    reduce_scalars(E, M, NN, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.a_ref, A.shared_w, lanes, tid);
-    __threadfence_block();
-    __syncthreads();
-  }
-  const float Etot = A.shared[NN + 4 * M + 1];
+  const float Etot = (parts & 1) ? sc[4 * M + 1] : 0.f;
   const bool use_reg = (A.reg_mode == 2);
   const bool pts = (A.lam_pts != 0.f && A.pts_early == 2);  // point-source starlet term evaluated by the reg launch
-  if (tid == 0) {
-    sc[0] = A.lr;
-    sc[1] = A.bc1;
-    sc[2] = A.bc2;
-  }
-  __syncthreads();
-  const float lr = sc[0], bc1 = sc[1], bc2 = sc[2];
-  const int k = blockIdx.x * blockDim.x + tid;
-  if (k < NN) {
-    const float g = A.shared[k] + (use_reg ? A.greg[k] : 0.f);
-    if (A.mode == 0 && A.gout[LC_P_H]) A.gout[LC_P_H][k] = g;
-    if (A.mode == 1 && A.free_mask[LC_P_H]) {
-      float hv = A.h[k], m = A.mh[k], s = A.sh[k];
-      adabelief_step(hv, m, s, g, lr, bc1, bc2, A.ab);
-      A.h[k] = hv;
-      A.mh[k] = m;
-      A.sh[k] = s;
-    }
-  }
-  if (blockIdx.x != 0) return;
-  // ---- block 0: small parameter blocks and the loss (same rules as joint_update_kernel) ----
   float pos_ps = 0.f;
+  if (parts & 1)
   for (int idx = tid; idx < E * M; idx += kGmThreads) {
     const int i = idx % M;
     float av = A.par[LC_P_A][idx];
@@ -253,8 +230,8 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
       ga -= A.lam_pos_ps;
     }
     if (A.lam_fu != 0.f && Etot > 1.f) {
-      const float meanc = A.shared[NN + 2 * M + i] / Etot;  // centred on a_ref (joint_kernels.h, kernel 2)
-      const float var = fmaxf(A.shared[NN + 3 * M + i] / Etot - meanc * meanc, 0.f);
+      const float meanc = sc[2 * M + i] / Etot;  // centred on a_ref (joint_kernels.h, kernel 2)
+      const float var = fmaxf(sc[3 * M + i] / Etot - meanc * meanc, 0.f);
       const float sd = sqrtf(var);
       if (sd > 0.f) ga += A.lam_fu * ((av - A.a_ref[i]) - meanc) / (Etot * sd);
     }
@@ -266,6 +243,7 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
       A.par[LC_P_A][idx] = av;
     }
   }
+  if (parts & 2)
   for (int idx = tid; idx < 3 * E; idx += kGmThreads) {
     const int which = (idx / E == 0) ? LC_P_DX : (idx / E == 1) ? LC_P_DY : LC_P_MEAN;
     const int e = idx % E;
@@ -278,12 +256,13 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
       A.par[which][e] = pv_;
     }
   }
+  if (!(parts & 1)) return;
   double prior_loss = 0.0;
   if (tid < 2 * M) {
     const int which = (tid < M) ? LC_P_CX : LC_P_CY, i = tid % M;
-    float gv = A.shared[NN + (which == LC_P_CX ? 0 : M) + i];
+    float gv = sc[(which == LC_P_CX ? 0 : M) + i];
     float cv = A.par[which][i];
-    if (pts) gv += (A.a_ref[i] + A.shared[NN + 2 * M + i] / Etot) * A.ss * A.regs[4 + i * 3 + (which == LC_P_CX ? 1 : 2)];
+    if (pts) gv += (A.a_ref[i] + sc[2 * M + i] / Etot) * A.ss * A.regs[4 + i * 3 + (which == LC_P_CX ? 1 : 2)];
     if (A.n_prior > 0) {
       const float mu = (which == LC_P_CX) ? A.prior_cx_mean[i] : A.prior_cy_mean[i];
       const float sg = (which == LC_P_CX) ? A.prior_cx_sigma[i] : A.prior_cy_sigma[i];
@@ -303,19 +282,89 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
   if (lane == 0) red[wid] = part;
   __syncthreads();
   if (tid == 0) {
-    double loss = 0.5 * (double)A.shared[NN + 4 * M];
+    double loss = 0.5 * (double)sc[4 * M];
     for (int w = 0; w < kGmThreads / 64; ++w) loss += red[w];
     if (use_reg) loss += (double)A.regs[0] + (double)A.regs[1];
     if (pts) loss += (double)A.regs[2];
     if (A.lam_fu != 0.f && Etot > 1.f)
       for (int i = 0; i < M; ++i) {
-        const double meanc = A.shared[NN + 2 * M + i] / Etot;
-        const double var = fmax((double)A.shared[NN + 3 * M + i] / Etot - meanc * meanc, 0.0);
+        const double meanc = sc[2 * M + i] / Etot;
+        const double var = fmax((double)sc[3 * M + i] / Etot - meanc * meanc, 0.0);
         loss += A.lam_fu * sqrt(var);
       }
     if (A.hist) A.hist[A.t] = (float)loss;
     if (A.out_loss) *A.out_loss = (float)loss;
   }
+}
+
+// AdaBelief on h (every block) and on the small blocks + loss (block 0).  A.greg / A.regs hold the h regulariser.
+__global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArgs A, int N) {
+  __shared__ double lanes[kGmThreads];
+  const int tid = threadIdx.x;
+  const int E = A.E, M = A.M, NN = N * N;
+  if (A.fuse_scalar_reduce) {  // grid of one block (the background is not updated)
+    reduce_scalars(E, M, NN, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.a_ref, A.shared_w, lanes, tid);
+    __threadfence_block();
+    __syncthreads();
+  }
+  const bool use_reg = (A.reg_mode == 2);
+  const float lr = A.lr, bc1 = A.bc1, bc2 = A.bc2;
+  const int k = blockIdx.x * blockDim.x + tid;
+  if (k < NN) {
+    const float g = A.shared[k] + (use_reg ? A.greg[k] : 0.f);
+    if (A.mode == 0 && A.gout[LC_P_H]) A.gout[LC_P_H][k] = g;
+    if (A.mode == 1 && A.free_mask[LC_P_H]) {
+      float hv = A.h[k], m = A.mh[k], s = A.sh[k];
+      adabelief_step(hv, m, s, g, lr, bc1, bc2, A.ab);
+      A.h[k] = hv;
+      A.mh[k] = m;
+      A.sh[k] = s;
+    }
+  }
+  if (blockIdx.x != 0) return;
+  gm_small_blocks(A, N, lr, bc1, bc2, A.shared + NN, 3);
+}
+
+// The reduction over the epochs and the update in ONE launch (the device loop of a single GPU, where nothing has to
+// happen between the two): block b < nimg sums its 16 pixels of the T^T slabs (joint_reduce_kernel's order) and applies
+// AdaBelief to them right away; block nimg reduces the scalars, updates fluxes and positions and writes the loss; block
+// nimg + 1 updates the per-epoch shifts and sky levels.
+__global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointUpdArgs A, int N, const float *HG) {
+  static_assert(kRedThreads == kGmThreads, "one block size");
+  __shared__ float4 part[kRedParts][kRedPix / 4];
+  __shared__ double lanes[kRedThreads];
+  const int E = A.E, M = A.M, NN = N * N;
+  const int nimg = NN / kRedPix;
+  const int tid = threadIdx.x;
+  const float lr = A.lr, bc1 = A.bc1, bc2 = A.bc2;
+  if ((int)blockIdx.x < nimg) {
+    const int px0 = blockIdx.x * kRedPix, px = px0 + tid;
+    // state of this thread's pixel: requested before the reduction, used after it
+    float hv = 0.f, m = 0.f, sv = 0.f, gr = 0.f;
+    if (tid < kRedPix) {
+      hv = A.h[px];
+      m = A.mh[px];
+      sv = A.sh[px];
+      gr = (A.reg_mode == 2) ? A.greg[px] : 0.f;
+    }
+    const float t = reduce_pixels16(E, NN, HG, px0, part, tid);
+    if (tid < kRedPix) {
+      A.shared_w[px] = t;
+      adabelief_step(hv, m, sv, t + gr, lr, bc1, bc2, A.ab);
+      A.h[px] = hv;
+      A.mh[px] = m;
+      A.sh[px] = sv;
+    }
+    return;
+  }
+  if ((int)blockIdx.x == nimg + 1) {  // shifts and sky levels: nothing to wait for
+    gm_small_blocks(A, N, lr, bc1, bc2, nullptr, 2);
+    return;
+  }
+  __shared__ float scl[4 * kMaxSources + 2];
+  reduce_scalars(E, M, NN, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.a_ref, A.shared_w, lanes, tid, scl);
+  __syncthreads();
+  gm_small_blocks(A, N, lr, bc1, bc2, scl, 1);
 }
 
 }  // namespace lc

@@ -780,74 +780,105 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 // flux-uniformity term needs var = <a^2> - <a>^2, which cancels catastrophically in fp32 when the relative scatter of
 // a source is below ~1e-3 (all fluxes start equal in the reference's ROI fit); centred, the cancellation is relative
 // to the scatter itself.
-// Image part: a block owns 32 consecutive pixels; its 8 groups of 32 lanes each sum one eighth of the epochs
-// (coalesced 128-byte rows, 4 independent loads in flight per lane), then the 8 partials are added in a fixed
-// order, so the result does not depend on scheduling.  Scalars: last block, one thread each, in double.
-constexpr int kRedPix = 32, kRedParts = 8;
-// Scalars of the shared block: quantity q in [0, 4M] (dc_x, dc_y, sum a, sum a^2 per source, then chi2), one wave per
-// quantity at a time; lanes stride over the epochs in double, partials combined in lane order.  256 threads.
+// Image part: a block owns 16 consecutive pixels (four 16-byte quads); its 64 groups of four lanes each sum the epochs
+// e = g, g + 64, g + 128 ... (every load of a thread independent of the others: the 13 MB of slabs of a 200-epoch fit are
+// in flight at once instead of trickling through a few waves per CU), then the 64 partials of a pixel are added in a
+// fixed order, so the result does not depend on scheduling.  Scalars: last block, in double.
+constexpr int kRedPix = 16, kRedParts = 64, kRedThreads = (kRedPix / 4) * kRedParts;
+// sum over the epochs of HG[e][px0 .. px0 + 15] -> one value per pixel in threads tid < 16 (others: 0)
+__device__ __forceinline__ float reduce_pixels16(int E, int NN, const float *HG, int px0, float4 (*part)[kRedPix / 4], int tid) {
+  const int quad = tid & (kRedPix / 4 - 1), grp = tid / (kRedPix / 4);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float *src = HG + px0 + 4 * quad;
+  int e = grp;
+  for (; e + 3 * kRedParts < E; e += 4 * kRedParts) {
+    const float4 v0 = *(const float4 *)(src + (size_t)e * NN), v1 = *(const float4 *)(src + (size_t)(e + kRedParts) * NN);
+    const float4 v2 = *(const float4 *)(src + (size_t)(e + 2 * kRedParts) * NN);
+    const float4 v3 = *(const float4 *)(src + (size_t)(e + 3 * kRedParts) * NN);
+    acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+    acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+    acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+    acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+  }
+  for (; e < E; e += kRedParts) {
+    const float4 v = *(const float4 *)(src + (size_t)e * NN);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  part[grp][quad] = acc;
+  __syncthreads();
+  float t = 0.f;
+  if (tid < kRedPix) {
+    const float *p = (const float *)part + tid;  // [grp][16 floats]
+#pragma unroll 8
+    for (int g = 0; g < kRedParts; ++g) t += p[g * kRedPix];
+  }
+  return t;
+}
+// Scalars of the shared block: dc_x, dc_y, sum (a - ref), sum (a - ref)^2 per source, then chi2 and the epoch count.
+// Every thread strides over the epochs with all 4 M + 1 running sums in double (the loads of an epoch are independent of
+// each other: one latency for the whole block at E <= 256), lanes combine by shuffles, waves through LDS in order.
+// lanes: [kRedThreads] doubles of LDS; scl (optional, LDS): receives a copy of the 4 M + 2 values.  256 threads.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
 __device__ __forceinline__ void reduce_scalars(int E, int M, int NN, const float *g_cx_e, const float *g_cy_e,
                                                const float *chi2_e, const float *a, const float *a_ref, float *shared,
-                                               double *lanes, int tid) {
-  const int lane = tid & 63, wid = tid >> 6, nw = (kRedPix * kRedParts) / 64;
-  for (int q = wid; q <= 4 * M; q += nw) {
-    double acc = 0.0;
-    for (int e = lane; e < E; e += 64) {
-      if (q == 4 * M) {
-        acc += chi2_e[e];
-      } else {
-        const int kind = q / M, i = q % M;
+                                               double *lanes, int tid, float *scl = nullptr) {
+  constexpr int NQ = 4 * kMaxSources + 1;
+  static_assert((kRedThreads / 64) * NQ <= kRedThreads, "LDS scratch");
+  const int lane = tid & 63, wid = tid >> 6, nw = kRedThreads / 64;
+  double acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+  for (int e = tid; e < E; e += kRedThreads) {
+#pragma unroll
+    for (int i = 0; i < kMaxSources; ++i) {
+      if (i < M) {
         const double ai = (double)a[e * M + i] - (double)a_ref[i];
-        acc += (kind == 0) ? (double)g_cx_e[e * M + i] : (kind == 1) ? (double)g_cy_e[e * M + i] : (kind == 2) ? ai : ai * ai;
+        acc[i] += (double)g_cx_e[e * M + i];
+        acc[kMaxSources + i] += (double)g_cy_e[e * M + i];
+        acc[2 * kMaxSources + i] += ai;
+        acc[3 * kMaxSources + i] += ai * ai;
       }
     }
-    lanes[tid] = acc;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane == 0) {
-      double t = 0.0;
-      for (int l = 0; l < 64; ++l) t += lanes[wid * 64 + l];
-      shared[NN + q] = (float)t;
-    }
-    __builtin_amdgcn_wave_barrier();
+    acc[4 * kMaxSources] += (double)chi2_e[e];
   }
-  if (tid == 0) shared[NN + 4 * M + 1] = (float)E;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if ((q % kMaxSources) < M || q == 4 * kMaxSources) {
+      const double v = wave_sum_f64(acc[q]);
+      if (lane == 0) lanes[wid * NQ + q] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < NQ && ((tid % kMaxSources) < M || tid == 4 * kMaxSources)) {
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += lanes[w * NQ + tid];
+    const int dst = (tid == 4 * kMaxSources) ? 4 * M : (tid / kMaxSources) * M + (tid % kMaxSources);
+    shared[NN + dst] = (float)t;
+    if (scl) scl[dst] = (float)t;
+  }
+  if (tid == 0) {
+    shared[NN + 4 * M + 1] = (float)E;
+    if (scl) scl[4 * M + 1] = (float)E;
+  }
 }
-__global__ __launch_bounds__(kRedPix *kRedParts) void joint_reduce_kernel(int E, int M, int NN, int need_h, const float *HG,
-                                                                           const float *g_cx_e, const float *g_cy_e,
-                                                                           const float *chi2_e, const float *a,
-                                                                           const float *a_ref, float *shared) {
-  __shared__ float part[kRedParts][kRedPix];
-  const int nimg = (NN + kRedPix - 1) / kRedPix;
+__global__ __launch_bounds__(kRedThreads) void joint_reduce_kernel(int E, int M, int NN, int need_h, const float *HG,
+                                                                    const float *g_cx_e, const float *g_cy_e,
+                                                                    const float *chi2_e, const float *a,
+                                                                    const float *a_ref, float *shared) {
+  __shared__ float4 part[kRedParts][kRedPix / 4];
+  const int nimg = NN / kRedPix;
   const int tid = threadIdx.x;
   if ((int)blockIdx.x < nimg) {
-    const int px = blockIdx.x * kRedPix + (tid % kRedPix), p = tid / kRedPix;
-    const int e0 = (int)(((long long)E * p) / kRedParts), e1 = (int)(((long long)E * (p + 1)) / kRedParts);
-    float acc = 0.f;
-    if (need_h && px < NN) {
-      int e = e0;
-      for (; e + 4 <= e1; e += 4) {
-        const float v0 = HG[(size_t)e * NN + px], v1 = HG[(size_t)(e + 1) * NN + px];
-        const float v2 = HG[(size_t)(e + 2) * NN + px], v3 = HG[(size_t)(e + 3) * NN + px];
-        acc += v0;
-        acc += v1;
-        acc += v2;
-        acc += v3;
-      }
-      for (; e < e1; ++e) acc += HG[(size_t)e * NN + px];
-    }
-    part[p][tid % kRedPix] = acc;
-    __syncthreads();
-    if (tid < kRedPix && px < NN) {
-      float t = 0.f;
-#pragma unroll
-      for (int q = 0; q < kRedParts; ++q) t += part[q][tid];
-      shared[px] = t;
-    }
+    const int px0 = blockIdx.x * kRedPix;
+    const float t = need_h ? reduce_pixels16(E, NN, HG, px0, part, tid) : 0.f;
+    if (tid < kRedPix) shared[px0 + tid] = t;
     return;
   }
-  __shared__ double lanes[kRedPix * kRedParts];
+  __shared__ double lanes[kRedThreads];
   reduce_scalars(E, M, NN, g_cx_e, g_cy_e, chi2_e, a, a_ref, shared, lanes, tid);
 }
 
