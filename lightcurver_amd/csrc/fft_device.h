@@ -13,7 +13,7 @@ __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) {  // a * conj(b
   return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
 }
 
-// ---- quarter-wave register FFT ------------------------------------------------------------------------
+// ---- quarter-wave (or half-wave) register FFT ------------------------------------------------------------------------
 // One length-L transform per group of 16 lanes (four per wave, side by side), data in registers:
 // (L = 16 * N2 with N2 = 2^m or 3 * 2^m: 32, 48, 96, 192, 384 ... -- the smallest alias-free length of an N-point 'same'
 //  convolution is 3N/2, so the factor 3 saves a quarter of the work of the next power of two)
@@ -153,6 +153,15 @@ LC_DEF_EXCHANGE(exch_b3, "row_ror:8 row_mask:0xf bank_mask:0xf")
 // x[k2] += s * (x[k2] of the lane whose fft_index differs in bit H), all k2
 template <int H, int N2>
 __device__ __forceinline__ void exchange_add(float2 (&x)[N2], float s) {
+  if constexpr (H == 16) {  // half-wave transforms: the partner sits in the neighbouring DPP row (lane ^ 16), through the LDS crossbar
+#pragma unroll
+    for (int k = 0; k < N2; ++k) {
+      const float px = __shfl_xor(x[k].x, 16, 64), py = __shfl_xor(x[k].y, 16, 64);
+      x[k].x = fmaf(px, s, x[k].x);
+      x[k].y = fmaf(py, s, x[k].y);
+    }
+    return;
+  }
   constexpr int N6 = N2 / 6 * 6;
 #pragma unroll
   for (int k = 0; k < N6; k += 6) {
@@ -172,55 +181,70 @@ __device__ __forceinline__ void exchange_add(float2 (&x)[N2], float s) {
 
 // One decimation-in-frequency stage across the lanes (span H): lower lane a + b, upper lane (a - b) w.
 // Branch- and select-free: t = x + s x[partner] with s = +-1 (the upper lane gets b - a, the sign goes into its
-// twiddle), then a multiplication by w (lower lanes: 1).  j16 = fft_index(lane & 15).
-template <int L, int H>
-__device__ __forceinline__ void dif_stage(float2 (&x)[L / 16], int j16, const float2 *tw) {
-  const bool upper = (j16 & H) != 0;
-  float2 wt = tw[(j16 & (H - 1)) * (L / (2 * H))];
-  asm volatile("" : "+v"(wt.x), "+v"(wt.y));  // every lane loads: no branch around the read (it would split the block the exchanges fold in)
+// twiddle), then a multiplication by w (lower lanes: 1).  j = transform index of the lane (fft_index_n).
+template <int L, int H, int LPF>
+__device__ __forceinline__ void dif_stage(float2 (&x)[L / LPF], int j, const float2 *tw) {
+  const bool upper = (j & H) != 0;
+  float2 wt = tw[(j & (H - 1)) * (L / (2 * H))];
+  asm volatile("" : "+v"(wt.x), "+v"(wt.y));  // every lane loads: no branch around the read
   const float sgn = upper ? -1.f : 1.f;
   const float2 w = upper ? make_float2(-wt.x, -wt.y) : make_float2(1.f, 0.f);
   exchange_add<H>(x, sgn);
 #pragma unroll
-  for (int k2 = 0; k2 < L / 16; ++k2) x[k2] = cmul(x[k2], w);
+  for (int k2 = 0; k2 < L / LPF; ++k2) x[k2] = cmul(x[k2], w);
 }
 // One decimation-in-time stage (inverse direction): upper lane pre-multiplied by conj w, then a + b / a - b.
 // The upper lane carries -t through the exchange (sign in its twiddle), so that both lanes do x = t - s t[partner].
-template <int L, int H>
-__device__ __forceinline__ void dit_stage_inv(float2 (&x)[L / 16], int j16, const float2 *tw) {
-  const bool upper = (j16 & H) != 0;
-  float2 wt = tw[(j16 & (H - 1)) * (L / (2 * H))];
-  asm volatile("" : "+v"(wt.x), "+v"(wt.y));  // every lane loads: no branch around the read (it would split the block the exchanges fold in)
+template <int L, int H, int LPF>
+__device__ __forceinline__ void dit_stage_inv(float2 (&x)[L / LPF], int j, const float2 *tw) {
+  const bool upper = (j & H) != 0;
+  float2 wt = tw[(j & (H - 1)) * (L / (2 * H))];
+  asm volatile("" : "+v"(wt.x), "+v"(wt.y));
   const float msg = upper ? 1.f : -1.f;
   const float2 w = upper ? make_float2(-wt.x, wt.y) : make_float2(1.f, 0.f);
 #pragma unroll
-  for (int k2 = 0; k2 < L / 16; ++k2) x[k2] = cmul(x[k2], w);
+  for (int k2 = 0; k2 < L / LPF; ++k2) x[k2] = cmul(x[k2], w);
   exchange_add<H>(x, msg);
 }
+// Transforms over LPF = 16 lanes (four per wave) or 32 lanes (two per wave; the longest grids, whose 24 registers per
+// lane at LPF = 16 would not leave room for anything else): transform index of a lane / lane of an index, and the bit
+// reversal of the block layout
+template <int LPF>
+__device__ __forceinline__ int fft_index_n(int l) {
+  if constexpr (LPF == 16) return fft_index(l);
+  else return fft_index(l & 15) | (l & 16);
+}
+template <int LPF>
+__device__ __forceinline__ int bitrev_n(int x) {
+  if constexpr (LPF == 16) return bitrev4(x);
+  else return (bitrev4(x & 15) << 1) | ((x >> 4) & 1);
+}
 // tw[m] = exp(-2 pi i m / L), m < L (LDS)
-template <int L>
-__device__ __forceinline__ void quarter_fft_fwd(float2 (&x)[L / 16], int l16, const float2 *tw) {
-  constexpr int N2 = L / 16;
-  if constexpr (N2 >= 24) LC_LAUNDER(l16);  // keep the 2 * N2 twiddle registers from being hoisted out of the caller's loops
+template <int L, int LPF = 16>
+__device__ __forceinline__ void group_fft_fwd(float2 (&x)[L / LPF], int j, const float2 *tw) {
+  constexpr int N2 = L / LPF;
+  if constexpr (N2 >= 24) LC_LAUNDER(j);  // keep the 2 * N2 twiddle registers from being hoisted out of the caller's loops
   inlane_fft_any<N2, false>(x);
 #pragma unroll
-  for (int k2 = 1; k2 < N2; ++k2) x[k2] = cmul(x[k2], tw[l16 * k2]);
-  dif_stage<L, 8>(x, l16, tw);
-  dif_stage<L, 4>(x, l16, tw);
-  dif_stage<L, 2>(x, l16, tw);
-  dif_stage<L, 1>(x, l16, tw);
+  for (int k2 = 1; k2 < N2; ++k2) x[k2] = cmul(x[k2], tw[j * k2]);
+  if constexpr (LPF == 32) dif_stage<L, 16, LPF>(x, j, tw);
+  dif_stage<L, 8, LPF>(x, j, tw);
+  dif_stage<L, 4, LPF>(x, j, tw);
+  dif_stage<L, 2, LPF>(x, j, tw);
+  dif_stage<L, 1, LPF>(x, j, tw);
 }
-template <int L>
-__device__ __forceinline__ void quarter_fft_inv(float2 (&x)[L / 16], int l16, const float2 *tw) {
-  constexpr int N2 = L / 16;
-  if constexpr (N2 >= 24) LC_LAUNDER(l16);
-  dit_stage_inv<L, 1>(x, l16, tw);
-  dit_stage_inv<L, 2>(x, l16, tw);
-  dit_stage_inv<L, 4>(x, l16, tw);
-  dit_stage_inv<L, 8>(x, l16, tw);
+template <int L, int LPF = 16>
+__device__ __forceinline__ void group_fft_inv(float2 (&x)[L / LPF], int j, const float2 *tw) {
+  constexpr int N2 = L / LPF;
+  if constexpr (N2 >= 24) LC_LAUNDER(j);
+  dit_stage_inv<L, 1, LPF>(x, j, tw);
+  dit_stage_inv<L, 2, LPF>(x, j, tw);
+  dit_stage_inv<L, 4, LPF>(x, j, tw);
+  dit_stage_inv<L, 8, LPF>(x, j, tw);
+  if constexpr (LPF == 32) dit_stage_inv<L, 16, LPF>(x, j, tw);
 #pragma unroll
   for (int k2 = 1; k2 < N2; ++k2) {
-    float2 w = tw[l16 * k2];
+    float2 w = tw[j * k2];
     w.y = -w.y;
     x[k2] = cmul(x[k2], w);
   }

@@ -105,9 +105,9 @@ JointVariant make_jv() {
                       (int)(StarletLds<N>::FLOATS * sizeof(float)), false, joint_epoch_kernel<C, true>};
 }
 // large grids: spectrum scratch in HBM, starlet / update as multi-block kernels
-template <int N, int SS, int L, int NW>
+template <int N, int SS, int L, int NW, int LPF = 16>
 JointVariant make_jv_gm() {
-  typedef JointCfg<N, SS, L, NW, true> C;
+  typedef JointCfg<N, SS, L, NW, true, LPF> C;
   return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, nullptr, 0, 0, true, joint_epoch_kernel<C, true>};
 }
 int g_debug_global = 0;  // lc_joint_set_debug_global: small stamps through the large-grid kernels (parity tests)
@@ -127,7 +127,9 @@ const JointVariant *find_jv(int n, int ss) {
       make_jv<48, 2, 96, 4, 8>(),     // n = 24 (default stamp_size_stars)
       make_jv<64, 2, 96, 8, 16>(),    // n = 32 (default stamp_size_ROI)
       make_jv<128, 2, 192, 16, 8>(),  // n = 64 (C4)
-      make_jv_gm<256, 2, 384, 8>(),   // n = 128 (C5); 4 waves (one per SIMD, 436 registers, no scratch) measured 1.23 x slower
+      // n = 128 (C5): transforms over 32 lanes (12 registers per lane like the n = 64 kernel; at 16 lanes the 24-register
+      // transforms spilled 200+ registers, and 4 waves with 436 registers each measured 1.23 x slower than that)
+      make_jv_gm<256, 2, 384, 8, 32>(),
   };
   for (const auto &v : table)
     if (v.n == n && v.ss == ss) return &v;

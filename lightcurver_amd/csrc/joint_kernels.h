@@ -69,9 +69,11 @@ __device__ __forceinline__ float bilinear_h(const float *h, float Xs, float Ys, 
   return top + fy * (bot - top);
 }
 
-template <int N_, int SS_, int L_, int NW_, bool GSPEC_ = false>
+template <int N_, int SS_, int L_, int NW_, bool GSPEC_ = false, int LPF_ = 16>
 struct JointCfg {
   static constexpr int N = N_, SS = SS_, L = L_, n = N / SS;
+  // lanes per transform (fft_device.h) and transforms side by side in a wave
+  static constexpr int LPF = LPF_, GPW = 64 / LPF_;
   // GSPEC: the N x (L/2+1) half spectrum of the epoch lives in a global scratch instead of LDS (N = 256 does not fit)
   static constexpr bool GSPEC = GSPEC_;
   static constexpr int NW = NW_, NTHR = 64 * NW_;  // waves per epoch workgroup: as many as the LDS workspace allows
@@ -81,8 +83,8 @@ struct JointCfg {
   static constexpr int OFF_WS = OFF_SPEC + SZ_SPEC;
   // linear row buffer(s) for the data-space step: one per quarter-wave when LDS allows (N <= 64), else one per
   // wave that the four quarters use in turn
-  static constexpr bool WSQ = (N <= 128) && (NW_ <= 8);
-  static constexpr int SZ_WS = NW * (WSQ ? 4 : 1) * L;
+  static constexpr bool WSQ = ((N <= 128) && (NW_ <= 8)) || GSPEC_;
+  static constexpr int SZ_WS = NW * (WSQ ? GPW : 1) * L;
   static constexpr int OFF_TW = OFF_WS + SZ_WS;
   static constexpr int SZ_TW = L;
   static constexpr int OFF_RED = OFF_TW + SZ_TW;  // float2 units; reduction scratch as floats
@@ -90,7 +92,7 @@ struct JointCfg {
   // three rows of h per quarter-wave (translated epochs read the background from LDS): L float2 = 3 N floats, i.e. the
   // quarter's row buffer where there is one, a region of its own otherwise
   static constexpr int OFF_HROW = OFF_RED + SZ_RED;
-  static constexpr int SZ_HROW = WSQ ? 0 : NW * 4 * ((3 * N + 1) / 2);
+  static constexpr int SZ_HROW = WSQ ? 0 : NW * GPW * ((3 * N + 1) / 2);
   // separable Gaussian factors of the point sources: GX[i][N], GY[i][N] floats, then their centres X_i, Y_i
   static constexpr int OFF_TAB = OFF_HROW + SZ_HROW;
   static constexpr int SZ_TAB = kMaxSources * N + kMaxSources;
@@ -148,13 +150,15 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   LC_JSTAMP(1);
   // Every FFT below is a quarter-wave register transform (fft_device.h): each group of 16 lanes owns one row pair
   // or one spectrum column, so a wave works on four of them side by side.
-  constexpr int N2 = L / 16;
+  constexpr int LPF = C::LPF, GPW = C::GPW;
+  constexpr int N2 = L / LPF;
   // l16: the lane's index inside its transform (fft_device.h: not the lane number, the exchanges are DPP involutions)
-  const int l16 = fft_index(lane & 15), qid = lane >> 4, qbase = lane & 48;
-  const int kbase = N2 * bitrev4(l16);                       // first bin of this lane in the block layout
-  const int lane_mirror = qbase | fft_index(15 - l16);       // holds bins L - k for k2 != 0
-  const int lane_neg = qbase | fft_index(bitrev4((16 - bitrev4(l16)) & 15));  // holds bin (L - k) mod L for k2 == 0
-  float2 *wsq = lds2 + C::OFF_WS + (C::WSQ ? (wid * 4 + qid) : wid) * L;  // linear workspace (L samples)
+  // (l16, qid: index inside the transform and transform of the wave - 16 lanes / four transforms except on the longest grids)
+  const int l16 = fft_index_n<LPF>(lane & (LPF - 1)), qid = lane / LPF, qbase = lane & (64 - LPF);
+  const int kbase = N2 * bitrev_n<LPF>(l16);                    // first bin of this lane in the block layout
+  const int lane_mirror = qbase | fft_index_n<LPF>(LPF - 1 - l16);  // holds bins L - k for k2 != 0
+  const int lane_neg = qbase | fft_index_n<LPF>(bitrev_n<LPF>((LPF - bitrev_n<LPF>(l16)) & (LPF - 1)));  // bin (L - k) mod L, k2 == 0
+  float2 *wsq = lds2 + C::OFF_WS + (C::WSQ ? (wid * GPW + qid) : wid) * L;  // linear workspace (L samples)
 
   // Translated epochs (alpha = 0: every fit of the reference): scene pixel (u, v) samples h at (u + iyc + fyc, v + ixc + fxc)
   // with ONE integer offset and ONE pair of fractional weights for the whole epoch, so scene rows u0, u0 + 1 read the
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   const float t_ixf = floorf(t_nsx), t_iyf = floorf(t_nsy);
   const float fxc = t_nsx - t_ixf, fyc = t_nsy - t_iyf;
   const int ixc = (int)t_ixf, iyc = (int)t_iyf;
-  float *hrow = C::WSQ ? (float *)wsq : (float *)(lds2 + C::OFF_HROW) + (wid * 4 + qid) * 3 * N;
+  float *hrow = C::WSQ ? (float *)wsq : (float *)(lds2 + C::OFF_HROW) + (wid * GPW + qid) * 3 * N;
   constexpr int HMASK = ((N & (N - 1)) == 0) ? N - 1 : -1;
   const int hskew = ((N & (N - 1)) == 0) ? 16 * qid : 0;  // the four quarters of a wave on different banks
   auto stage_rows = [&](int u0, bool active) {
@@ -175,16 +179,16 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const float *src = A.h + (size_t)min(max(u0 + iyc + r, 0), N - 1) * N;
-        if constexpr (N % 64 == 0) {
+        if constexpr (N % (4 * LPF) == 0) {
 #pragma unroll
-          for (int t = 0; t < N / 64; ++t) {
-            const int x = 4 * (l16 + 16 * t);
+          for (int t = 0; t < N / (4 * LPF); ++t) {
+            const int x = 4 * (l16 + LPF * t);
             *(float4 *)&hrow[r * N + ((x + hskew) & HMASK)] = *(const float4 *)&src[x];
           }
         } else {
 #pragma unroll
-          for (int t = 0; t < N / 16; ++t) {
-            const int x = l16 + 16 * t;
+          for (int t = 0; t < N / LPF; ++t) {
+            const int x = l16 + LPF * t;
             hrow[r * N + ((x + hskew) & HMASK)] = src[x];
           }
         }
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   auto load_column = [&](float2 (&x)[N2], int kc, bool active, int row_off) {
 #pragma unroll
     for (int n2 = 0; n2 < N2; ++n2) {
-      const int r = l16 + 16 * n2 - row_off;
+      const int r = l16 + LPF * n2 - row_off;
       float2 v = make_float2(0.f, 0.f);
       if (active && r >= 0 && r < N) {
         v = SPEC[r * KH + kc];
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   auto store_column = [&](const float2 (&x)[N2], int kc, bool active, int row_off) {
 #pragma unroll
     for (int n2 = 0; n2 < N2; ++n2) {
-      const int r = l16 + 16 * n2 - row_off;
+      const int r = l16 + LPF * n2 - row_off;
       if (active && r >= 0 && r < N) {
         if (kc == 0) {
           SPEC[r * KH] = make_float2(x[n2].x, 0.f);
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   };
 
   // ---- phase A: scene rows, two real rows per complex FFT ---------------------------------------
-  for (int rp0 = wid * 4; rp0 < N / 2; rp0 += C::NW * 4) {
+  for (int rp0 = wid * GPW; rp0 < N / 2; rp0 += C::NW * GPW) {
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
     float2 x[N2];
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     LC_JSTAMP(10);
 #pragma unroll
     for (int n2 = 0; n2 < N2; ++n2) {
-      const int v = l16 + 16 * n2;
+      const int v = l16 + LPF * n2;
       float2 z = make_float2(0.f, 0.f);
       if constexpr (AUX) {
         if (active && v < N) {
@@ -345,8 +349,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         if (i < M && active) {
           const float ay0 = amp[i] * GY[i * N + u0], ay1 = amp[i] * GY[i * N + u0 + 1];
 #pragma unroll
-          for (int n2 = 0; n2 < N / 16; ++n2) {
-            const float gx = GX[i * N + l16 + 16 * n2];
+          for (int n2 = 0; n2 < N / LPF; ++n2) {
+            const float gx = GX[i * N + l16 + LPF * n2];
             x[n2].x = fmaf(ay0, gx, x[n2].x);
             x[n2].y = fmaf(ay1, gx, x[n2].y);
           }
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       }
     }
     LC_JSTAMP(11);
-    quarter_fft_fwd<L>(x, l16, TW);
+    group_fft_fwd<L, LPF>(x, l16, TW);
     LC_JSTAMP(12);
     unpack_rows(x, u0, active);
     LC_JSTAMP(13);
@@ -365,13 +369,13 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     if (A.mode == 4) {  // forward column transforms only: the spectrum of scene_in[e], transposed, divided by L^2
       float2 *So = A.St_out + (size_t)e * KH * L;
       const float sc = 1.0f / ((float)L * (float)L);
-      for (int kc0 = wid * 4; kc0 < NCOL; kc0 += C::NW * 4) {
+      for (int kc0 = wid * GPW; kc0 < NCOL; kc0 += C::NW * GPW) {
         const int kc = kc0 + qid;
         const bool active = kc < NCOL;
         const int kcs = active ? kc : 1;
         float2 x[N2];
         load_column(x, kcs, active, 0);
-        quarter_fft_fwd<L>(x, l16, TW);
+        group_fft_fwd<L, LPF>(x, l16, TW);
         if (kcs == 0) {  // packed pair: column 0 = Hermitian part, column L/2 = anti-Hermitian part / i
 #pragma unroll
           for (int k2 = 0; k2 < N2; ++k2) {
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   }
   // ---- phase B: columns: FFT, multiply by the PSF spectrum, inverse FFT, keep the 'same' window ----
   const float2 *Ste = A.St + (size_t)e * KH * L;
-  for (int kc0 = wid * 4; kc0 < NCOL; kc0 += C::NW * 4) {
+  for (int kc0 = wid * GPW; kc0 < NCOL; kc0 += C::NW * GPW) {
     const int kc = kc0 + qid;
     const bool active = kc < NCOL;
     const int kcs = active ? kc : 1;
@@ -398,24 +402,24 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 #pragma unroll
     for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)kcs * L + kbase + k2];
     load_column(x, kcs, active, 0);
-    quarter_fft_fwd<L>(x, l16, TW);
+    group_fft_fwd<L, LPF>(x, l16, TW);
     times_spectrum(x, sv, Ste, kcs, false);
-    quarter_fft_inv<L>(x, l16, TW);
+    group_fft_inv<L, LPF>(x, l16, TW);
     store_column(x, kcs, active, CREF);
   }
   __syncthreads();
   LC_JSTAMP(3);
   if constexpr (AUX) {  // mode 3: inverse rows, 'same' window of the convolution at full resolution
     float *co = A.conv_out + (size_t)e * N * N;
-    for (int rp0 = wid * 4; rp0 < N / 2; rp0 += C::NW * 4) {
+    for (int rp0 = wid * GPW; rp0 < N / 2; rp0 += C::NW * GPW) {
       const int rp = rp0 + qid, u0 = 2 * rp;
       const bool active = rp < N / 2;
       float2 x[N2];
       pack_rows(x, u0, active);
-      quarter_fft_inv<L>(x, l16, TW);
+      group_fft_inv<L, LPF>(x, l16, TW);
 #pragma unroll
       for (int n2 = 0; n2 < N2; ++n2) {
-        const int v = l16 + 16 * n2 - CREF;
+        const int v = l16 + LPF * n2 - CREF;
         if (active && v >= 0 && v < N) {
           co[u0 * N + v] = x[n2].x;
           co[(u0 + 1) * N + v] = x[n2].y;
@@ -427,28 +431,28 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   // ---- phase C: inverse rows -> model, residuals; forward rows of the up-sampled weighted residual ----
   float acc_chi = 0.f, acc_mean = 0.f, acc_fis = 0.f;
   const float *de = A.data + (size_t)e * n * n, *we = A.wgt + (size_t)e * n * n;
-  for (int rp0 = wid * 4; rp0 < N / 2; rp0 += C::NW * 4) {
+  for (int rp0 = wid * GPW; rp0 < N / 2; rp0 += C::NW * GPW) {
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
     float2 x[N2];
     pack_rows(x, u0, active);
-    quarter_fft_inv<L>(x, l16, TW);
-    constexpr int NTURN = C::WSQ ? 1 : 4;
+    group_fft_inv<L, LPF>(x, l16, TW);
+    constexpr int NTURN = C::WSQ ? 1 : GPW;
 #pragma unroll
     for (int turn = 0; turn < NTURN; ++turn) {
     const bool mine = C::WSQ || (qid == turn);  // with a per-wave buffer the quarters take turns
     if (!C::WSQ) wave_lds_sync();
     if (mine) {
 #pragma unroll
-      for (int n2 = 0; n2 < N2; ++n2) wsq[l16 + 16 * n2] = x[n2];  // linear order for the data-space step
+      for (int n2 = 0; n2 < N2; ++n2) wsq[l16 + LPF * n2] = x[n2];  // linear order for the data-space step
     }
     wave_lds_sync();
-    constexpr int NDP = (n + 15) / 16;  // data pixels of this quarter's row(s) per lane
+    constexpr int NDP = (n + LPF - 1) / LPF;  // data pixels of this quarter's row(s) per lane
     float rw0[NDP], rw1[NDP];
 #pragma unroll
     for (int t = 0; t < NDP; ++t) {
       rw0[t] = rw1[t] = 0.f;
-      const int jd = l16 + 16 * t;
+      const int jd = l16 + LPF * t;
       if (mine && active && jd < n) {
         if (SS == 2) {
           const int I = rp;
@@ -493,12 +497,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       wave_lds_sync();
       if (mine) {
 #pragma unroll
-        for (int n2 = 0; n2 < N2; ++n2) wsq[l16 + 16 * n2] = make_float2(0.f, 0.f);
+        for (int n2 = 0; n2 < N2; ++n2) wsq[l16 + LPF * n2] = make_float2(0.f, 0.f);
       }
       wave_lds_sync();
 #pragma unroll
       for (int t = 0; t < NDP; ++t) {
-        const int jd = l16 + 16 * t;
+        const int jd = l16 + LPF * t;
         if (mine && active && jd < n) {
           if (SS == 2) {
             wsq[2 * jd + CREF] = make_float2(rw0[t], rw0[t]);
@@ -511,12 +515,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       wave_lds_sync();
       if (mine) {
 #pragma unroll
-        for (int n2 = 0; n2 < N2; ++n2) x[n2] = wsq[l16 + 16 * n2];
+        for (int n2 = 0; n2 < N2; ++n2) x[n2] = wsq[l16 + LPF * n2];
       }
     }
     }  // turns
     if (A.mode == 0) {
-      quarter_fft_fwd<L>(x, l16, TW);
+      group_fft_fwd<L, LPF>(x, l16, TW);
       unpack_rows(x, u0, active);
     }
     wave_lds_sync();
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   __syncthreads();
   LC_JSTAMP(4);
   // ---- phase B': adjoint columns (rows sit at offset CREF), multiply by conj(spectrum) ------------
-  for (int kc0 = wid * 4; kc0 < NCOL; kc0 += C::NW * 4) {
+  for (int kc0 = wid * GPW; kc0 < NCOL; kc0 += C::NW * GPW) {
     const int kc = kc0 + qid;
     const bool active = kc < NCOL;
     const int kcs = active ? kc : 1;
@@ -544,9 +548,9 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 #pragma unroll
     for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)kcs * L + kbase + k2];
     load_column(x, kcs, active, CREF);
-    quarter_fft_fwd<L>(x, l16, TW);
+    group_fft_fwd<L, LPF>(x, l16, TW);
     times_spectrum(x, sv, Ste, kcs, true);
-    quarter_fft_inv<L>(x, l16, TW);
+    group_fft_inv<L, LPF>(x, l16, TW);
     store_column(x, kcs, active, 0);
   }
   __syncthreads();
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   // KH float2 of spectrum row u), so the T^T gather below reads LDS, not global memory
   float *GSl = (float *)SPEC;
   constexpr int GST = 2 * KH;
-  for (int rp0 = wid * 4; rp0 < N / 2; rp0 += C::NW * 4) {
+  for (int rp0 = wid * GPW; rp0 < N / 2; rp0 += C::NW * GPW) {
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
     float2 x[N2];
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       stage_rows(u0, active);
     }
     pack_rows(x, u0, active);
-    quarter_fft_inv<L>(x, l16, TW);
+    group_fft_inv<L, LPF>(x, l16, TW);
     if (use_h && translated) wave_lds_sync();
     // point sources: per source the row factors of the quarter's two rows, then one LDS read and seven multiply-adds
     // per pixel pair
@@ -580,8 +584,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         const float gy0 = GY[i * N + u0], gy1 = GY[i * N + u0 + 1];
         const float dgy0 = gy0 * (((float)u0 - Yi) * inv_s2), dgy1 = gy1 * (((float)(u0 + 1) - Yi) * inv_s2);
 #pragma unroll
-        for (int n2 = 0; n2 < N / 16; ++n2) {
-          const int v = l16 + 16 * n2;
+        for (int n2 = 0; n2 < N / LPF; ++n2) {
+          const int v = l16 + LPF * n2;
           const float2 g = x[n2];
           const float gx = GX[i * N + v], dgx = gx * (((float)v - Xi) * inv_s2);
           const float gg = g.x * gy0 + g.y * gy1;
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     }
 #pragma unroll
     for (int n2 = 0; n2 < N2; ++n2) {
-      const int v = l16 + 16 * n2;
+      const int v = l16 + LPF * n2;
       if (active && v < N) {
         const float2 g = x[n2];
         if (use_h && translated) {
