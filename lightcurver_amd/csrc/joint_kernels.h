@@ -96,7 +96,13 @@ struct JointCfg {
   // separable Gaussian factors of the point sources: GX[i][N], GY[i][N] floats, then their centres X_i, Y_i
   static constexpr int OFF_TAB = OFF_HROW + SZ_HROW;
   static constexpr int SZ_TAB = kMaxSources * N + kMaxSources;
-  static constexpr int LDS_BYTES = (OFF_TAB + SZ_TAB) * 8;
+  // binned rows (SS = 2): the inverse row transforms of the model and the forward ones of the residual run at the DATA
+  // resolution, length L / 2 (joint_epoch_kernel, phase C): its twiddles, and phi[k] = exp(2 pi i k CREF / L) (1 +
+  // exp(2 pi i k / L)), the transfer function of "shift by CREF, add neighbours" that precedes the decimation
+  static constexpr bool FOLD = (SS == 2) && ((L / 2) % LPF == 0);
+  static constexpr int OFF_TWH = OFF_TAB + SZ_TAB;
+  static constexpr int SZ_TWH = FOLD ? (L / 2 + L / 2 + 1) : 0;
+  static constexpr int LDS_BYTES = (OFF_TWH + SZ_TWH) * 8;
   static_assert(!WSQ || 2 * L >= 3 * N, "row buffer holds three rows of h");
   static constexpr int CREF = (N - 1) / 2;
   static_assert(N % 2 == 0, "row pairs");
@@ -124,6 +130,14 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 
   LC_JSTAMP(0);
   for (int k = tid; k < L; k += C::NTHR) TW[k] = A.twid[k];
+  if constexpr (C::FOLD) {
+    float2 *TWH = lds2 + C::OFF_TWH, *PHI = TWH + L / 2;
+    for (int k = tid; k <= L / 2; k += C::NTHR) {
+      if (k < L / 2) TWH[k] = A.twid[2 * k];
+      const float2 sh = A.twid[(k * CREF) % L], on = A.twid[k];  // exp(-2 pi i k CREF / L), exp(-2 pi i k / L)
+      PHI[k] = cmul(make_float2(sh.x, -sh.y), make_float2(1.f + on.x, -on.y));
+    }
+  }
   // separable Gaussian factors of every point source (full grid, as the oracle evaluates them), in LDS: the scene and
   // gradient loops read them per pixel, and a global table put a load latency into every one of those reads
   {
@@ -431,6 +445,95 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   // ---- phase C: inverse rows -> model, residuals; forward rows of the up-sampled weighted residual ----
   float acc_chi = 0.f, acc_mean = 0.f, acc_fis = 0.f;
   const float *de = A.data + (size_t)e * n * n, *we = A.wgt + (size_t)e * n * n;
+  if constexpr (C::FOLD) {
+    // Binned rows.  Data row I is the sum of scene rows 2 I, 2 I + 1 (add their half spectra), shifted by CREF, added to
+    // its right neighbour and decimated by two along x: in Fourier space a multiplication by phi and the fold
+    // D[k'] = G[k'] + G[k' + L/2].  So ONE transform of length L / 2 per pair of DATA rows returns the model at the data
+    // resolution (half as many transforms as scene row pairs, half as long), the residuals are formed in registers, and
+    // their spectrum, periodically extended and multiplied by conj(phi), is the spectrum of the up-sampled residual rows.
+    constexpr int LH = L / 2, N2H = LH / LPF, KQ = LH / 2;
+    const float2 *TWH = lds2 + C::OFF_TWH, *PHI = TWH + LH;
+    const int kbh = N2H * bitrev_n<LPF>(l16);
+    auto folded = [&](int r0, int m) {  // D[m], 0 <= m <= KQ, of the data row made of scene rows r0, r0 + 1
+      const float2 a0 = SPEC[r0 * KH + m], a1 = SPEC[(r0 + 1) * KH + m];
+      const float2 b0 = SPEC[r0 * KH + LH - m], b1 = SPEC[(r0 + 1) * KH + LH - m];
+      const float2 ga = cmul(make_float2(a0.x + a1.x, a0.y + a1.y), PHI[m]);
+      const float2 gb = cmul(make_float2(b0.x + b1.x, b0.y + b1.y), PHI[LH - m]);
+      return make_float2(ga.x + gb.x, ga.y - gb.y);
+    };
+    for (int t0 = wid * GPW; t0 < n / 2; t0 += C::NW * GPW) {
+      const int t = t0 + qid, I0 = 2 * t, I1 = I0 + 1;
+      const bool active = t < n / 2;
+      float2 x[N2H];
+#pragma unroll
+      for (int k2 = 0; k2 < N2H; ++k2) {
+        const int k = kbh + k2, m = (k <= KQ) ? k : LH - k;
+        float2 z = make_float2(0.f, 0.f);
+        if (active) {
+          float2 d0 = folded(2 * I0, m), d1 = folded(2 * I1, m);
+          if (k > KQ) {  // Hermitian extension
+            d0.y = -d0.y;
+            d1.y = -d1.y;
+          }
+          z = make_float2(d0.x - d1.y, d0.y + d1.x);  // row I0 + i row I1
+        }
+        x[k2] = z;
+      }
+      group_fft_inv<LH, LPF>(x, l16, TWH);
+#pragma unroll
+      for (int n2 = 0; n2 < N2H; ++n2) {
+        const int jd = l16 + LPF * n2;
+        float2 rw = make_float2(0.f, 0.f);
+        if (active && jd < n) {
+          const float2 y = x[n2];
+          const float w0 = we[I0 * n + jd], w1 = we[I1 * n + jd];
+          if (A.mode == 2) {
+            acc_fis = fmaf(w0 * y.x, y.x, acc_fis);
+            acc_fis = fmaf(w1 * y.y, y.y, acc_fis);
+          } else {
+            const float m0 = y.x + meane, m1 = y.y + meane;
+            const float r0 = m0 - de[I0 * n + jd], r1 = m1 - de[I1 * n + jd];
+            rw = make_float2(w0 * r0, w1 * r1);
+            acc_chi = fmaf(rw.x, r0, acc_chi);
+            acc_chi = fmaf(rw.y, r1, acc_chi);
+            acc_mean += rw.x + rw.y;
+            if (A.model_out) {
+              A.model_out[(size_t)e * n * n + I0 * n + jd] = m0;
+              A.model_out[(size_t)e * n * n + I1 * n + jd] = m1;
+            }
+          }
+        }
+        x[n2] = rw;
+      }
+      if (A.mode == 0) {
+        group_fft_fwd<LH, LPF>(x, l16, TWH);
+#pragma unroll
+        for (int k2 = 0; k2 < N2H; ++k2) {
+          const float2 zk = x[k2];
+          const float2 zc = (k2 == 0) ? shfl2(x[0], lane_neg) : shfl2(x[(N2H - k2) % N2H], lane_mirror);
+          const int k = kbh + k2;
+          if (active && k <= KQ) {
+            const float2 R0 = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));   // spectrum of row I0's residual
+            const float2 R1 = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));  // and of row I1's
+            // scene rows 2 I, 2 I + 1 carry the same up-sampled row: columns k and LH - k of the periodic extension
+            const float2 pa = PHI[k], pb = PHI[LH - k];
+            const float2 u0a = cmul_conj(R0, pa), u1a = cmul_conj(R1, pa);
+            const float2 u0b = cmul_conj(make_float2(R0.x, -R0.y), pb), u1b = cmul_conj(make_float2(R1.x, -R1.y), pb);
+            SPEC[(2 * I0) * KH + k] = u0a;
+            SPEC[(2 * I0 + 1) * KH + k] = u0a;
+            SPEC[(2 * I1) * KH + k] = u1a;
+            SPEC[(2 * I1 + 1) * KH + k] = u1a;
+            if (k != KQ) {
+              SPEC[(2 * I0) * KH + LH - k] = u0b;
+              SPEC[(2 * I0 + 1) * KH + LH - k] = u0b;
+              SPEC[(2 * I1) * KH + LH - k] = u1b;
+              SPEC[(2 * I1 + 1) * KH + LH - k] = u1b;
+            }
+          }
+        }
+      }
+    }
+  } else {
   for (int rp0 = wid * GPW; rp0 < N / 2; rp0 += C::NW * GPW) {
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
@@ -524,6 +627,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       unpack_rows(x, u0, active);
     }
     wave_lds_sync();
+  }
   }
   if (A.mode != 0) {
     const float v0 = wave_sum((A.mode == 2) ? acc_fis : acc_chi);
