@@ -188,12 +188,48 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   float *hrow = C::WSQ ? (float *)wsq : (float *)(lds2 + C::OFF_HROW) + (wid * GPW + qid) * 3 * N;
   constexpr int HMASK = ((N & (N - 1)) == 0) ? N - 1 : -1;
   const int hskew = ((N & (N - 1)) == 0) ? 16 * qid : 0;  // the four quarters of a wave on different banks
+  // The rows travel in two steps so that a sweep can request the rows of the NEXT one before its own transforms and
+  // find them in registers afterwards (fetch_rows), then drop them into LDS once the readers of the previous contents
+  // are done (put_rows): the load latency hides behind a whole sweep.
+  constexpr bool HPIPE = (N % (4 * LPF) == 0);
+  constexpr int NPRE = HPIPE ? 3 * (N / (4 * LPF)) : 1;
+  auto fetch_rows = [&](int u0, bool active, float4 (&pre)[NPRE]) {
+    if constexpr (HPIPE) {  // (the row index is clamped: an idle group loads valid rows it never uses)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float *src = A.h + (size_t)min(max(u0 + iyc + r, 0), N - 1) * N;
+#pragma unroll
+        for (int t = 0; t < N / (4 * LPF); ++t) pre[r * (N / (4 * LPF)) + t] = *(const float4 *)&src[4 * (l16 + LPF * t)];
+      }
+    }
+  };
+  auto put_rows = [&](int u0, bool active, const float4 (&pre)[NPRE]) {
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if constexpr (HPIPE) {
+#pragma unroll
+          for (int t = 0; t < N / (4 * LPF); ++t) {
+            const int x = 4 * (l16 + LPF * t);
+            *(float4 *)&hrow[r * N + ((x + hskew) & HMASK)] = pre[r * (N / (4 * LPF)) + t];
+          }
+        } else {
+          const float *src = A.h + (size_t)min(max(u0 + iyc + r, 0), N - 1) * N;
+#pragma unroll
+          for (int t = 0; t < N / LPF; ++t) {
+            const int x = l16 + LPF * t;
+            hrow[r * N + ((x + hskew) & HMASK)] = src[x];
+          }
+        }
+      }
+    }
+  };
   auto stage_rows = [&](int u0, bool active) {
     if (active) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const float *src = A.h + (size_t)min(max(u0 + iyc + r, 0), N - 1) * N;
-        if constexpr (N % (4 * LPF) == 0) {
+        if constexpr (HPIPE) {
 #pragma unroll
           for (int t = 0; t < N / (4 * LPF); ++t) {
             const int x = 4 * (l16 + LPF * t);
@@ -316,6 +352,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   };
 
   // ---- phase A: scene rows, two real rows per complex FFT ---------------------------------------
+  float4 hpre[NPRE];
+#pragma unroll
+  for (int q = 0; q < NPRE; ++q) hpre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (!AUX) {
+    if (use_h && translated) fetch_rows(2 * (wid * GPW + qid), wid * GPW + qid < N / 2, hpre);
+  }
   for (int rp0 = wid * GPW; rp0 < N / 2; rp0 += C::NW * GPW) {
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
@@ -324,8 +366,10 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     if constexpr (!AUX) {
       if (use_h && translated) {
         wave_lds_sync();  // the previous sweep's readers are done with the buffer
-        stage_rows(u0, active);
+        put_rows(u0, active, hpre);
         wave_lds_sync();
+        const int rpn = rp + C::NW * GPW;
+        if (rp0 + C::NW * GPW < N / 2) fetch_rows(2 * rpn, rpn < N / 2, hpre);
       }
     }
     LC_JSTAMP(10);
@@ -672,7 +716,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
     float2 x[N2];
-    if (use_h && translated) {
+    if (use_h && translated) {  // (no registers to spare here for rows in flight across a sweep: fetched and stored at once)
       wave_lds_sync();
       stage_rows(u0, active);
     }
@@ -851,6 +895,13 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       if (kx == N - 1) vhi = N - 1;
       if (ky == 0) ulo = 0;
       if (ky == N - 1) uhi = N - 1;
+      if (translated) {
+        // exact candidate ranges: scene pixel (u, v) touches rows clamp(u + iyc), clamp(u + iyc + 1) and the same in x
+        ulo = (ky == 0) ? 0 : ky - iyc - 1;
+        uhi = (ky == N - 1) ? N - 1 : ky - iyc;
+        vlo = (kx == 0) ? 0 : kx - ixc - 1;
+        vhi = (kx == N - 1) ? N - 1 : kx - ixc;
+      }
       vlo = max(vlo, 0);
       vhi = min(vhi, N - 1);
       ulo = max(ulo, 0);
