@@ -98,9 +98,9 @@ int d2h(lc_joint *j, void *dst, const void *src, size_t bytes) {
   return LC_OK;
 }
 
-template <int N, int SS, int L, int PX, int NW>
+template <int N, int SS, int L, int PX, int NW, int LPF = 16>
 JointVariant make_jv() {
-  typedef JointCfg<N, SS, L, NW> C;
+  typedef JointCfg<N, SS, L, NW, false, LPF> C;
   return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, joint_update_kernel<N, PX>, N * N / PX,
                       (int)(StarletLds<N>::FLOATS * sizeof(float)), false, joint_epoch_kernel<C, true>};
 }
@@ -126,7 +126,8 @@ const JointVariant *find_jv(int n, int ss) {
       make_jv<32, 2, 48, 4, 16>(),    // n = 16, ss = 2
       make_jv<48, 2, 96, 4, 8>(),     // n = 24 (default stamp_size_stars)
       make_jv<64, 2, 96, 8, 16>(),    // n = 32 (default stamp_size_ROI)
-      make_jv<128, 2, 192, 16, 8>(),  // n = 64 (C4)
+      // n = 64 (C4); 16 waves with 32-lane transforms (4 waves per SIMD, 128 registers, 34 spilled) measured 2 % slower
+      make_jv<128, 2, 192, 16, 8>(),
       // n = 128 (C5): transforms over 32 lanes (12 registers per lane like the n = 64 kernel; at 16 lanes the 24-register
       // transforms spilled 200+ registers, and 4 waves with 436 registers each measured 1.23 x slower than that)
       make_jv_gm<256, 2, 384, 8, 32>(),

@@ -83,7 +83,7 @@ struct JointCfg {
   static constexpr int OFF_WS = OFF_SPEC + SZ_SPEC;
   // linear row buffer(s) for the data-space step: one per quarter-wave when LDS allows (N <= 64), else one per
   // wave that the four quarters use in turn
-  static constexpr bool WSQ = ((N <= 128) && (NW_ <= 8)) || GSPEC_;
+  static constexpr bool WSQ = ((N <= 128) && (NW_ * GPW <= 32)) || GSPEC_;
   static constexpr int SZ_WS = NW * (WSQ ? GPW : 1) * L;
   static constexpr int OFF_TW = OFF_WS + SZ_WS;
   static constexpr int SZ_TW = L;
@@ -95,11 +95,13 @@ struct JointCfg {
   static constexpr int SZ_HROW = WSQ ? 0 : NW * GPW * ((3 * N + 1) / 2);
   // separable Gaussian factors of the point sources: GX[i][N], GY[i][N] floats, then their centres X_i, Y_i
   static constexpr int OFF_TAB = OFF_HROW + SZ_HROW;
-  static constexpr int SZ_TAB = kMaxSources * N + kMaxSources;
+  static constexpr int SZ_TAB = kMaxSources * N + kMaxSources + (kMaxSources + 1) / 2;  // + the fluxes of the epoch
   // binned rows (SS = 2): the inverse row transforms of the model and the forward ones of the residual run at the DATA
   // resolution, length L / 2 (joint_epoch_kernel, phase C): its twiddles, and phi[k] = exp(2 pi i k CREF / L) (1 +
   // exp(2 pi i k / L)), the transfer function of "shift by CREF, add neighbours" that precedes the decimation
   static constexpr bool FOLD = (SS == 2) && ((L / 2) % LPF == 0);
+  // scene phase: next sweep's rows of h held in registers across a sweep (needs 24 registers: not at 4 waves per SIMD)
+  static constexpr bool ROWPIPE = (NW_ <= 8);
   static constexpr int OFF_TWH = OFF_TAB + SZ_TAB;
   static constexpr int SZ_TWH = FOLD ? (L / 2 + L / 2 + 1) : 0;
   static constexpr int LDS_BYTES = (OFF_TWH + SZ_TWH) * 8;
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   const float sdx = SS * dxe, sdy = SS * dye;
   const float meane = A.mean[e];
   float *GX = (float *)(lds2 + C::OFF_TAB), *GY = GX + kMaxSources * N, *PSX = GY + kMaxSources * N, *PSY = PSX + kMaxSources;
+  float *AMPL = PSY + kMaxSources;  // flux of source i in this epoch (mode 2: indicator of the source whose Fisher term is wanted)
   constexpr float inv_s2 = 1.0f / (kSigmaG * kSigmaG);
 
   LC_JSTAMP(0);
@@ -155,10 +158,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       }
     }
   }
+  if (tid < kMaxSources) AMPL[tid] = (tid < M) ? ((A.mode == 2) ? ((tid == A.isrc) ? 1.f : 0.f) : A.a[e * M + tid]) : 0.f;
+  {  // per-wave reduction slots: the gradient sums of the point sources are accumulated there sweep by sweep
+    constexpr int NQ0 = 4 + 3 * kMaxSources;
+    if (lane < NQ0) RED[wid * NQ0 + lane] = 0.f;
+  }
   __syncthreads();
-  float amp[kMaxSources];
-#pragma unroll
-  for (int i = 0; i < kMaxSources; ++i) amp[i] = (i < M) ? ((A.mode == 2) ? ((i == A.isrc) ? 1.f : 0.f) : A.a[e * M + i]) : 0.f;
   const bool use_h = A.h_active && A.mode != 2;
 
   LC_JSTAMP(1);
@@ -355,24 +360,27 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   float4 hpre[NPRE];
 #pragma unroll
   for (int q = 0; q < NPRE; ++q) hpre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (!AUX) {
+  if constexpr (!AUX && C::ROWPIPE) {
     if (use_h && translated) fetch_rows(2 * (wid * GPW + qid), wid * GPW + qid < N / 2, hpre);
   }
   for (int rp0 = wid * GPW; rp0 < N / 2; rp0 += C::NW * GPW) {
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
     float2 x[N2];
-    LC_JSTAMP(9);
     if constexpr (!AUX) {
       if (use_h && translated) {
         wave_lds_sync();  // the previous sweep's readers are done with the buffer
-        put_rows(u0, active, hpre);
-        wave_lds_sync();
-        const int rpn = rp + C::NW * GPW;
-        if (rp0 + C::NW * GPW < N / 2) fetch_rows(2 * rpn, rpn < N / 2, hpre);
+        if constexpr (C::ROWPIPE) {
+          put_rows(u0, active, hpre);
+          wave_lds_sync();
+          const int rpn = rp + C::NW * GPW;
+          if (rp0 + C::NW * GPW < N / 2) fetch_rows(2 * rpn, rpn < N / 2, hpre);
+        } else {
+          stage_rows(u0, active);
+          wave_lds_sync();
+        }
       }
     }
-    LC_JSTAMP(10);
 #pragma unroll
     for (int n2 = 0; n2 < N2; ++n2) {
       const int v = l16 + LPF * n2;
@@ -405,7 +413,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 #pragma unroll
       for (int i = 0; i < kMaxSources; ++i) {
         if (i < M && active) {
-          const float ay0 = amp[i] * GY[i * N + u0], ay1 = amp[i] * GY[i * N + u0 + 1];
+          const float ai = AMPL[i];
+          const float ay0 = ai * GY[i * N + u0], ay1 = ai * GY[i * N + u0 + 1];
 #pragma unroll
           for (int n2 = 0; n2 < N / LPF; ++n2) {
             const float gx = GX[i * N + l16 + LPF * n2];
@@ -415,11 +424,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         }
       }
     }
-    LC_JSTAMP(11);
     group_fft_fwd<L, LPF>(x, l16, TW);
-    LC_JSTAMP(12);
     unpack_rows(x, u0, active);
-    LC_JSTAMP(13);
   }
   __syncthreads();
   LC_JSTAMP(2);
@@ -457,13 +463,19 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     const bool active = kc < NCOL;
     const int kcs = active ? kc : 1;
     float2 x[N2], sv[N2];
+    LC_JSTAMP(9);
 #pragma unroll
     for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)kcs * L + kbase + k2];
     load_column(x, kcs, active, 0);
+    LC_JSTAMP(10);
     group_fft_fwd<L, LPF>(x, l16, TW);
+    LC_JSTAMP(11);
     times_spectrum(x, sv, Ste, kcs, false);
+    LC_JSTAMP(12);
     group_fft_inv<L, LPF>(x, l16, TW);
+    LC_JSTAMP(13);
     store_column(x, kcs, active, CREF);
+    LC_JSTAMP(14);
   }
   __syncthreads();
   LC_JSTAMP(3);
@@ -704,9 +716,6 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   __syncthreads();
   LC_JSTAMP(5);
   // ---- phase C': adjoint inverse rows -> scene gradient rows; parameter gradients ------------------
-  float pa[kMaxSources], pX[kMaxSources], pY[kMaxSources];
-#pragma unroll
-  for (int i = 0; i < kMaxSources; ++i) pa[i] = pX[i] = pY[i] = 0.f;
   float acc_dx = 0.f, acc_dy = 0.f, acc_hx = 0.f, acc_hy = 0.f;
   // scene-gradient rows overwrite the spectrum rows they were computed from (row u: N floats inside the
   // KH float2 of spectrum row u), so the T^T gather below reads LDS, not global memory
@@ -725,21 +734,34 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     if (use_h && translated) wave_lds_sync();
     // point sources: per source the row factors of the quarter's two rows, then one LDS read and seven multiply-adds
     // per pixel pair
+    // (their three sums per source leave the registers at the end of every sweep: lanes by shuffles, into the wave's slot)
 #pragma unroll
     for (int i = 0; i < kMaxSources; ++i) {
-      if (i < M && active) {
-        const float Xi = PSX[i], Yi = PSY[i];
-        const float gy0 = GY[i * N + u0], gy1 = GY[i * N + u0 + 1];
-        const float dgy0 = gy0 * (((float)u0 - Yi) * inv_s2), dgy1 = gy1 * (((float)(u0 + 1) - Yi) * inv_s2);
+      if (i < M) {
+        float pa = 0.f, pX = 0.f, pY = 0.f;
+        if (active) {
+          const float Xi = PSX[i], Yi = PSY[i];
+          const float gy0 = GY[i * N + u0], gy1 = GY[i * N + u0 + 1];
+          const float dgy0 = gy0 * (((float)u0 - Yi) * inv_s2), dgy1 = gy1 * (((float)(u0 + 1) - Yi) * inv_s2);
 #pragma unroll
-        for (int n2 = 0; n2 < N / LPF; ++n2) {
-          const int v = l16 + LPF * n2;
-          const float2 g = x[n2];
-          const float gx = GX[i * N + v], dgx = gx * (((float)v - Xi) * inv_s2);
-          const float gg = g.x * gy0 + g.y * gy1;
-          pa[i] = fmaf(gg, gx, pa[i]);
-          pX[i] = fmaf(gg, dgx, pX[i]);
-          pY[i] = fmaf(g.x * dgy0 + g.y * dgy1, gx, pY[i]);
+          for (int n2 = 0; n2 < N / LPF; ++n2) {
+            const int v = l16 + LPF * n2;
+            const float2 g = x[n2];
+            const float gx = GX[i * N + v], dgx = gx * (((float)v - Xi) * inv_s2);
+            const float gg = g.x * gy0 + g.y * gy1;
+            pa = fmaf(gg, gx, pa);
+            pX = fmaf(gg, dgx, pX);
+            pY = fmaf(g.x * dgy0 + g.y * dgy1, gx, pY);
+          }
+        }
+        pa = wave_sum(pa);
+        pX = wave_sum(pX);
+        pY = wave_sum(pY);
+        if (lane == 0) {
+          float *slot = RED + wid * (4 + 3 * kMaxSources) + 4 + 3 * i;
+          slot[0] += pa;
+          slot[1] += pX;
+          slot[2] += pY;
         }
       }
     }
@@ -782,23 +804,14 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   // reductions: lanes by shuffles, the four waves in fixed order
   {
     constexpr int NQ = 4 + 3 * kMaxSources;
-    float vals[NQ];
-    vals[0] = acc_chi;
-    vals[1] = acc_mean;
-    vals[2] = acc_dx;
-    vals[3] = acc_dy;
-#pragma unroll
-    for (int i = 0; i < kMaxSources; ++i) {
-      vals[4 + 3 * i] = pa[i];
-      vals[5 + 3 * i] = pX[i];
-      vals[6 + 3 * i] = pY[i];
-    }
-    const int nq = 4 + 3 * M;  // quantities in use (wave-uniform): the unused sources are not reduced
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      if (q < nq) {
-        const float s = wave_sum(vals[q]);
-        if (lane == 0) RED[wid * NQ + q] = s;
+    const int nq = 4 + 3 * M;  // quantities in use: the sums of the sources already sit in the waves' slots
+    {
+      const float s0 = wave_sum(acc_chi), s1 = wave_sum(acc_mean), s2 = wave_sum(acc_dx), s3 = wave_sum(acc_dy);
+      if (lane == 0) {
+        RED[wid * NQ + 0] = s0;
+        RED[wid * NQ + 1] = s1;
+        RED[wid * NQ + 2] = s2;
+        RED[wid * NQ + 3] = s3;
       }
     }
     __syncthreads();
@@ -815,7 +828,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       A.g_mean[e] = t[1];
       float gdx = t[2], gdy = t[3];
       for (int i = 0; i < M; ++i) {
-        const float ai = amp[i];  // = a[e][i] in this mode
+        const float ai = AMPL[i];  // = a[e][i] in this mode
         const float gX = ai * t[5 + 3 * i], gY = ai * t[6 + 3 * i];
         A.g_a[e * M + i] = t[4 + 3 * i];
         gdx += SS * gX;

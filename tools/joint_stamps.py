@@ -26,4 +26,4 @@ tot = s[8] - s[0]
 for k, nm in enumerate(names):
     print(f'{nm:28s} {s[k+1]-s[k]:8d} cycles {100*(s[k+1]-s[k])/tot:5.1f}%')
 print('total', tot)
-print('phase A last sweep of wave 0: stage', s[10]-s[9], 'scene', s[11]-s[10], 'fft', s[12]-s[11], 'unpack', s[13]-s[12])
+print('phase B last sweep of wave 0: loads', s[10]-s[9], 'fwd fft', s[11]-s[10], 'times spectrum', s[12]-s[11], 'inv fft', s[13]-s[12], 'store', s[14]-s[13])
