@@ -211,8 +211,29 @@ __global__ void gm_pts_final_kernel(int nblocks, int M, const float *part, const
 // joint_update_kernel).  A.greg / A.regs hold the h regulariser when A.reg_mode == 2.
 // sc: the scalar part of the reduced block (A.shared + N * N, or a copy in LDS); parts: bit 0 = fluxes, positions and the
 // loss, bit 1 = dx, dy, mean (independent of the reduction: a block of their own in the fused launch)
+// flux elements tid and tid + kGmThreads with their gradient and AdaBelief moments: requested by the fused kernel before
+// the scalar reduction they have to wait for, so that one load latency serves both
+struct FluxPre {
+  float av0, ga0, pm0, ps0, av1, ga1, pm1, ps1;
+};
+__device__ __forceinline__ void gm_flux_preload(const JointUpdArgs &A, FluxPre &P) {
+  const int tid = threadIdx.x, EM = A.E * A.M;
+  P.av0 = P.ga0 = P.pm0 = P.ps0 = P.av1 = P.ga1 = P.pm1 = P.ps1 = 0.f;
+  if (tid < EM) {
+    P.av0 = A.par[LC_P_A][tid];
+    P.ga0 = A.g_a[tid];
+    P.pm0 = A.pm[LC_P_A][tid];
+    P.ps0 = A.ps[LC_P_A][tid];
+  }
+  if (tid + kGmThreads < EM) {
+    P.av1 = A.par[LC_P_A][tid + kGmThreads];
+    P.ga1 = A.g_a[tid + kGmThreads];
+    P.pm1 = A.pm[LC_P_A][tid + kGmThreads];
+    P.ps1 = A.ps[LC_P_A][tid + kGmThreads];
+  }
+}
 __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, float lr, float bc1, float bc2, const float *sc,
-                                                int parts) {
+                                                int parts, const FluxPre *pre = nullptr) {
   __shared__ float red[kGmThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int E = A.E, M = A.M, NN = N * N;
@@ -220,11 +241,8 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
   const bool use_reg = (A.reg_mode == 2);
   const bool pts = (A.lam_pts != 0.f && A.pts_early == 2);  // point-source starlet term evaluated by the reg launch
   float pos_ps = 0.f;
-  if (parts & 1)
-  for (int idx = tid; idx < E * M; idx += kGmThreads) {
+  auto flux = [&](int idx, float av, float ga, float pmv, float psv) {
     const int i = idx % M;
-    float av = A.par[LC_P_A][idx];
-    float ga = A.g_a[idx];
     if (A.lam_pos_ps != 0.f && av < 0.f) {
       pos_ps += -A.lam_pos_ps * av;
       ga -= A.lam_pos_ps;
@@ -239,9 +257,21 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
     if (A.mode == 0) {
       if (A.gout[LC_P_A]) A.gout[LC_P_A][idx] = ga;
     } else if (A.free_mask[LC_P_A]) {
-      adabelief_step(av, A.pm[LC_P_A][idx], A.ps[LC_P_A][idx], ga, lr, bc1, bc2, A.ab);
+      adabelief_step(av, pmv, psv, ga, lr, bc1, bc2, A.ab);
       A.par[LC_P_A][idx] = av;
+      A.pm[LC_P_A][idx] = pmv;
+      A.ps[LC_P_A][idx] = psv;
     }
+  };
+  if (parts & 1) {
+    int first = tid;
+    if (pre) {
+      if (tid < E * M) flux(tid, pre->av0, pre->ga0, pre->pm0, pre->ps0);
+      if (tid + kGmThreads < E * M) flux(tid + kGmThreads, pre->av1, pre->ga1, pre->pm1, pre->ps1);
+      first = tid + 2 * kGmThreads;
+    }
+    for (int idx = first; idx < E * M; idx += kGmThreads)
+      flux(idx, A.par[LC_P_A][idx], A.g_a[idx], A.pm[LC_P_A][idx], A.ps[LC_P_A][idx]);
   }
   if (parts & 2)
   for (int idx = tid; idx < 3 * E; idx += kGmThreads) {
@@ -362,9 +392,11 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointU
     return;
   }
   __shared__ float scl[4 * kMaxSources + 2];
+  FluxPre pre;
+  gm_flux_preload(A, pre);
   reduce_scalars(E, M, NN, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.a_ref, A.shared_w, lanes, tid, scl);
   __syncthreads();
-  gm_small_blocks(A, N, lr, bc1, bc2, scl, 1);
+  gm_small_blocks(A, N, lr, bc1, bc2, scl, 1, &pre);
 }
 
 }  // namespace lc
