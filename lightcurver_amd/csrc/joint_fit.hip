@@ -72,6 +72,9 @@ struct lc_joint {
   hipEvent_t evReg = nullptr, evUpd = nullptr;
   bool reg_pending = false;
   bool in_device_loop = false, fuse_pending = false;
+  unsigned int *reg_flag = nullptr;  // [0] sequence number of the last finished regulariser chain, [1] a flag wait ran out
+  unsigned int reg_seq = 0;
+  bool flag_sync = false;            // this iteration's update checks reg_flag itself instead of waiting for evReg
   bool fuse_full = false;  // lc_joint_run_adabelief, background free: reduction over the epochs and update in one launch
   bool pts_pending = false;  // the point-source starlet term of this iteration was evaluated by the stream-B launch  // lc_joint_run_adabelief: scalar reduction fused into the update
   std::vector<float> h_sigma2, h_psf;  // host copies for the one-time noise propagation
@@ -400,8 +403,9 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
   hipLaunchKernelGGL(mreg_finish_kernel, dim3(nb), dim3(kGmThreads), 0, stream, N, J, l1_on ? 1 : 0, with_pts ? 1 : 0, j->ss,
                      j->M, j->mr_Z, j->par[LC_P_H], j->cfg.lam_positivity, j->par[LC_P_CX], j->par[LC_P_CY], j->greg,
                      j->mr_pos, j->mr_part);
+  j->reg_seq += 1;
   hipLaunchKernelGGL(mreg_regs_kernel, dim3(1), dim3(64), 0, stream, J, l1_on ? 1 : 0, with_pts ? 1 : 0, nb, j->M, j->mr_l1,
-                     j->mr_pos, j->mr_part, j->regs);
+                     j->mr_pos, j->mr_part, j->regs, j->reg_flag, j->reg_seq);
   LC_HIP(j->ctx, hipGetLastError());
   return LC_OK;
 }
@@ -477,6 +481,11 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
     const int NN = j->N * j->N;
     int nblk = (NN + kGmThreads - 1) / kGmThreads;
     if (j->fuse_full && mode == 1) {
+      if (j->flag_sync) {
+        A.wait_flag = j->reg_flag;
+        A.wait_seq = j->reg_seq;
+        A.wait_err = j->reg_flag + 1;
+      }
       A.g_cx_e = j->g_cx_e;
       A.g_cy_e = j->g_cy_e;
       A.chi2_e = j->chi2_e;
@@ -630,6 +639,7 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
     TRY(dmalloc(j, &j->mr_pos, nb));
     TRY(dmalloc(j, &j->mr_part, nb * 3 * kMaxSources));
     TRY(dmalloc(j, &j->mr_pbar, NN));
+    TRY(dmalloc(j, &j->reg_flag, 2));
     LC_HIP(ctx, hipFuncSetAttribute((const void *)j->mreg->fwd, hipFuncAttributeMaxDynamicSharedMemorySize, j->mreg->lds_fwd));
     LC_HIP(ctx, hipFuncSetAttribute((const void *)j->mreg->adj, hipFuncAttributeMaxDynamicSharedMemorySize, j->mreg->lds_adj));
   }
@@ -943,7 +953,10 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   LC_ENTER(j->ctx);
   int rc = ensure_hist(j, j->iters_done + 2);
   if (rc) return rc;
-  if (j->reg_pending) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
+  // the regulariser chain of this iteration was enqueued (second stream) before the epoch kernel.  The fused update checks
+  // its completion flag in the kernel; every other form waits for the event
+  j->flag_sync = j->reg_pending && j->fuse_full && j->mreg && j->reg_flag && !std::getenv("LCMI_EVENT_SYNC");
+  if (j->reg_pending && !j->flag_sync) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
   rc = launch_update(j, 1, j->iters_done, cfg, true, false, j->reg_pending ? 2 : 0);
   if (rc) return rc;
   LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
@@ -1004,11 +1017,24 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
   int rc = ensure_hist(j, j->iters_done + n_iter + 2);
   if (rc) return rc;
   j->in_device_loop = true;
+  bool flags_used = false;
   for (int it = 0; it < n_iter && !rc; ++it) {
     if ((rc = lc_joint_step_local(j))) break;
     rc = lc_joint_step_update(j, cfg);
+    flags_used = flags_used || j->flag_sync;
   }
   j->in_device_loop = false;
+  j->flag_sync = false;
+  if (!rc && flags_used) {  // an update that gave up waiting for its regulariser would have used stale numbers: report it
+    unsigned int err = 0;
+    if ((rc = d2h(j, &err, j->reg_flag + 1, sizeof(err)))) return rc;
+    if (err) {
+      const unsigned int zero = 0;
+      h2d(j, j->reg_flag + 1, &zero, sizeof(zero));
+      j->ctx->err = "joint fit: the regulariser of an iteration did not complete in time on the second stream (set LCMI_EVENT_SYNC=1)";
+      return LC_ERR_DEVICE;
+    }
+  }
   return rc;
 }
 int lc_joint_iterations_done(lc_joint *j) { return j ? j->iters_done : LC_ERR_INVALID; }

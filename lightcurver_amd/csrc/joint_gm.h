@@ -253,7 +253,7 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
       const float sd = sqrtf(var);
       if (sd > 0.f) ga += A.lam_fu * ((av - A.a_ref[i]) - meanc) / (Etot * sd);
     }
-    if (pts) ga += A.regs[4 + i * 3] / Etot;
+    if (pts) ga += ld_coherent(A.regs + (4 + i * 3), A.wait_flag != nullptr) / Etot;
     if (A.mode == 0) {
       if (A.gout[LC_P_A]) A.gout[LC_P_A][idx] = ga;
     } else if (A.free_mask[LC_P_A]) {
@@ -292,7 +292,7 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
     const int which = (tid < M) ? LC_P_CX : LC_P_CY, i = tid % M;
     float gv = sc[(which == LC_P_CX ? 0 : M) + i];
     float cv = A.par[which][i];
-    if (pts) gv += (A.a_ref[i] + sc[2 * M + i] / Etot) * A.ss * A.regs[4 + i * 3 + (which == LC_P_CX ? 1 : 2)];
+    if (pts) gv += (A.a_ref[i] + sc[2 * M + i] / Etot) * A.ss * ld_coherent(A.regs + (4 + i * 3 + (which == LC_P_CX ? 1 : 2)), A.wait_flag != nullptr);
     if (A.n_prior > 0) {
       const float mu = (which == LC_P_CX) ? A.prior_cx_mean[i] : A.prior_cy_mean[i];
       const float sg = (which == LC_P_CX) ? A.prior_cx_sigma[i] : A.prior_cy_sigma[i];
@@ -314,8 +314,8 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
   if (tid == 0) {
     double loss = 0.5 * (double)sc[4 * M];
     for (int w = 0; w < kGmThreads / 64; ++w) loss += red[w];
-    if (use_reg) loss += (double)A.regs[0] + (double)A.regs[1];
-    if (pts) loss += (double)A.regs[2];
+    if (use_reg) loss += (double)ld_coherent(A.regs + (0), A.wait_flag != nullptr) + (double)ld_coherent(A.regs + (1), A.wait_flag != nullptr);
+    if (pts) loss += (double)ld_coherent(A.regs + (2), A.wait_flag != nullptr);
     if (A.lam_fu != 0.f && Etot > 1.f)
       for (int i = 0; i < M; ++i) {
         const double meanc = sc[2 * M + i] / Etot;
@@ -370,15 +370,16 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointU
   if ((int)blockIdx.x < nimg) {
     const int px0 = blockIdx.x * kRedPix, px = px0 + tid;
     // state of this thread's pixel: requested before the reduction, used after it
-    float hv = 0.f, m = 0.f, sv = 0.f, gr = 0.f;
+    float hv = 0.f, m = 0.f, sv = 0.f;
     if (tid < kRedPix) {
       hv = A.h[px];
       m = A.mh[px];
       sv = A.sh[px];
-      gr = (A.reg_mode == 2) ? A.greg[px] : 0.f;
     }
     const float t = reduce_pixels16(E, NN, HG, px0, part, tid);
+    wait_for_flag(A.wait_flag, A.wait_seq, A.wait_err);  // the regulariser of this iteration (second stream)
     if (tid < kRedPix) {
+      const float gr = (A.reg_mode == 2) ? ld_coherent(A.greg + px, A.wait_flag != nullptr) : 0.f;
       A.shared_w[px] = t;
       adabelief_step(hv, m, sv, t + gr, lr, bc1, bc2, A.ab);
       A.h[px] = hv;
@@ -396,6 +397,7 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointU
   gm_flux_preload(A, pre);
   reduce_scalars(E, M, NN, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.a_ref, A.shared_w, lanes, tid, scl);
   __syncthreads();
+  wait_for_flag(A.wait_flag, A.wait_seq, A.wait_err);
   gm_small_blocks(A, N, lr, bc1, bc2, scl, 1, &pre);
 }
 

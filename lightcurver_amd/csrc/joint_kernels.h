@@ -1084,7 +1084,35 @@ struct JointUpdArgs {
   // leaves regs[2] = value, regs[4 + 3 i ..] = d/d abar_i, d/dX_i / abar_i, d/dY_i / abar_i;  pts_early = 2 in the
   // update launch consumes them instead of evaluating the term
   int pts_early;
+  // fused update of the device loop: the regulariser chain on the second stream publishes wait_seq in *wait_flag when greg /
+  // regs are complete; the kernel checks the flag itself (the chain was enqueued first and is normally long done), which
+  // spares the cross-stream event wait in front of it.  A wait that runs out sets *wait_err.
+  const unsigned int *wait_flag;
+  unsigned int wait_seq;
+  unsigned int *wait_err;
 };
+
+// All threads of a block: block until *flag has reached seq (thread 0 polls, bounded: ~0.2 s).  No acquire fence follows: an
+// agent-scope acquire invalidates the L2 of the XCD, and a thousand blocks doing that cost 33 us; the few values the
+// chain produced are read with ld_coherent (L2-bypassing loads) instead, and the chain wrote its L2 back before the flag.
+__device__ __forceinline__ void wait_for_flag(const unsigned int *flag, unsigned int seq, unsigned int *err) {
+  if (flag) {
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > (1 << 20)) {
+          if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ float ld_coherent(const float *p, bool coherent) {
+  return coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
 
 __device__ __forceinline__ float adabelief_step(float &p, float &m, float &s, float g, float lr, float bc1, float bc2,
                                                 const lc_adabelief_cfg &ab) {

@@ -258,8 +258,10 @@ __global__ __launch_bounds__(kGmThreads) void mreg_finish_kernel(int N, int J, i
 }
 
 // regs[0] = l1, regs[1] = positivity, regs[2] = point-source term, regs[4 + 3 i + q] = its inner products (one wave)
+// done_flag (optional): receives done_seq once everything above is written — the fused update kernel of the device loop
+// checks it instead of the host enqueueing a cross-stream event wait in front of it (joint_reduce_update_kernel)
 __global__ void mreg_regs_kernel(int J, int l1_on, int has_pts, int nblocks, int M, const float *l1p, const float *pos_part,
-                                 const float *pts_part, float *regs) {
+                                 const float *pts_part, float *regs, unsigned int *done_flag, unsigned int done_seq) {
   const int lane = threadIdx.x;
   float b = 0.f;
   for (int i = lane; i < nblocks; i += 64) b += pos_part[i];
@@ -279,6 +281,10 @@ __global__ void mreg_regs_kernel(int J, int l1_on, int has_pts, int nblocks, int
       acc = wave_sum_shfl(acc);
       if (lane == 0) regs[4 + t] = acc;
     }
+  if (done_flag) {  // (one wave; every write of this chain before the flag)
+    __threadfence();
+    if (lane == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 }  // namespace lc

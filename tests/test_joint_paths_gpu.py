@@ -3,7 +3,8 @@
 * the starlet regulariser of the large background grids (N >= 128): two-sided products on the fp32 matrix cores
   (csrc/joint_reg_mfma.h, default) or the a-trous cascade kernels (LCMI_REG_CASCADE=1);
 * inside lc_joint_run_adabelief with the background free: reduction over the epochs and update in one launch (default) or
-  as two kernels (LCMI_SPLIT_UPDATE=1; the kernels the sharded drive uses).
+  as two kernels (LCMI_SPLIT_UPDATE=1; the kernels the sharded drive uses); the fused launch learns that the second
+  stream's regulariser is complete from a flag it checks itself (default) or from an event wait (LCMI_EVENT_SYNC=1).
 
 Both pairs compute the same numbers in different summation orders; these tests run the same fit through each and compare
 (fp32 rounding of the sums only: 1e-5 relative on the loss history, a few 1e-6 of the parameter scale on the parameters).
@@ -81,6 +82,17 @@ def test_fused_reduction_and_update_equals_the_two_kernels(ctx, E, n, M):
     a = _fit(ctx, ds, M, 25)
     b = _fit(ctx, ds, M, 25, env={'LCMI_SPLIT_UPDATE': '1'})
     # same reduction order in both forms: the histories are identical, not merely close
+    np.testing.assert_array_equal(a[0], b[0])
+    for k in ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'):
+        np.testing.assert_array_equal(a[1][k], b[1][k])
+
+
+def test_flag_synchronised_update_equals_the_event_synchronised_one(ctx):
+    """Device loop, N >= 128: the fused update checks the completion flag of the regulariser chain in the kernel (default)
+    or the host enqueues a cross-stream event wait in front of it (LCMI_EVENT_SYNC=1).  Same kernels, same numbers."""
+    ds = make_roi_dataset(E=8, M=2, n=64, ss=2, seed=104)
+    a = _fit(ctx, ds, 2, 40)
+    b = _fit(ctx, ds, 2, 40, env={'LCMI_EVENT_SYNC': '1'})
     np.testing.assert_array_equal(a[0], b[0])
     for k in ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'):
         np.testing.assert_array_equal(a[1][k], b[1][k])
