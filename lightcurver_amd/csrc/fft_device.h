@@ -182,9 +182,14 @@ __device__ __forceinline__ void exchange_add(float2 (&x)[N2], float s) {
 // One decimation-in-frequency stage across the lanes (span H): lower lane a + b, upper lane (a - b) w.
 // Branch- and select-free: t = x + s x[partner] with s = +-1 (the upper lane gets b - a, the sign goes into its
 // twiddle), then a multiplication by w (lower lanes: 1).  j = transform index of the lane (fft_index_n).
-template <int L, int H, int LPF>
+template <int L, int H, int LPF, bool BARE = false>
 __device__ __forceinline__ void dif_stage(float2 (&x)[L / LPF], int j, const float2 *tw) {
   const bool upper = (j & H) != 0;
+  if constexpr (BARE) {  // H = 1: the twiddle is 1, so w = -+1; the caller takes the sign of the odd lanes elsewhere
+    static_assert(H == 1, "bare stage");
+    exchange_add<H>(x, upper ? -1.f : 1.f);
+    return;
+  }
   float2 wt = tw[(j & (H - 1)) * (L / (2 * H))];
   asm volatile("" : "+v"(wt.x), "+v"(wt.y));  // every lane loads: no branch around the read
   const float sgn = upper ? -1.f : 1.f;
@@ -195,9 +200,14 @@ __device__ __forceinline__ void dif_stage(float2 (&x)[L / LPF], int j, const flo
 }
 // One decimation-in-time stage (inverse direction): upper lane pre-multiplied by conj w, then a + b / a - b.
 // The upper lane carries -t through the exchange (sign in its twiddle), so that both lanes do x = t - s t[partner].
-template <int L, int H, int LPF>
+template <int L, int H, int LPF, bool BARE = false>
 __device__ __forceinline__ void dit_stage_inv(float2 (&x)[L / LPF], int j, const float2 *tw) {
   const bool upper = (j & H) != 0;
+  if constexpr (BARE) {  // H = 1: the odd lanes arrive already negated
+    static_assert(H == 1, "bare stage");
+    exchange_add<H>(x, upper ? 1.f : -1.f);
+    return;
+  }
   float2 wt = tw[(j & (H - 1)) * (L / (2 * H))];
   asm volatile("" : "+v"(wt.x), "+v"(wt.y));
   const float msg = upper ? 1.f : -1.f;
@@ -220,7 +230,11 @@ __device__ __forceinline__ int bitrev_n(int x) {
   else return (bitrev4(x & 15) << 1) | ((x >> 4) & 1);
 }
 // tw[m] = exp(-2 pi i m / L), m < L (LDS)
-template <int L, int LPF = 16>
+// ODDNEG: the last forward stage (span 1) has twiddle 1, i.e. multiplies the odd-index lanes by -1, and the first inverse
+// stage undoes exactly that.  A forward transform that is followed by lane-local arithmetic and the inverse transform (the
+// column passes: multiply by a spectrum) may therefore leave the odd lanes negated (ODDNEG forward) and hand them to an
+// ODDNEG inverse as they are: two complex multiplications per element less, same numbers (products with +-1 are exact).
+template <int L, int LPF = 16, bool ODDNEG = false>
 __device__ __forceinline__ void group_fft_fwd(float2 (&x)[L / LPF], int j, const float2 *tw) {
   constexpr int N2 = L / LPF;
   if constexpr (N2 >= 24) LC_LAUNDER(j);  // keep the 2 * N2 twiddle registers from being hoisted out of the caller's loops
@@ -231,13 +245,13 @@ __device__ __forceinline__ void group_fft_fwd(float2 (&x)[L / LPF], int j, const
   dif_stage<L, 8, LPF>(x, j, tw);
   dif_stage<L, 4, LPF>(x, j, tw);
   dif_stage<L, 2, LPF>(x, j, tw);
-  dif_stage<L, 1, LPF>(x, j, tw);
+  dif_stage<L, 1, LPF, ODDNEG>(x, j, tw);
 }
-template <int L, int LPF = 16>
+template <int L, int LPF = 16, bool ODDNEG = false>
 __device__ __forceinline__ void group_fft_inv(float2 (&x)[L / LPF], int j, const float2 *tw) {
   constexpr int N2 = L / LPF;
   if constexpr (N2 >= 24) LC_LAUNDER(j);
-  dit_stage_inv<L, 1, LPF>(x, j, tw);
+  dit_stage_inv<L, 1, LPF, ODDNEG>(x, j, tw);
   dit_stage_inv<L, 2, LPF>(x, j, tw);
   dit_stage_inv<L, 4, LPF>(x, j, tw);
   dit_stage_inv<L, 8, LPF>(x, j, tw);

@@ -363,6 +363,11 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   auto times_spectrum = [&](float2 (&x)[N2], const float2 (&sv)[N2], const float2 *Ste, int kc, bool conj) {
     // sv: spectrum column kc, requested before the forward transform so that its latency hides behind it
     if (kc == 0) {  // one quarter of one wave, once per phase
+      // (the split below pairs lanes of opposite index parity: give the odd lanes their sign back for it, and take it away
+      //  again afterwards - the transforms around this function run in their ODDNEG form)
+      const float osg = (l16 & 1) ? -1.f : 1.f;
+#pragma unroll
+      for (int k2 = 0; k2 < N2; ++k2) x[k2] = make_float2(osg * x[k2].x, osg * x[k2].y);
       // bin k2 of this lane and bin N2 - k2 of its mirror lane are each other's conjugate partners: the two
       // registers of such a pair are read (own value + partner's value by shuffle) before either is overwritten,
       // so the split / multiply / re-pack runs in place
@@ -383,6 +388,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         x[N2 - k2] = one(zb, cb, N2 - k2);
       }
       if constexpr (N2 % 2 == 0) x[N2 / 2] = one(x[N2 / 2], shfl2(x[N2 / 2], lane_mirror), N2 / 2);
+#pragma unroll
+      for (int k2 = 0; k2 < N2; ++k2) x[k2] = make_float2(osg * x[k2].x, osg * x[k2].y);
     } else {
 #pragma unroll
       for (int k2 = 0; k2 < N2; ++k2) x[k2] = conj ? cmul_conj(x[k2], sv[k2]) : cmul(x[k2], sv[k2]);
@@ -502,11 +509,11 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     const bool paired = PAIRCOL && kc0 != 0;  // (the packed DC / Nyquist column takes the element-wise form)
     if (paired) pair_load_columns(x, kc0, active, 0); else load_column(x, kcs, active, 0);
     LC_JSTAMP(10);
-    group_fft_fwd<L, LPF>(x, l16, TW);
+    group_fft_fwd<L, LPF, true>(x, l16, TW);
     LC_JSTAMP(11);
     times_spectrum(x, sv, Ste, kcs, false);
     LC_JSTAMP(12);
-    group_fft_inv<L, LPF>(x, l16, TW);
+    group_fft_inv<L, LPF, true>(x, l16, TW);
     LC_JSTAMP(13);
     if (paired) pair_store_columns(x, kc0, active, CREF); else store_column(x, kcs, active, CREF);
     LC_JSTAMP(14);
@@ -743,9 +750,9 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)kcs * L + kbase + k2];
     const bool paired = PAIRCOL && kc0 != 0;
     if (paired) pair_load_columns(x, kc0, active, CREF); else load_column(x, kcs, active, CREF);
-    group_fft_fwd<L, LPF>(x, l16, TW);
+    group_fft_fwd<L, LPF, true>(x, l16, TW);
     times_spectrum(x, sv, Ste, kcs, true);
-    group_fft_inv<L, LPF>(x, l16, TW);
+    group_fft_inv<L, LPF, true>(x, l16, TW);
     if (paired) pair_store_columns(x, kc0, active, 0); else store_column(x, kcs, active, 0);
   }
   __syncthreads();
