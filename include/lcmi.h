@@ -123,7 +123,9 @@ int lc_psf_batch_get_weights(lc_psf_batch *b, float *W);
 /* (after lc_psf_batch_set_moffat_q, grad_moffat is d loss / d (q11, q12, q22, beta)) */
 int lc_psf_batch_eval(lc_psf_batch *b, float *loss, float *chi2, float *grad_moffat,
                       float *grad_stars, float *grad_grid, float *model);
-/* Stage A of build_psf: Moffat + a, x0, y0 by bounded L-BFGS with B = 0 (n_iter_analytic). */
+/* Stage A of build_psf: Moffat + a, x0, y0 by bounded L-BFGS with B = 0 (n_iter_analytic).  One independent problem per
+ * frame, optimiser state and two-loop recursion on the device (csrc/psf_lbfgs.h); replaces STARRED's
+ * Optimizer(method='l-bfgs-b') inside build_psf (reference call site lightcurver/processes/psf_modelling.py:164-171). */
 int lc_psf_batch_fit_moffat(lc_psf_batch *b, int n_iter, float *final_loss /* [F] or NULL */);
 /* Stage B: n_iter AdaBelief steps on B, a, x0, y0, state and loop on device (the hot loop).
  * Asynchronous on the context stream.  loss history accumulates across calls. */

@@ -12,6 +12,7 @@
 #include "psf_kernels.h"
 #include "psf_noise.h"
 #include "psf_distort.h"
+#include "psf_lbfgs.h"
 
 using namespace lc;
 
@@ -742,7 +743,89 @@ int lc_psf_batch_fit_moffat(lc_psf_batch *b, int n_iter, float *final_loss) {
     }
   }
   const bool had_W = b->have_W;
-  // pinned staging: parameters up, loss + gradients down, one synchronisation per evaluation
+  hipStream_t q = b->ctx->stream;
+  if (D <= 64 && !b->moffat_is_q && !std::getenv("LCMI_LBFGS_HOST")) {
+    // the optimiser on the device (csrc/psf_lbfgs.h): per round one evaluation of all frames at the points the step
+    // kernel left in the parameter blocks, then the step kernel; the host reads one integer every 8 rounds
+    const size_t FD = (size_t)F * D;
+    const int max_rounds = std::max(1, n_iter) * 4 + 32;  // accepted steps + back-tracking trials; stops earlier when all frames are done
+    double *dbl = nullptr;
+    int *ints = nullptr;
+    const size_t n_dbl = 6 * FD + 2 * FD * kPsfLbfgsMem + (size_t)F * kPsfLbfgsMem + 2 * (size_t)F;
+    const size_t n_int = 4 * (size_t)F + (size_t)max_rounds + 1;
+    LC_HIP(b->ctx, hipMalloc((void **)&dbl, n_dbl * sizeof(double)));
+    struct DevGuard {
+      void *p;
+      ~DevGuard() { (void)hipFree(p); }
+    } g1{dbl};
+    LC_HIP(b->ctx, hipMalloc((void **)&ints, n_int * sizeof(int)));
+    DevGuard g2{ints};
+    LC_HIP(b->ctx, hipMemsetAsync(dbl, 0, n_dbl * sizeof(double), q));
+    LC_HIP(b->ctx, hipMemsetAsync(ints, 0, n_int * sizeof(int), q));
+    PsfLbfgsDev P;
+    P.F = F;
+    P.S = S;
+    P.D = D;
+    P.maxiter = n_iter;
+    P.gtol = 1e-7;
+    P.ftol = 1e-12;
+    P.x = dbl;
+    P.g = P.x + FD;
+    P.d = P.g + FD;
+    P.xt = P.d + FD;
+    P.lo = P.xt + FD;
+    P.hi = P.lo + FD;
+    P.Sm = P.hi + FD;
+    P.Ym = P.Sm + FD * kPsfLbfgsMem;
+    P.rho = P.Ym + FD * kPsfLbfgsMem;
+    P.f = P.rho + (size_t)F * kPsfLbfgsMem;
+    P.alpha = P.f + F;
+    P.state = ints;
+    P.ls = P.state + F;
+    P.iters = P.ls + F;
+    P.m = P.iters + F;
+    P.n_active = P.m + F;
+    P.moffat = b->moffat;
+    P.stars = b->stars;
+    P.o_loss = b->o_loss;
+    P.o_gmoffat = b->o_gmoffat;
+    P.o_gstars = b->o_gstars;
+    for (size_t i = 0; i < x.size(); ++i) x[i] = std::min(std::max(x[i], lo[i]), hi[i]);
+    for (auto &v : hi) v = std::min(v, 1e300);  // (infinite bounds travel as huge finite ones)
+    LC_HIP(b->ctx, hipMemcpyAsync(P.x, x.data(), FD * sizeof(double), hipMemcpyHostToDevice, q));
+    LC_HIP(b->ctx, hipMemcpyAsync(P.lo, lo.data(), FD * sizeof(double), hipMemcpyHostToDevice, q));
+    LC_HIP(b->ctx, hipMemcpyAsync(P.hi, hi.data(), FD * sizeof(double), hipMemcpyHostToDevice, q));
+    auto evaluate = [&]() -> int {
+      hipLaunchKernelGGL(moffat_raster_kernel, dim3(F), dim3(256), 0, q, b->N, b->ss, b->moffat, b->Tm);
+      int r = ensure_hist(b, b->iters_done + 1);
+      if (r) return r;
+      if ((r = launch_psf(b, 0, 1, nullptr, true, false))) return r;  // stage A: no regularisation (B fixed)
+      hipLaunchKernelGGL(moffat_grad_kernel, dim3(F), dim3(256), 0, q, b->N, b->ss, b->moffat, b->o_gT, b->o_gmoffat);
+      LC_HIP(b->ctx, hipGetLastError());
+      return LC_OK;
+    };
+    hipLaunchKernelGGL(psf_lbfgs_step_kernel, dim3(F), dim3(64), 0, q, P, 2, 0);  // clipped start -> parameter blocks
+    if ((rc = evaluate())) return rc;
+    hipLaunchKernelGGL(psf_lbfgs_step_kernel, dim3(F), dim3(64), 0, q, P, 0, 0);
+    for (int round = 1; round <= max_rounds; ++round) {
+      if ((rc = evaluate())) return rc;
+      hipLaunchKernelGGL(psf_lbfgs_step_kernel, dim3(F), dim3(64), 0, q, P, 1, round);
+      LC_HIP(b->ctx, hipGetLastError());
+      if (round % 8 == 0 || round == max_rounds) {
+        int active = 0;
+        if ((rc = d2h(b, &active, P.n_active + round, sizeof(int)))) return rc;
+        if (active == 0) break;
+      }
+    }
+    hipLaunchKernelGGL(psf_lbfgs_step_kernel, dim3(F), dim3(64), 0, q, P, 2, 0);  // leave the device at the accepted optimum
+    if ((rc = evaluate())) return rc;
+    b->have_W = had_W;
+    if (final_loss && (rc = d2h(b, final_loss, b->o_loss, (size_t)F * sizeof(float)))) return rc;
+    LC_HIP(b->ctx, hipStreamSynchronize(q));
+    return LC_OK;
+  }
+  // host form (LCMI_LBFGS_HOST=1, the quadratic-form Moffat of the distortion fit): the same state machine in
+  // csrc/lbfgs_host.h, pinned staging: parameters up, loss + gradients down, one synchronisation per evaluation
   const size_t n_in = (size_t)F * 4 + (size_t)F * S * 4, n_out = (size_t)F + (size_t)F * 4 + (size_t)F * S * 4;
   float *pin = nullptr;
   LC_HIP(b->ctx, hipHostMalloc((void **)&pin, (n_in + n_out) * sizeof(float), hipHostMallocDefault));
@@ -752,7 +835,6 @@ int lc_psf_batch_fit_moffat(lc_psf_batch *b, int n_iter, float *final_loss) {
   } guard{pin};
   float *pmof = pin, *pst = pin + (size_t)F * 4, *loss = pin + n_in, *gm = loss + F, *gs = gm + (size_t)F * 4;
   std::memcpy(pst, st.data(), st.size() * sizeof(float));  // sky (column 3) stays as it is
-  hipStream_t q = b->ctx->stream;
   auto eval = [&](const std::vector<double> &X, std::vector<double> &Fv, std::vector<double> &G) -> int {
     for (int f = 0; f < F; ++f) {
       const double *xf = &X[(size_t)f * D];

@@ -170,6 +170,37 @@ def test_moffat_stage_reaches_oracle_optimum(ctx):
         assert abs(fw_gpu - fw_or) / fw_or < 2e-2
 
 
+def test_moffat_stage_on_the_device_equals_the_host_driven_one(ctx):
+    """Stage A has its L-BFGS state machine on the device (csrc/psf_lbfgs.h, default) and on the host (csrc/lbfgs_host.h,
+    LCMI_LBFGS_HOST=1): the same algorithm in double precision on the same fp32 loss / gradient evaluations.  The two
+    follow the same iterates up to the order of the dot products, so the optima agree far inside the optimum-level
+    tolerance that is asked against scipy."""
+    import os
+    n, ss, S, F = 32, 2, 8, 12
+    out = []
+    for env in (None, '1'):
+        if env:
+            os.environ['LCMI_LBFGS_HOST'] = env
+        try:
+            ds, plist, b = _setup(n, ss, F, S, 37, ctx, jitter=0.0)
+            b.set_grid(None)
+            stars = H.stars_array(plist)
+            stars[..., 3] = 0.0
+            stars[..., 0] *= 0.8          # start away from the optimum
+            b.set_stars(stars)
+            mof0 = b.get_moffat().copy()
+            mof0[:, :2] *= 1.3
+            b.set_moffat(mof0)
+            out.append((np.asarray(b.fit_moffat(100), dtype=np.float64), b.get_moffat().copy(), np.array(b.get_stars())))
+        finally:
+            os.environ.pop('LCMI_LBFGS_HOST', None)
+    (fd, md, sd), (fh, mh, sh) = out
+    assert np.all(np.isfinite(fd)) and np.max(np.abs(fd - fh) / fh) < 1e-4
+    assert np.max(np.abs(sd[..., 0] - sh[..., 0]) / np.abs(sh[..., 0])) < 2e-3
+    assert np.max(np.abs(sd[..., 1:3] - sh[..., 1:3])) < 2e-3
+    assert np.max(np.abs(0.5 * (md[:, 0] + md[:, 1]) - 0.5 * (mh[:, 0] + mh[:, 1]))) < 1e-2
+
+
 @pytest.mark.parametrize('n,S,F', [(16, 4, 5), (24, 5, 3), (32, 8, 100), (64, 8, 63)])
 def test_two_workgroup_form_is_bit_identical(ctx, n, S, F):
     """Small batches run the optimisation loop with two workgroups per frame (chi2 gradient / starlet term,
