@@ -957,7 +957,7 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   // its completion flag in the kernel; every other form waits for the event
   // (only while the update's blocks cannot fill the machine: a block that had to wait for a late chain holds its wave
   //  slots, and the chain needs some of its own to finish - N = 256 launches 4098 blocks and keeps the event)
-  const bool few_blocks = (j->N * j->N) / kRedPix + 2 <= 4 * j->ctx->n_cu;
+  const bool few_blocks = (j->N * j->N) / kRedPix <= 4 * j->ctx->n_cu;  // four 256-thread blocks per CU: half its wave slots
   j->flag_sync = j->reg_pending && j->fuse_full && j->mreg && j->reg_flag && few_blocks && !std::getenv("LCMI_EVENT_SYNC");
   if (j->reg_pending && !j->flag_sync) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
   rc = launch_update(j, 1, j->iters_done, cfg, true, false, j->reg_pending ? 2 : 0);
