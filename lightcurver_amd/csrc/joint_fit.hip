@@ -490,8 +490,9 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
       A.g_cy_e = j->g_cy_e;
       A.chi2_e = j->chi2_e;
       A.shared_w = j->shared;
-      const int nimg = NN / kRedPix;
-      hipLaunchKernelGGL(joint_reduce_update_kernel, dim3(nimg + 2), dim3(kRedThreads), 0, stream, A, j->N, j->HG);
+      const int tiles = j->flag_sync ? 2 : 1;
+      const int nimg = NN / kRedPix / tiles;
+      hipLaunchKernelGGL(joint_reduce_update_kernel, dim3(nimg + 2), dim3(kRedThreads), 0, stream, A, j->N, j->HG, tiles);
       LC_HIP(j->ctx, hipGetLastError());
       return LC_OK;
     }
@@ -956,8 +957,10 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   // the regulariser chain of this iteration was enqueued (second stream) before the epoch kernel.  The fused update checks
   // its completion flag in the kernel; every other form waits for the event
   // (only while the update's blocks cannot fill the machine: a block that had to wait for a late chain holds its wave
-  //  slots, and the chain needs some of its own to finish - N = 256 launches 4098 blocks and keeps the event)
-  const bool few_blocks = (j->N * j->N) / kRedPix <= 4 * j->ctx->n_cu;  // four 256-thread blocks per CU: half its wave slots
+  //  slots and registers, and the chain needs some of its own to finish - N = 256 keeps the event)
+  // two 16-pixel tiles per block: at most two resident 256-thread blocks per CU (8 of 32 wave slots, 192 of 512 registers
+  // per lane and SIMD), next to which every kernel of the chain fits
+  const bool few_blocks = ((j->N * j->N) / kRedPix) % 2 == 0 && (j->N * j->N) / kRedPix / 2 <= 2 * j->ctx->n_cu;
   j->flag_sync = j->reg_pending && j->fuse_full && j->mreg && j->reg_flag && few_blocks && !std::getenv("LCMI_EVENT_SYNC");
   if (j->reg_pending && !j->flag_sync) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
   rc = launch_update(j, 1, j->iters_done, cfg, true, false, j->reg_pending ? 2 : 0);

@@ -359,32 +359,37 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
 // happen between the two): block b < nimg sums its 16 pixels of the T^T slabs (joint_reduce_kernel's order) and applies
 // AdaBelief to them right away; block nimg reduces the scalars, updates fluxes and positions and writes the loss; block
 // nimg + 1 updates the per-epoch shifts and sky levels.
-__global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointUpdArgs A, int N, const float *HG) {
+// `tiles` 16-pixel tiles per image block (2 where the regulariser flag is checked in the kernel: at most two 256-thread
+// blocks per CU are then resident, so a chain that runs late always finds the wave slots and registers to finish).
+__global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointUpdArgs A, int N, const float *HG, int tiles) {
   static_assert(kRedThreads == kGmThreads, "one block size");
   __shared__ float4 part[kRedParts][kRedPix / 4];
   __shared__ double lanes[kRedThreads];
   const int E = A.E, M = A.M, NN = N * N;
-  const int nimg = NN / kRedPix;
+  const int nimg = NN / kRedPix / tiles;  // image blocks
   const int tid = threadIdx.x;
   const float lr = A.lr, bc1 = A.bc1, bc2 = A.bc2;
   if ((int)blockIdx.x < nimg) {
-    const int px0 = blockIdx.x * kRedPix, px = px0 + tid;
-    // state of this thread's pixel: requested before the reduction, used after it
-    float hv = 0.f, m = 0.f, sv = 0.f;
-    if (tid < kRedPix) {
-      hv = A.h[px];
-      m = A.mh[px];
-      sv = A.sh[px];
-    }
-    const float t = reduce_pixels16(E, NN, HG, px0, part, tid);
-    wait_for_flag(A.wait_flag, A.wait_seq, A.wait_err);  // the regulariser of this iteration (second stream)
-    if (tid < kRedPix) {
-      const float gr = (A.reg_mode == 2) ? ld_coherent(A.greg + px, A.wait_flag != nullptr) : 0.f;
-      A.shared_w[px] = t;
-      adabelief_step(hv, m, sv, t + gr, lr, bc1, bc2, A.ab);
-      A.h[px] = hv;
-      A.mh[px] = m;
-      A.sh[px] = sv;
+    for (int tl = 0; tl < tiles; ++tl) {
+      const int px0 = (blockIdx.x * tiles + tl) * kRedPix, px = px0 + tid;
+      // state of this thread's pixel: requested before the reduction, used after it
+      float hv = 0.f, m = 0.f, sv = 0.f;
+      if (tid < kRedPix) {
+        hv = A.h[px];
+        m = A.mh[px];
+        sv = A.sh[px];
+      }
+      const float t = reduce_pixels16(E, NN, HG, px0, part, tid);
+      if (tl == 0) wait_for_flag(A.wait_flag, A.wait_seq, A.wait_err);  // the regulariser of this iteration (second stream)
+      if (tid < kRedPix) {
+        const float gr = (A.reg_mode == 2) ? ld_coherent(A.greg + px, A.wait_flag != nullptr) : 0.f;
+        A.shared_w[px] = t;
+        adabelief_step(hv, m, sv, t + gr, lr, bc1, bc2, A.ab);
+        A.h[px] = hv;
+        A.mh[px] = m;
+        A.sh[px] = sv;
+      }
+      __syncthreads();  // the partial sums in LDS are rewritten by the next tile
     }
     return;
   }

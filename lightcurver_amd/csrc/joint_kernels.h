@@ -1156,8 +1156,11 @@ __device__ __forceinline__ float ld_coherent(const float *p, bool coherent) {
   return coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
 
+// (no contraction into fused multiply-adds here: several kernels apply this step - fused and split update, single-workgroup
+//  and multi-block form - and their results are required to agree bit for bit, whatever the surrounding code looks like)
 __device__ __forceinline__ float adabelief_step(float &p, float &m, float &s, float g, float lr, float bc1, float bc2,
                                                 const lc_adabelief_cfg &ab) {
+#pragma clang fp contract(off)
   const float mn = ab.b1 * m + (1.f - ab.b1) * g;
   const float dg = g - mn;
   const float sn = ab.b2 * s + (1.f - ab.b2) * dg * dg + ab.eps_root;
