@@ -392,6 +392,8 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
   A.lam_pts = j->cfg.lam_pts_source;
   A.Z = j->mr_Z;
   A.l1p = j->mr_l1;
+  if (const char *dly = std::getenv("LCMI_REG_DELAY_US"))  // test hook: a chain that finishes after the epoch kernel
+    hipLaunchKernelGGL(mreg_delay_kernel, dim3(1), dim3(64), 0, stream, (long long)(std::atof(dly) * 100.0));  // wall_clock64: 100 MHz
   if (with_pts)
     hipLaunchKernelGGL(mreg_pbar_kernel, dim3(nb), dim3(kGmThreads), 0, stream, N, j->ss, j->E, j->M, j->par[LC_P_A],
                        j->par[LC_P_CX], j->par[LC_P_CY], j->mr_pbar);

@@ -287,4 +287,11 @@ __global__ void mreg_regs_kernel(int J, int l1_on, int has_pts, int nblocks, int
   }
 }
 
+// test hook (LCMI_REG_DELAY_US): holds the second stream back in front of the chain, so that the update kernel of the
+// iteration really has to wait for the chain's completion flag
+__global__ void mreg_delay_kernel(long long ticks) {  // ticks of the constant 100 MHz counter
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 }  // namespace lc

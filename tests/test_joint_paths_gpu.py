@@ -98,6 +98,18 @@ def test_flag_synchronised_update_equals_the_event_synchronised_one(ctx):
         np.testing.assert_array_equal(a[1][k], b[1][k])
 
 
+def test_update_waits_for_a_regulariser_chain_that_runs_late(ctx):
+    """The fused update reads the regulariser's completion flag in the kernel.  Normally the chain is done before the
+    epoch kernel ends and nothing waits; LCMI_REG_DELAY_US holds the second stream back by 300 us per iteration (five epoch
+    kernels), so every update of this fit really waits in the kernel - with its blocks resident - and the chain must
+    still find room to run.  Same numbers as the undelayed fit, and no time-out."""
+    ds = make_roi_dataset(E=8, M=2, n=64, ss=2, seed=104)
+    a = _fit(ctx, ds, 2, 30)
+    b = _fit(ctx, ds, 2, 30, env={'LCMI_REG_DELAY_US': '300'})
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1]['h'], b[1]['h'])
+
+
 def test_c5_at_its_full_epoch_count(ctx):
     """BASELINE.json configs[4] on one GPU: 1000 epochs x 128 x 128, 4 point sources + background, everything free."""
     E, M, n, T = 1000, 4, 128, 6
