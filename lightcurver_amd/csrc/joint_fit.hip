@@ -28,6 +28,8 @@ struct JointVariant {
   int u_thr, u_lds;
   bool gspec;
   epoch_fn ek_aux;  // plain convolution / spectrum modes of the same pipeline (noise propagation)
+  epoch_fn ek_tile = nullptr;  // global-spectrum kernels: the variant whose column passes go through an LDS tile
+  int e_lds_tile = 0;
 };
 
 typedef void (*mreg_fn)(MregArgs);
@@ -111,7 +113,9 @@ JointVariant make_jv() {
 template <int N, int SS, int L, int NW, int LPF = 16>
 JointVariant make_jv_gm() {
   typedef JointCfg<N, SS, L, NW, true, LPF> C;
-  return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, nullptr, 0, 0, true, joint_epoch_kernel<C, true>};
+  typedef JointCfg<N, SS, L, NW, true, LPF, true> CT;
+  return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, nullptr, 0, 0, true, joint_epoch_kernel<C, true>,
+                      joint_epoch_kernel<CT>, CT::LDS_BYTES};
 }
 int g_debug_global = 0;  // lc_joint_set_debug_global: small stamps through the large-grid kernels (parity tests)
 const JointVariant *find_jv(int n, int ss) {
@@ -263,8 +267,14 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
       return 0;
     }
   }
-  LC_HIP(j->ctx, hipFuncSetAttribute((const void *)v->ek, hipFuncAttributeMaxDynamicSharedMemorySize, v->e_lds));
-  hipLaunchKernelGGL(v->ek, dim3(j->E), dim3(v->e_thr), v->e_lds, j->ctx->stream, A);
+  // global-spectrum kernels: past ~150 workgroups in flight the 8 / 16-byte column accesses saturate L2 / Infinity Cache and
+  // the LDS-tile variant of the column passes wins (LCMI_TILE_COLS=0/1 overrides the choice)
+  bool tile = v->ek_tile && j->E >= 160;
+  if (const char *tc = std::getenv("LCMI_TILE_COLS")) tile = v->ek_tile && std::atoi(tc) != 0;
+  epoch_fn ek = tile ? v->ek_tile : v->ek;
+  const int e_lds = tile ? v->e_lds_tile : v->e_lds;
+  LC_HIP(j->ctx, hipFuncSetAttribute((const void *)ek, hipFuncAttributeMaxDynamicSharedMemorySize, e_lds));
+  hipLaunchKernelGGL(ek, dim3(j->E), dim3(v->e_thr), e_lds, j->ctx->stream, A);
   LC_HIP(j->ctx, hipGetLastError());
   return A.need_hgrad;
 }

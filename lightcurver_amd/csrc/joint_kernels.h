@@ -69,8 +69,9 @@ __device__ __forceinline__ float bilinear_h(const float *h, float Xs, float Ys, 
   return top + fy * (bot - top);
 }
 
-template <int N_, int SS_, int L_, int NW_, bool GSPEC_ = false, int LPF_ = 16>
+template <int N_, int SS_, int L_, int NW_, bool GSPEC_ = false, int LPF_ = 16, bool TILECOLS_ = false>
 struct JointCfg {
+  static constexpr bool TILECOLS = TILECOLS_ && GSPEC_;  // column passes through an LDS tile (see OFF_TILE below)
   static constexpr int N = N_, SS = SS_, L = L_, n = N / SS;
   // lanes per transform (fft_device.h) and transforms side by side in a wave
   static constexpr int LPF = LPF_, GPW = 64 / LPF_;
@@ -104,7 +105,14 @@ struct JointCfg {
   static constexpr bool ROWPIPE = (NW_ <= 8);
   static constexpr int OFF_TWH = OFF_TAB + SZ_TAB;
   static constexpr int SZ_TWH = FOLD ? (L / 2 + L / 2 + 1) : 0;
-  static constexpr int LDS_BYTES = (OFF_TWH + SZ_TWH) * 8;
+  // GSPEC: the column passes can stage the NW * GPW spectrum columns of a sweep through an LDS tile [N][CPS + 1]: every
+  // global access then moves whole 128-byte lines instead of 8 or 16 bytes of a line per lane.  Three more barriers per
+  // sweep: slower while few workgroups run (C5 shard, 125 epochs: +3 %), faster once the column traffic of 200+
+  // workgroups saturates L2 / Infinity Cache: a kernel variant of its own (TILECOLS), chosen by the host from the epoch count.
+  static constexpr int CPS = NW * GPW, TP = CPS + 1;
+  static constexpr int OFF_TILE = OFF_TWH + SZ_TWH;
+  static constexpr int SZ_TILE = TILECOLS ? N * TP : 0;
+  static constexpr int LDS_BYTES = (OFF_TILE + SZ_TILE) * 8;
   static_assert(!WSQ || 2 * L >= 3 * N, "row buffer holds three rows of h");
   static constexpr int CREF = (N - 1) / 2;
   static_assert(N % 2 == 0, "row pairs");
@@ -358,6 +366,61 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       }
     }
   };
+  // LDS-tile form of the column access (GSPEC kernels built with TILECOLS): columns kt .. kt + CPS - 1 of the global spectrum
+  // <-> tile, by every thread (the DC / Nyquist pair is packed into column 0 on the way in and separated on the way out)
+  float2 *TILE = lds2 + C::OFF_TILE;
+  constexpr int CPS = C::CPS, TP = C::TP;
+  constexpr int TPT = (N * CPS + C::NTHR - 1) / C::NTHR;  // tile elements per thread
+  auto tile_in = [&](int kt) {
+    float2 v[TPT];
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) {  // all loads first: one latency per tile
+      const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS, kc = kt + c;
+      v[q] = make_float2(0.f, 0.f);
+      if (i < N * CPS && kc < NCOL) v[q] = SPEC[r * KH + kc];
+    }
+    if (kt == 0) {
+#pragma unroll
+      for (int q = 0; q < TPT; ++q) {
+        const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS;
+        if (i < N * CPS && c == 0) v[q].y = SPEC[r * KH + L / 2].x;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) {
+      const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS;
+      if (i < N * CPS) TILE[r * TP + c] = v[q];
+    }
+  };
+  auto tile_out = [&](int kt) {
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) {
+      const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS, kc = kt + c;
+      if (i < N * CPS && kc < NCOL) {
+        const float2 v = TILE[r * TP + c];
+        if (kc == 0) {
+          SPEC[r * KH] = make_float2(v.x, 0.f);
+          SPEC[r * KH + L / 2] = make_float2(v.y, 0.f);
+        } else {
+          SPEC[r * KH + kc] = v;
+        }
+      }
+    }
+  };
+  auto tile_load_column = [&](float2 (&x)[N2], int c, bool active, int row_off) {
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) {
+      const int r = l16 + LPF * n2 - row_off;
+      x[n2] = (active && r >= 0 && r < N) ? TILE[r * TP + c] : make_float2(0.f, 0.f);
+    }
+  };
+  auto tile_store_column = [&](const float2 (&x)[N2], int c, bool active, int row_off) {
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) {
+      const int r = l16 + LPF * n2 - row_off;
+      if (active && r >= 0 && r < N) TILE[r * TP + c] = x[n2];
+    }
+  };
   // x (block layout) *= PSF spectrum of column kc (conjugated for the adjoint); the packed column first splits
   // into its two Hermitian parts, each multiplied by its own spectrum column, and is packed again
   auto times_spectrum = [&](float2 (&x)[N2], const float2 (&sv)[N2], const float2 *Ste, int kc, bool conj) {
@@ -498,7 +561,9 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   }
   // ---- phase B: columns: FFT, multiply by the PSF spectrum, inverse FFT, keep the 'same' window ----
   const float2 *Ste = A.St + (size_t)e * KH * L;
-  for (int kc0 = wid * GPW; kc0 < NCOL; kc0 += C::NW * GPW) {
+  for (int kt = 0; kt < NCOL; kt += C::NW * GPW) {  // one sweep: NW * GPW consecutive columns
+    const int kc0 = kt + wid * GPW;
+    if (!C::TILECOLS && kc0 >= NCOL) break;  // (the tile form has workgroup barriers inside: every wave makes every sweep)
     const int kc = kc0 + qid;
     const bool active = kc < NCOL;
     const int kcs = active ? kc : 1;
@@ -507,7 +572,16 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 #pragma unroll
     for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)kcs * L + kbase + k2];
     const bool paired = PAIRCOL && kc0 != 0;  // (the packed DC / Nyquist column takes the element-wise form)
-    if (paired) pair_load_columns(x, kc0, active, 0); else load_column(x, kcs, active, 0);
+    constexpr bool tiled = C::TILECOLS;
+    if (tiled) {
+      tile_in(kt);
+      __syncthreads();
+      tile_load_column(x, wid * GPW + qid, active, 0);
+    } else if (paired) {
+      pair_load_columns(x, kc0, active, 0);
+    } else {
+      load_column(x, kcs, active, 0);
+    }
     LC_JSTAMP(10);
     group_fft_fwd<L, LPF, true>(x, l16, TW);
     LC_JSTAMP(11);
@@ -515,7 +589,16 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     LC_JSTAMP(12);
     group_fft_inv<L, LPF, true>(x, l16, TW);
     LC_JSTAMP(13);
-    if (paired) pair_store_columns(x, kc0, active, CREF); else store_column(x, kcs, active, CREF);
+    if (tiled) {
+      tile_store_column(x, wid * GPW + qid, active, CREF);
+      __syncthreads();
+      tile_out(kt);
+      __syncthreads();
+    } else if (paired) {
+      pair_store_columns(x, kc0, active, CREF);
+    } else {
+      store_column(x, kcs, active, CREF);
+    }
     LC_JSTAMP(14);
   }
   __syncthreads();
@@ -741,7 +824,9 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   __syncthreads();
   LC_JSTAMP(4);
   // ---- phase B': adjoint columns (rows sit at offset CREF), multiply by conj(spectrum) ------------
-  for (int kc0 = wid * GPW; kc0 < NCOL; kc0 += C::NW * GPW) {
+  for (int kt = 0; kt < NCOL; kt += C::NW * GPW) {
+    const int kc0 = kt + wid * GPW;
+    if (!C::TILECOLS && kc0 >= NCOL) break;
     const int kc = kc0 + qid;
     const bool active = kc < NCOL;
     const int kcs = active ? kc : 1;
@@ -749,11 +834,29 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 #pragma unroll
     for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)kcs * L + kbase + k2];
     const bool paired = PAIRCOL && kc0 != 0;
-    if (paired) pair_load_columns(x, kc0, active, CREF); else load_column(x, kcs, active, CREF);
+    constexpr bool tiled = C::TILECOLS;
+    if (tiled) {
+      tile_in(kt);
+      __syncthreads();
+      tile_load_column(x, wid * GPW + qid, active, CREF);
+    } else if (paired) {
+      pair_load_columns(x, kc0, active, CREF);
+    } else {
+      load_column(x, kcs, active, CREF);
+    }
     group_fft_fwd<L, LPF, true>(x, l16, TW);
     times_spectrum(x, sv, Ste, kcs, true);
     group_fft_inv<L, LPF, true>(x, l16, TW);
-    if (paired) pair_store_columns(x, kc0, active, 0); else store_column(x, kcs, active, 0);
+    if (tiled) {
+      tile_store_column(x, wid * GPW + qid, active, 0);
+      __syncthreads();
+      tile_out(kt);
+      __syncthreads();
+    } else if (paired) {
+      pair_store_columns(x, kc0, active, 0);
+    } else {
+      store_column(x, kcs, active, 0);
+    }
   }
   __syncthreads();
   LC_JSTAMP(5);
