@@ -98,6 +98,17 @@ def test_flag_synchronised_update_equals_the_event_synchronised_one(ctx):
         np.testing.assert_array_equal(a[1][k], b[1][k])
 
 
+def test_tiled_column_passes_equal_the_direct_ones(ctx):
+    """128 x 128 ROIs keep the spectrum of an epoch in global memory; from 160 epochs up the column passes stage it through
+    an LDS tile (LCMI_TILE_COLS forces either form).  Only the data movement differs; the two are separate kernel builds,
+    so the compiler's choice of fused multiply-adds may differ in the last bit."""
+    ds = make_roi_dataset(E=3, M=4, n=128, ss=2, seed=104)
+    a = _fit(ctx, ds, 4, 12, env={'LCMI_TILE_COLS': '0'})
+    b = _fit(ctx, ds, 4, 12, env={'LCMI_TILE_COLS': '1'})
+    assert np.max(np.abs(a[0] - b[0]) / np.abs(b[0])) < 1e-6
+    _compare(a, b, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 12, 1e-4)
+
+
 def test_update_waits_for_a_regulariser_chain_that_runs_late(ctx):
     """The fused update reads the regulariser's completion flag in the kernel.  Normally the chain is done before the
     epoch kernel ends and nothing waits; LCMI_REG_DELAY_US holds the second stream back by 300 us per iteration (five epoch
