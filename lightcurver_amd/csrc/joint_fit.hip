@@ -267,9 +267,10 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
       return 0;
     }
   }
-  // global-spectrum kernels: past ~150 workgroups in flight the 8 / 16-byte column accesses saturate L2 / Infinity Cache and
-  // the LDS-tile variant of the column passes wins (LCMI_TILE_COLS=0/1 overrides the choice)
-  bool tile = v->ek_tile && j->E >= 160;
+  // global-spectrum kernels: with many workgroups in flight the 8 / 16-byte column accesses saturate L2 / Infinity Cache and
+  // the LDS-tile variant of the column passes wins (128 x 128 ROIs: 32 epochs +1.4 %, 64 +-0, 125 -1 %, 160 -7 %, 200 -16 %,
+  // 1000 -15 %; LCMI_TILE_COLS=0/1 overrides the choice)
+  bool tile = v->ek_tile && j->E >= 96;
   if (const char *tc = std::getenv("LCMI_TILE_COLS")) tile = v->ek_tile && std::atoi(tc) != 0;
   epoch_fn ek = tile ? v->ek_tile : v->ek;
   const int e_lds = tile ? v->e_lds_tile : v->e_lds;

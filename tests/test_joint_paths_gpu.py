@@ -99,7 +99,7 @@ def test_flag_synchronised_update_equals_the_event_synchronised_one(ctx):
 
 
 def test_tiled_column_passes_equal_the_direct_ones(ctx):
-    """128 x 128 ROIs keep the spectrum of an epoch in global memory; from 160 epochs up the column passes stage it through
+    """128 x 128 ROIs keep the spectrum of an epoch in global memory; from 96 epochs up the column passes stage it through
     an LDS tile (LCMI_TILE_COLS forces either form).  Only the data movement differs; the two are separate kernel builds,
     so the compiler's choice of fused multiply-adds may differ in the last bit."""
     ds = make_roi_dataset(E=3, M=4, n=128, ss=2, seed=104)
