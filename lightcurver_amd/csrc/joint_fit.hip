@@ -198,12 +198,12 @@ bool reg_h_on(const lc_joint *j) {
 }
 
 typedef void (*ps_fn)(JointPsArgs);
-void find_ps_kernel(int N, int ss, ps_fn *fn, int *lds) {
+void find_ps_kernel(int N, int ss, ps_fn *fn, int *lds, bool persist = false) {
   *fn = nullptr;
-#define LC_PS(NN_, SS_)                          \
-  if (N == NN_ && ss == SS_) {                   \
-    *fn = joint_ps_kernel<NN_, SS_>;             \
-    *lds = joint_ps_lds_bytes<NN_, SS_>();       \
+#define LC_PS(NN_, SS_)                                                                   \
+  if (N == NN_ && ss == SS_) {                                                            \
+    *fn = persist ? joint_ps_kernel<NN_, SS_, true> : joint_ps_kernel<NN_, SS_, false>;   \
+    *lds = joint_ps_lds_bytes<NN_, SS_>();                                                \
   }
   LC_PS(16, 1)
   LC_PS(32, 2)
@@ -1030,11 +1030,94 @@ int lc_joint_deconvolved(lc_joint *j, int epoch, float *scene, float *background
   return LC_OK;
 }
 
+// Every free parameter belongs to one epoch and nothing couples the epochs (fluxes, shifts, sky levels free; the shared
+// positions fixed, no background, no flux-uniformity / point-source / prior term - e.g. photometry at known positions;
+// the reference's default star photometry frees c_x, c_y and does not qualify): the loop runs inside ONE launch of the
+// point-source-only kernel (csrc/joint_ps.h, PERSIST), then the per-epoch losses are summed.
+static int run_adabelief_persistent(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg, bool *done) {
+  *done = false;
+  const bool coupled = j->free_mask[LC_P_H] || j->h_nonzero || j->free_mask[LC_P_CX] || j->free_mask[LC_P_CY] ||
+                       j->free_mask[LC_P_ALPHA] || j->cfg.lam_flux_uniformity != 0.f || j->cfg.lam_pts_source != 0.f ||
+                       j->n_prior > 0;
+  const bool any_free = j->free_mask[LC_P_A] || j->free_mask[LC_P_DX] || j->free_mask[LC_P_DY] || j->free_mask[LC_P_MEAN];
+  if (coupled || !any_free || j->M <= 0 || j->M > kMaxSources || !j->psf_dev || std::getenv("LCMI_JOINT_FFT_ONLY") ||
+      std::getenv("LCMI_PS_LOOP"))
+    return LC_OK;
+  ps_fn pk = nullptr;
+  int plds = 0;
+  find_ps_kernel(j->N, j->ss, &pk, &plds, true);
+  if (!pk) return LC_OK;
+  int rc;
+  if (!j->psF && (rc = dmalloc(j, &j->psF, (size_t)j->E * j->M * 3 * j->n * j->n))) return rc;
+  hipStream_t q = j->ctx->stream;
+  lc_adabelief_cfg ab;
+  if (cfg) ab = *cfg; else lc_adabelief_defaults(&ab);
+  std::vector<float> sched((size_t)n_iter * 3);
+  for (int t = 0; t < n_iter; ++t) adabelief_schedule(ab, j->iters_done + t, sched[3 * t], sched[3 * t + 1], sched[3 * t + 2]);
+  float *d_sched = nullptr, *d_hist_e = nullptr;
+  LC_HIP(j->ctx, hipMalloc((void **)&d_sched, sched.size() * sizeof(float)));
+  struct DevGuard {
+    void *p;
+    ~DevGuard() { (void)hipFree(p); }
+  } g1{d_sched};
+  LC_HIP(j->ctx, hipMalloc((void **)&d_hist_e, (size_t)j->E * n_iter * sizeof(float)));
+  DevGuard g2{d_hist_e};
+  LC_HIP(j->ctx, hipMemcpyAsync(d_sched, sched.data(), sched.size() * sizeof(float), hipMemcpyHostToDevice, q));
+  JointPsArgs P;
+  std::memset(&P, 0, sizeof(P));
+  JointArgs &A = P.J;
+  A.E = j->E;
+  A.M = j->M;
+  A.mode = 0;
+  A.data = j->data;
+  A.wgt = j->wgt;
+  A.a = j->par[LC_P_A];
+  A.cx = j->par[LC_P_CX];
+  A.cy = j->par[LC_P_CY];
+  A.dx = j->par[LC_P_DX];
+  A.dy = j->par[LC_P_DY];
+  A.alpha = j->par[LC_P_ALPHA];
+  A.mean = j->par[LC_P_MEAN];
+  P.psf = j->psf_dev;
+  P.F = j->psF;
+  P.T = n_iter;
+  P.sched = d_sched;
+  P.ab = ab;
+  P.free_a = j->free_mask[LC_P_A];
+  P.free_dx = j->free_mask[LC_P_DX];
+  P.free_dy = j->free_mask[LC_P_DY];
+  P.free_mean = j->free_mask[LC_P_MEAN];
+  P.lam_pos_ps = j->cfg.lam_positivity_ps;
+  P.par_a = j->par[LC_P_A];
+  P.par_dx = j->par[LC_P_DX];
+  P.par_dy = j->par[LC_P_DY];
+  P.par_mean = j->par[LC_P_MEAN];
+  P.pm_a = j->pm[LC_P_A];
+  P.ps_a = j->ps[LC_P_A];
+  P.pm_dx = j->pm[LC_P_DX];
+  P.ps_dx = j->ps[LC_P_DX];
+  P.pm_dy = j->pm[LC_P_DY];
+  P.ps_dy = j->ps[LC_P_DY];
+  P.pm_mean = j->pm[LC_P_MEAN];
+  P.ps_mean = j->ps[LC_P_MEAN];
+  P.hist_e = d_hist_e;
+  LC_HIP(j->ctx, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
+  hipLaunchKernelGGL(pk, dim3(j->E), dim3(kPsThreads), plds, q, P);
+  hipLaunchKernelGGL(joint_ps_hist_kernel, dim3(n_iter), dim3(64), 0, q, j->E, n_iter, d_hist_e, j->hist + j->iters_done);
+  LC_HIP(j->ctx, hipGetLastError());
+  LC_HIP(j->ctx, hipStreamSynchronize(q));  // the two temporaries go out of scope
+  j->iters_done += n_iter;
+  *done = true;
+  return LC_OK;
+}
+
 int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg) {
   if (!j || n_iter <= 0) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
   int rc = ensure_hist(j, j->iters_done + n_iter + 2);
   if (rc) return rc;
+  bool done = false;
+  if ((rc = run_adabelief_persistent(j, n_iter, cfg, &done)) || done) return rc;
   j->in_device_loop = true;
   bool flags_used = false;
   for (int it = 0; it < n_iter && !rc; ++it) {

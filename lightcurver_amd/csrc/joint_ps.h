@@ -44,9 +44,24 @@ struct JointPsArgs {
   JointArgs J;
   const float *psf;  // [E][N][N] narrow PSFs
   float *F;          // [E][M][3][n*n] scratch: value, d/dX, d/dY filter outputs of every source
+  // persistent form (PERSIST = true): T AdaBelief iterations of this epoch's own parameters inside one launch
+  int T;
+  const float *sched;                  // [T][3] learning rate and bias corrections of every iteration (host, adabelief_schedule)
+  lc_adabelief_cfg ab;
+  int free_a, free_dx, free_dy, free_mean;
+  float lam_pos_ps;
+  float *par_a, *par_dx, *par_dy, *par_mean;  // [E*M], [E], [E], [E]: read at the start, written at the end
+  float *pm_a, *ps_a, *pm_dx, *ps_dx, *pm_dy, *ps_dy, *pm_mean, *ps_mean;  // AdaBelief moments, same shapes
+  float *hist_e;                       // [E][T] this epoch's share of the loss before every update
 };
 
-template <int N, int SS>
+// PERSIST: when every free parameter belongs to one epoch (fluxes, shifts, sky levels; the shared positions c_x, c_y held
+// fixed - the reference's default star photometry leaves them free and takes the launch-per-iteration form - and no
+// flux-uniformity / point-source / prior term) the epochs are independent fits, and the whole
+// optimisation loop runs inside this kernel: the PSF tile stays in LDS, the parameters and their AdaBelief moments in
+// LDS / registers, and the loss history leaves as one value per epoch and iteration (summed over the epochs afterwards).
+// Same arithmetic per iteration as the launch-per-iteration form (same filters, same reductions, same update).
+template <int N, int SS, bool PERSIST = false>
 __global__ __launch_bounds__(kPsThreads) void joint_ps_kernel(JointPsArgs P) {
   constexpr int n = N / SS, NT = ntaps(SS), TS = N + 1, RS = n + 1, nn = n * n, NWV = kPsThreads / 64;
   constexpr int NQ = 4 + 3 * kMaxSources;
@@ -61,10 +76,37 @@ __global__ __launch_bounds__(kPsThreads) void joint_ps_kernel(JointPsArgs P) {
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, M = A.M;
   const float c0 = (N - 1) * 0.5f, c_off = c0 - (float)((N - 1) / 2);
   const float al = A.alpha[e] * 0.017453292519943295f;
-  const float ca = cosf(al), sa = sinf(al), dxe = A.dx[e], dye = A.dy[e], meane = A.mean[e];
+  const float ca = cosf(al), sa = sinf(al);
+  float dxe = A.dx[e], dye = A.dy[e], meane = A.mean[e];
   const float *se = P.psf + (size_t)e * N * N;
   for (int k = tid; k < N * N; k += kPsThreads) Sx[(k / N) * TS + (k % N)] = se[k];
   float *Fe = P.F + (size_t)e * M * 3 * nn;
+  // persistent form: parameters [a_0 .. a_{M-1}, dx, dy, mean] and their moments, one thread each
+  __shared__ float PP[kMaxSources + 3];
+  float my_p = 0.f, my_m = 0.f, my_s = 0.f;
+  bool my_free = false;
+  if constexpr (PERSIST) {
+    if (tid < M + 3) {
+      const int k = tid - M;  // < 0: flux tid
+      const float *src = (k < 0) ? P.par_a + e * M + tid : (k == 0 ? P.par_dx + e : (k == 1 ? P.par_dy + e : P.par_mean + e));
+      const float *sm = (k < 0) ? P.pm_a + e * M + tid : (k == 0 ? P.pm_dx + e : (k == 1 ? P.pm_dy + e : P.pm_mean + e));
+      const float *sv = (k < 0) ? P.ps_a + e * M + tid : (k == 0 ? P.ps_dx + e : (k == 1 ? P.ps_dy + e : P.ps_mean + e));
+      my_p = *src;
+      my_m = *sm;
+      my_s = *sv;
+      my_free = (k < 0) ? P.free_a != 0 : (k == 0 ? P.free_dx != 0 : (k == 1 ? P.free_dy != 0 : P.free_mean != 0));
+      PP[tid] = my_p;
+    }
+  }
+  const int n_it = PERSIST ? P.T : 1;
+  for (int iter = 0; iter < n_it; ++iter) {
+  if constexpr (PERSIST) {
+    __syncthreads();  // parameters of this iteration in PP; the previous iteration's readers of TOT / R are done
+    dxe = PP[M];
+    dye = PP[M + 1];
+    meane = PP[M + 2];
+  }
+  auto flux = [&](int i) { return PERSIST ? PP[i] : A.a[e * M + i]; };
   for (int i = 0; i < M; ++i) {
     __syncthreads();  // PSF tile loaded; previous source's passes done with TAP / R
     if (tid < 2 * NT) {
@@ -128,7 +170,7 @@ __global__ __launch_bounds__(kPsThreads) void joint_ps_kernel(JointPsArgs P) {
       continue;
     }
     float model = meane;
-    for (int i = 0; i < M; ++i) model = fmaf(A.a[e * M + i], Fe[((size_t)i * 3) * nn + px], model);
+    for (int i = 0; i < M; ++i) model = fmaf(flux(i), Fe[((size_t)i * 3) * nn + px], model);
     if (A.model_out) A.model_out[(size_t)e * nn + px] = model;
     const float res = model - de[px], rw = w * res;
     vals[0] = fmaf(rw, res, vals[0]);
@@ -159,6 +201,34 @@ __global__ __launch_bounds__(kPsThreads) void joint_ps_kernel(JointPsArgs P) {
     TOT[tid] = acc;
   }
   __syncthreads();
+  if constexpr (PERSIST) {
+    // gradient of this thread's parameter (the rules of gm_small_blocks, joint_gm.h), loss share, AdaBelief step
+    if (tid < M + 3) {
+      const int k = tid - M;
+      float g;
+      if (k < 0) {
+        g = TOT[4 + 3 * tid];
+        if (P.lam_pos_ps != 0.f && my_p < 0.f) g -= P.lam_pos_ps;
+      } else if (k == 2) {
+        g = TOT[1];
+      } else {
+        g = 0.f;
+        for (int i = 0; i < M; ++i) g += SS * (PP[i] * TOT[(k == 0 ? 5 : 6) + 3 * i]);
+      }
+      if (tid == 0) {
+        float loss = 0.5f * TOT[0];
+        if (P.lam_pos_ps != 0.f)
+          for (int i = 0; i < M; ++i) loss += (PP[i] < 0.f) ? -P.lam_pos_ps * PP[i] : 0.f;
+        P.hist_e[(size_t)e * P.T + iter] = loss;
+      }
+      __builtin_amdgcn_wave_barrier();  // (threads 0 .. M + 2 sit in one wave: everyone has read PP before anyone rewrites it)
+      if (my_free) {
+        adabelief_step(my_p, my_m, my_s, g, P.sched[3 * iter], P.sched[3 * iter + 1], P.sched[3 * iter + 2], P.ab);
+        PP[tid] = my_p;
+      }
+    }
+    continue;
+  }
   if (tid == 0) {
     if (A.mode == 2) {
       A.fisher_out[e * M + A.isrc] = 1.0f / sqrtf(TOT[0]);
@@ -180,6 +250,27 @@ __global__ __launch_bounds__(kPsThreads) void joint_ps_kernel(JointPsArgs P) {
     A.g_dx[e] = gdx;
     A.g_dy[e] = gdy;
   }
+  }  // iterations
+  if constexpr (PERSIST) {
+    if (tid < M + 3) {
+      const int k = tid - M;
+      float *dst = (k < 0) ? P.par_a + e * M + tid : (k == 0 ? P.par_dx + e : (k == 1 ? P.par_dy + e : P.par_mean + e));
+      float *dm = (k < 0) ? P.pm_a + e * M + tid : (k == 0 ? P.pm_dx + e : (k == 1 ? P.pm_dy + e : P.pm_mean + e));
+      float *dv = (k < 0) ? P.ps_a + e * M + tid : (k == 0 ? P.ps_dx + e : (k == 1 ? P.ps_dy + e : P.ps_mean + e));
+      *dst = my_p;
+      *dm = my_m;
+      *dv = my_s;
+    }
+  }
+}
+
+// hist[t0 + it] = sum over the epochs of hist_e[e][it] (lanes stride over the epochs, fixed combine order)
+__global__ void joint_ps_hist_kernel(int E, int T, const float *hist_e, float *hist) {
+  const int it = blockIdx.x, lane = threadIdx.x;
+  float acc = 0.f;
+  for (int e = lane; e < E; e += 64) acc += hist_e[(size_t)e * T + it];
+  acc = wave_sum_shfl(acc);
+  if (lane == 0) hist[it] = acc;
 }
 
 template <int N, int SS>

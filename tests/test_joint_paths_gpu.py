@@ -98,6 +98,40 @@ def test_flag_synchronised_update_equals_the_event_synchronised_one(ctx):
         np.testing.assert_array_equal(a[1][k], b[1][k])
 
 
+@pytest.mark.parametrize('E,n,M,free', [(7, 32, 1, ('a', 'dx', 'dy', 'mean')), (5, 16, 2, ('a', 'mean')), (3, 64, 1, ('a', 'dx', 'dy'))])
+def test_persistent_star_photometry_loop_equals_the_launch_per_iteration_one(ctx, E, n, M, free):
+    """Photometry at fixed positions (no background, only per-epoch parameters free, nothing coupling the epochs): the whole
+    AdaBelief loop runs inside one launch of the point-source-only kernel (default) or as one kernel pair per iteration
+    (LCMI_PS_LOOP=1; also the form the reference's default star photometry takes, whose shared position is free).
+    Same filters, reductions and update per epoch: identical parameters; the loss history differs only in the order in
+    which the epochs are added."""
+    from lightcurver_amd.joint import JointFit
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=31, with_background=False)
+    out = []
+    for env in ({}, {'LCMI_PS_LOOP': '1'}):
+        os.environ.update(env)
+        try:
+            j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], 2, M, ctx)
+            p = {k: np.asarray(v, dtype=np.float64) for k, v in ds['truth'].items()}
+            p['a'] = 0.8 * p['a']
+            p['h'] = np.zeros_like(p['h'])
+            j.set_params(**p)
+            j.set_loss(lam_positivity_ps=3.0)
+            j.set_free(list(free))
+            j.run_adabelief(60, init_learning_rate=1e-3, schedule_learning_rate=True)
+            j.run_adabelief(40, init_learning_rate=1e-3, schedule_learning_rate=True)   # a second call continues the first
+            out.append((np.asarray(j.loss_history(), dtype=np.float64), {k: np.asarray(v) for k, v in j.get_params().items()}))
+            j.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    (ha, pa), (hb, pb) = out
+    assert ha.shape == hb.shape == (101,)
+    assert np.max(np.abs(ha - hb) / np.abs(hb)) < 2e-6 and ha[-1] < ha[0]
+    for k in ('a', 'dx', 'dy', 'mean'):
+        np.testing.assert_array_equal(pa[k], pb[k])
+
+
 def test_tiled_column_passes_equal_the_direct_ones(ctx):
     """128 x 128 ROIs keep the spectrum of an epoch in global memory; from 96 epochs up the column passes stage it through
     an LDS tile (LCMI_TILE_COLS forces either form).  Only the data movement differs; the two are separate kernel builds,
