@@ -66,7 +66,7 @@ class Optimizer:
         flat = {k: np.asarray(v, dtype=np.float64) for k, v in final.items()}
         p.set_best_fit(flat)
         # loss_history[t] = loss after update t (len == the number of iterations run: max_iterations without early stop)
-        self.loss_history = [float(v) for v in hist[1:]]
+        self.loss_history = np.asarray(hist[1:], dtype=np.float64).tolist()
         extra = {'loss_history': np.array(self.loss_history), 'initial_loss': float(hist[0])}
         if return_param_history:
             extra['param_history'] = param_history
@@ -91,7 +91,7 @@ class Optimizer:
             hist, nit, nev = fit.run_lbfgs(int(maxiter), lower, upper)
             flat = {k: np.asarray(v, dtype=np.float64) for k, v in fit.get_params().items()}
             p.set_best_fit(flat)
-            self.loss_history = [float(v) for v in hist]
+            self.loss_history = np.asarray(hist, dtype=np.float64).tolist()
             return p.best_fit_values(), -float(hist[-1]), {'loss_history': np.array(self.loss_history),
                                                            'iterations': nit, 'evaluations': nev}
         hist, last = [], {}

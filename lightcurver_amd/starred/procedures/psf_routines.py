@@ -135,7 +135,7 @@ def build_psf_batch(images, noisemaps, subsampling_factor, masks=None, n_iter_an
             'chi2': float(res['chi2'][f]),
             'norm': norms[f],
             'analytic_extra_fields': {'final_loss': None if analytic_loss is None else float(analytic_loss[f])},
-            'adabelief_extra_fields': {'loss_history': [float(v) for v in hist[f, 1:]],
+            'adabelief_extra_fields': {'loss_history': hist[f, 1:].astype(np.float64).tolist(),
                                        'initial_loss': float(hist[f, 0])},
         })
     return out
@@ -292,7 +292,7 @@ def _fit_with_distortion(images, data, weight, norms, stars, moffat, S_list, coo
             'full_psf': res_f['full_psf'][f], 'narrow_psf': res_f['narrow_psf'][f],
             'models': np.asarray(images[f], dtype=np.float64) - resid, 'residuals': resid, 'kwargs_psf': kwargs_psf,
             'chi2': chi2, 'norm': norms[f], 'analytic_extra_fields': {'final_loss': float(fl[f])},
-            'adabelief_extra_fields': {'loss_history': [float(v) for v in hist[f, 1:]], 'initial_loss': float(hist[f, 0])},
+            'adabelief_extra_fields': {'loss_history': hist[f, 1:].astype(np.float64).tolist(), 'initial_loss': float(hist[f, 0])},
         })
     return out
 
