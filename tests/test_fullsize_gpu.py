@@ -126,6 +126,35 @@ def test_c2_frames_are_independent(ctx):
     assert np.all(out[0][0][:, -1] < out[0][0][:, 0])
 
 
+def test_c3_all_500_frames_on_one_gpu(ctx):
+    """C3 at its full frame count on one GPU (500 frames x 8 stars x 64 x 64; the 8-GPU run shards it 63 frames per rank):
+    four rounds of workgroups through the N = 128 kernel.  A frame's fit does not depend on the batch it is in: the last ten
+    frames fitted alone give bit-identical grids, stars and loss histories; every frame's loss decreases."""
+    from lightcurver_amd.psf_batch import PsfBatch
+    F, S, n, ss, T = 500, 8, 64, 2, 40
+    ds = make_psf_dataset(F=F, S=S, n=n, ss=ss, seed=103)
+    w = (ds['masks'] / ds['noisemap'].astype(np.float64) ** 2).astype(np.float32)
+    out = []
+    for sub in (slice(0, F), slice(F - 10, F)):
+        b = PsfBatch(ds['data'][sub], w[sub], ss, ctx)
+        g = ds['fwhm_guess'][sub]
+        f0 = np.sqrt(np.maximum(g * g - 1.0, 1.0))
+        k = len(g)
+        b.set_moffat(np.stack([f0, f0, np.zeros(k), np.full(k, 2.5)], axis=-1))
+        st = np.zeros((k, S, 4), np.float32)
+        st[..., 0] = (ds['data'][sub] * ds['masks'][sub]).sum(axis=(-1, -2))
+        b.set_stars(st)
+        b.set_grid(None)
+        b.propagate_noise()
+        b.set_regularization(None, 1.0, 1.0)
+        b.run_adabelief(T, init_learning_rate=1e-4)
+        out.append((b.loss_history(), b.get_grid(), b.get_stars()))
+        b.close()
+    for a, c in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a[F - 10:], c)
+    assert np.all(np.isfinite(out[0][0])) and np.all(out[0][0][:, -1] < out[0][0][:, 0])
+
+
 def test_c5_sized_epochs_decrease_the_loss(ctx):
     """C5 stamp size (128 x 128 ROI, 4 sources) on 16 epochs: finite, decreasing loss, fluxes move towards the truth."""
     E, M, n = 16, 4, 128
