@@ -61,25 +61,41 @@ int dmalloc(lc_psf_batch *b, T **p, size_t count) {
 }
 
 // ---- Moffat rasterisation and its parameter gradient (double precision, one block per frame) ----
-__device__ inline void moffat_terms(int N, int ss, const float *par, int u, int v, double &M, double dM[4]) {
-  const double fx = par[0], fy = par[1], phi = par[2], beta = par[3];
-  const int c = (N - 1) / 2;
-  const double x = v - c, y = u - c;
-  const double p2 = pow(2.0, 1.0 / beta);
+// (the frame's constants - 2^(1/beta), the axis scales, the rotation - are formed once per thread, not per pixel: the
+//  stage-A optimiser rasterises all frames once per trial point)
+struct MoffatFrame {
+  double beta, ax, ay, cs, sn, s_over_kb, dax_db, day_db;
+  int c;
+};
+__device__ inline MoffatFrame moffat_frame(int N, int ss, const float *par) {
+  MoffatFrame m;
+  const double fx = par[0], fy = par[1], phi = par[2];
+  m.beta = par[3];
+  m.c = (N - 1) / 2;
+  const double p2 = pow(2.0, 1.0 / m.beta);
   const double kb = 2.0 * sqrt(p2 - 1.0);
-  const double ax = ss * fx / kb, ay = ss * fy / kb;
-  const double cs = cos(phi), sn = sin(phi);
-  const double xr = x * cs + y * sn, yr = -x * sn + y * cs;
-  const double A = xr * xr / (ax * ax) + yr * yr / (ay * ay);
-  M = pow(1.0 + A, -beta);
+  m.ax = ss * fx / kb;
+  m.ay = ss * fy / kb;
+  m.cs = cos(phi);
+  m.sn = sin(phi);
+  m.s_over_kb = ss / kb;
+  const double dkb_db = (1.0 / sqrt(p2 - 1.0)) * p2 * log(2.0) * (-1.0 / (m.beta * m.beta));
+  m.dax_db = (-ss * fx / (kb * kb)) * dkb_db;
+  m.day_db = (-ss * fy / (kb * kb)) * dkb_db;
+  return m;
+}
+__device__ inline void moffat_terms(const MoffatFrame &m, int u, int v, double &M, double dM[4]) {
+  const double x = v - m.c, y = u - m.c;
+  const double xr = x * m.cs + y * m.sn, yr = -x * m.sn + y * m.cs;
+  const double A = xr * xr / (m.ax * m.ax) + yr * yr / (m.ay * m.ay);
+  M = pow(1.0 + A, -m.beta);
   const double Mb1 = M / (1.0 + A);  // (1+A)^(-beta-1)
-  const double dM_dax = 2.0 * beta * Mb1 * xr * xr / (ax * ax * ax);
-  const double dM_day = 2.0 * beta * Mb1 * yr * yr / (ay * ay * ay);
-  const double dkb_db = (1.0 / sqrt(p2 - 1.0)) * p2 * log(2.0) * (-1.0 / (beta * beta));
-  dM[0] = dM_dax * ss / kb;
-  dM[1] = dM_day * ss / kb;
-  dM[2] = -beta * Mb1 * 2.0 * xr * yr * (1.0 / (ax * ax) - 1.0 / (ay * ay));
-  dM[3] = -log(1.0 + A) * M + dM_dax * (-ss * fx / (kb * kb)) * dkb_db + dM_day * (-ss * fy / (kb * kb)) * dkb_db;
+  const double dM_dax = 2.0 * m.beta * Mb1 * xr * xr / (m.ax * m.ax * m.ax);
+  const double dM_day = 2.0 * m.beta * Mb1 * yr * yr / (m.ay * m.ay * m.ay);
+  dM[0] = dM_dax * m.s_over_kb;
+  dM[1] = dM_day * m.s_over_kb;
+  dM[2] = -m.beta * Mb1 * 2.0 * xr * yr * (1.0 / (m.ax * m.ax) - 1.0 / (m.ay * m.ay));
+  dM[3] = -log(1.0 + A) * M + dM_dax * m.dax_db + dM_day * m.day_db;
 }
 
 __device__ inline double block_sum_d(double v, double *sh) {
@@ -98,17 +114,17 @@ __device__ inline double block_sum_d(double v, double *sh) {
 __global__ void moffat_raster_kernel(int N, int ss, const float *par, float *Tm) {
   __shared__ double sh[256];
   const int f = blockIdx.x;
-  const float *p = par + f * 4;
+  const MoffatFrame mf = moffat_frame(N, ss, par + f * 4);
   double acc = 0;
   for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
     double M, dM[4];
-    moffat_terms(N, ss, p, i / N, i % N, M, dM);
+    moffat_terms(mf, i / N, i % N, M, dM);
     acc += M;
   }
   const double S = block_sum_d(acc, sh);
   for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
     double M, dM[4];
-    moffat_terms(N, ss, p, i / N, i % N, M, dM);
+    moffat_terms(mf, i / N, i % N, M, dM);
     Tm[(size_t)f * N * N + i] = (float)(M / S);
   }
 }
@@ -116,11 +132,11 @@ __global__ void moffat_raster_kernel(int N, int ss, const float *par, float *Tm)
 __global__ void moffat_grad_kernel(int N, int ss, const float *par, const float *gT, float *gmoffat) {
   __shared__ double sh[256];
   const int f = blockIdx.x;
-  const float *p = par + f * 4;
+  const MoffatFrame mf = moffat_frame(N, ss, par + f * 4);
   double sM = 0, sdM[4] = {0, 0, 0, 0}, gM = 0, gdM[4] = {0, 0, 0, 0};
   for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
     double M, dM[4];
-    moffat_terms(N, ss, p, i / N, i % N, M, dM);
+    moffat_terms(mf, i / N, i % N, M, dM);
     const double g = gT[(size_t)f * N * N + i];
     sM += M;
     gM += g * M;
