@@ -29,10 +29,21 @@ DEFAULT_REGULARIZATION = {  # code fall-backs of the reference (roi_modelling.py
 }
 
 
+def _median_stack(data):
+    """np.nanmedian(data, axis=0); the NaN-free case (the usual one) takes np.median, an order of magnitude faster than
+    numpy's median along a strided axis for (epochs, n, n) stacks (a sort of contiguous rows)."""
+    data = np.asarray(data)
+    if np.isnan(data).any():
+        return np.nanmedian(data, axis=0)
+    E = data.shape[0]
+    s = np.sort(np.ascontiguousarray(data.reshape(E, -1).T), axis=1)     # pixels x epochs, each row contiguous
+    return (0.5 * (s[:, (E - 1) // 2] + s[:, E // 2])).reshape(data.shape[1:])
+
+
 def initial_point_source_fluxes(data, xs, ys, radius):
     """Aperture sums on the median stack (roi_modelling.py:198-204 uses photutils' exact circular
     apertures; this is the pixel-centre version, good enough for a starting point)."""
-    stack = np.nanmedian(data, axis=0)
+    stack = _median_stack(data)
     n = stack.shape[0]
     yy, xx = np.mgrid[0:n, 0:n]
     return [float(np.nansum(stack[(xx - x) ** 2 + (yy - y) ** 2 <= radius ** 2])) for x, y in zip(xs, ys)]
@@ -161,7 +172,7 @@ def sigma_clipped_weighted_stack(data, noisemap, n_sigma=3.0):
     (roi_modelling.py:60-83), written out since ccdproc is not a dependency here."""
     data = np.asarray(data, dtype=np.float64)
     weights = 1.0 / np.asarray(noisemap, dtype=np.float64)
-    med = np.nanmedian(data, axis=0)
+    med = _median_stack(data)
     dev = np.nanstd(data, axis=0)
     keep = np.abs(data - med) <= n_sigma * dev
     keep |= ~np.isfinite(dev)[None]
