@@ -18,6 +18,7 @@
 
 using namespace lc;
 
+constexpr int kMaxParts = 4;  // workgroups per epoch of the phased launches
 typedef void (*epoch_fn)(JointArgs);
 typedef void (*update_fn)(JointUpdArgs);
 struct JointVariant {
@@ -30,6 +31,10 @@ struct JointVariant {
   epoch_fn ek_aux;  // plain convolution / spectrum modes of the same pipeline (noise propagation)
   epoch_fn ek_tile = nullptr;  // global-spectrum kernels: the variant whose column passes go through an LDS tile
   int e_lds_tile = 0;
+  // global-spectrum kernels: one phase (A, B, C, B', C', D) per launch on a grid (E, parts); [1] / [3] also in the tile build
+  epoch_fn ek_phase[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  epoch_fn ek_phase_tile[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int e_lds_lite = 0, e_lds_lite_tile = 0;  // LDS of the column phases and of phase D (JointCfg::LDS_LITE)
 };
 
 typedef void (*mreg_fn)(MregArgs);
@@ -48,6 +53,7 @@ struct lc_joint {
   float *par[LC_P_COUNT] = {}, *pm[LC_P_COUNT] = {}, *ps[LC_P_COUNT] = {}, *gout[LC_P_COUNT] = {};
   int psize[LC_P_COUNT] = {};
   float *tabs = nullptr, *HG = nullptr;
+  float *part = nullptr;  // [E][kMaxParts][4 + 3 kMaxSources] partial sums of phased launches
   float *chi2_e = nullptr, *g_a = nullptr, *g_cx_e = nullptr, *g_cy_e = nullptr, *g_dx = nullptr, *g_dy = nullptr,
         *g_mean = nullptr;
   float *model = nullptr, *fisher = nullptr, *shared = nullptr, *W = nullptr, *norms = nullptr,
@@ -59,7 +65,7 @@ struct lc_joint {
   bool have_W = false, h_nonzero = false;
   lc_joint_loss_cfg cfg{};
   float *greg = nullptr, *regs = nullptr;
-  float2 *spec = nullptr;             // [E][N][KH] spectrum scratch of the large-grid epoch kernel
+  float2 *spec = nullptr;             // [E][N][KS] spectrum scratch of the large-grid epoch kernel
   float *nz_a = nullptr, *nz_b = nullptr, *nz_c = nullptr, *nz_up = nullptr, *nz_scene = nullptr;  // noise propagation [E][N*N]
   float2 *St_alt = nullptr;                                                                        // [E][KH][L]
   float *psf_dev = nullptr, *psF = nullptr;  // point-source-only path: narrow PSFs [E][N*N], filter outputs [E][M][3][n*n]
@@ -114,8 +120,19 @@ template <int N, int SS, int L, int NW, int LPF = 16>
 JointVariant make_jv_gm() {
   typedef JointCfg<N, SS, L, NW, true, LPF> C;
   typedef JointCfg<N, SS, L, NW, true, LPF, true> CT;
-  return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, nullptr, 0, 0, true, joint_epoch_kernel<C, true>,
-                      joint_epoch_kernel<CT>, CT::LDS_BYTES};
+  JointVariant v{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, nullptr, 0, 0, true, joint_epoch_kernel<C, true>,
+                 joint_epoch_kernel<CT>, CT::LDS_BYTES};
+  v.ek_phase[0] = joint_epoch_kernel<C, false, 1>;
+  v.ek_phase[1] = joint_epoch_kernel<C, false, 2>;
+  v.ek_phase[2] = joint_epoch_kernel<C, false, 3>;
+  v.ek_phase[3] = joint_epoch_kernel<C, false, 4>;
+  v.ek_phase[4] = joint_epoch_kernel<C, false, 5>;
+  v.ek_phase[5] = joint_epoch_kernel<C, false, 6>;
+  v.ek_phase_tile[1] = joint_epoch_kernel<CT, false, 2>;
+  v.ek_phase_tile[3] = joint_epoch_kernel<CT, false, 4>;
+  v.e_lds_lite = C::LDS_LITE;
+  v.e_lds_lite_tile = CT::LDS_LITE;
+  return v;
 }
 int g_debug_global = 0;  // lc_joint_set_debug_global: small stamps through the large-grid kernels (parity tests)
 const JointVariant *find_jv(int n, int ss) {
@@ -246,6 +263,7 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   A.g_dy = j->g_dy;
   A.g_mean = j->g_mean;
   A.model_out = model_out;
+  A.part = j->part;
   A.fisher_out = j->fisher;
   // no background in the scene: separable Gaussian filtering of the epoch PSFs instead of the FFT pipeline
   if (!A.h_active && j->M > 0 && j->psf_dev && !std::getenv("LCMI_JOINT_FFT_ONLY")) {
@@ -270,8 +288,35 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   // global-spectrum kernels: with many workgroups in flight the 8 / 16-byte column accesses saturate L2 / Infinity Cache and
   // the LDS-tile variant of the column passes wins (128 x 128 ROIs: 32 epochs +1.4 %, 64 +-0, 125 -1 %, 160 -7 %, 200 -16 %,
   // 1000 -15 %; LCMI_TILE_COLS=0/1 overrides the choice)
-  bool tile = v->ek_tile && j->E >= 96;
+  // ... and an epoch that would leave CUs idle is spread over several workgroups, one launch per phase (LCMI_EPOCH_PARTS)
+  // (C5 shard, 125 epochs: 425 us per iteration as one kernel, 338 us with two workgroups per epoch, 328 us with three in the
+  //  column phases; 64 epochs 409 -> 231 us with four; 150 epochs and up: the single kernel, whose workgroups overlap each
+  //  other's phases, is faster - 200 epochs 470 against 613 us)
+  int parts = 1, parts_col = 1;
+  if (v->ek_phase[0] && mode == 0 && j->part) {
+    parts = std::min(kMaxParts, std::max(1, j->ctx->n_cu / std::max(j->E, 1)));
+    if (const char *ep = std::getenv("LCMI_EPOCH_PARTS")) parts = std::min(kMaxParts, std::max(1, std::atoi(ep)));
+    parts_col = (parts == 2) ? 3 : parts;
+    if (const char *ep = std::getenv("LCMI_EPOCH_PARTS_COL")) parts_col = std::min(2 * kMaxParts, std::max(1, std::atoi(ep)));
+  }
+  const bool phased = parts > 1;
+  bool tile = v->ek_tile && j->E * parts >= 96;
   if (const char *tc = std::getenv("LCMI_TILE_COLS")) tile = v->ek_tile && std::atoi(tc) != 0;
+  if (phased) {
+    for (int ph = 0; ph < 6; ++ph) {
+      if (ph == 5 && !(A.h_active && A.need_hgrad)) continue;
+      const bool tl = tile && v->ek_phase_tile[ph];
+      const bool col = (ph == 1 || ph == 3), lite = col || ph == 5;
+      epoch_fn pk = tl ? v->ek_phase_tile[ph] : v->ek_phase[ph];
+      const int plds = lite ? (tl ? v->e_lds_lite_tile : v->e_lds_lite) : v->e_lds;
+      const int np = col ? parts_col : parts;
+      LC_HIP(j->ctx, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
+      hipLaunchKernelGGL(pk, dim3(j->E, np), dim3(v->e_thr), plds, j->ctx->stream, A);
+    }
+    hipLaunchKernelGGL(joint_epoch_finish_kernel, dim3(j->E), dim3(64), 0, j->ctx->stream, A, j->ss, parts);
+    LC_HIP(j->ctx, hipGetLastError());
+    return A.need_hgrad;
+  }
   epoch_fn ek = tile ? v->ek_tile : v->ek;
   const int e_lds = tile ? v->e_lds_tile : v->e_lds;
   LC_HIP(j->ctx, hipFuncSetAttribute((const void *)ek, hipFuncAttributeMaxDynamicSharedMemorySize, e_lds));
@@ -626,7 +671,8 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   TRY(dmalloc(j, &j->out_loss, 4));
   TRY(dmalloc(j, &j->greg, NN));
   TRY(dmalloc(j, &j->regs, 4 + 3 * kMaxSources + 4));
-  if (v->gspec) TRY(dmalloc(j, &j->spec, (size_t)E * N * KH));
+  if (v->gspec) TRY(dmalloc(j, &j->spec, (size_t)E * N * ((KH + 15) / 16 * 16)));  // rows padded to 128-byte lines (JointCfg::KS)
+  if (v->gspec) TRY(dmalloc(j, &j->part, (size_t)E * kMaxParts * (4 + 3 * kMaxSources)));
   if (!v->uk) {
     const size_t nb = (NN + kGmThreads - 1) / kGmThreads;
     TRY(dmalloc(j, &j->gm_c, NN));

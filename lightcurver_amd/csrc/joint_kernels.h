@@ -38,6 +38,7 @@ struct JointArgs {
   float *HG;                  // [E][N*N] T_e^T (scene gradient)
   float *chi2_e, *g_a, *g_cx_e, *g_cy_e, *g_dx, *g_dy, *g_mean;
   float *model_out;           // [E][n][n] or null
+  float *part;                // phased launches: [E][parts][4 + 3 kMaxSources] partial sums of the epoch's workgroups
   float *fisher_out;          // [E][M]
   // auxiliary instantiation (AUX = true; noise propagation on the device, csrc/joint_noise.h):
   //   mode 3: conv_same(scene_in[e], image whose spectrum is St[e]) -> conv_out[e] at full resolution
@@ -79,6 +80,9 @@ struct JointCfg {
   static constexpr bool GSPEC = GSPEC_;
   static constexpr int NW = NW_, NTHR = 64 * NW_;  // waves per epoch workgroup: as many as the LDS workspace allows
   static constexpr int KH = L / 2 + 1;           // stored spectrum columns
+  // row stride of the spectrum: in global memory a multiple of 16 elements, so that rows and the 16-column tiles of the
+  // column passes start on 128-byte lines
+  static constexpr int KS = GSPEC_ ? (KH + 15) / 16 * 16 : KH;
   static constexpr int OFF_SPEC = 0;             // float2 units
   static constexpr int SZ_SPEC = GSPEC ? 0 : N * KH;
   static constexpr int OFF_WS = OFF_SPEC + SZ_SPEC;
@@ -113,6 +117,9 @@ struct JointCfg {
   static constexpr int OFF_TILE = OFF_TWH + SZ_TWH;
   static constexpr int SZ_TILE = TILECOLS ? N * TP : 0;
   static constexpr int LDS_BYTES = (OFF_TILE + SZ_TILE) * 8;
+  // phased launches: the column phases and phase D use neither the row workspace nor the tables of the point sources; their
+  // workgroups allocate [ twiddles | reduction scratch | tile ] only, so that several of them fit on a CU
+  static constexpr int LITE_RED = L, LITE_TILE = L + SZ_RED, LDS_LITE = (LITE_TILE + SZ_TILE) * 8;
   static_assert(!WSQ || 2 * L >= 3 * N, "row buffer holds three rows of h");
   static constexpr int CREF = (N - 1) / 2;
   static_assert(N % 2 == 0, "row pairs");
@@ -120,14 +127,32 @@ struct JointCfg {
   static_assert(LDS_BYTES <= 163840, "LDS");
 };
 
-template <class C, bool AUX = false>
-__global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
-  constexpr int N = C::N, SS = C::SS, L = C::L, n = C::n, KH = C::KH, CREF = C::CREF;
+// Workgroups of a column phase the compiler leaves register room for on one CU.  Two (128 registers; 31 - 74 of them spilled)
+// measured slower than one at every split of the C5 shard (125 epochs: 367 - 405 us per iteration against 338).
+#ifndef LC_COL_PHASE_BLOCKS
+#define LC_COL_PHASE_BLOCKS 1
+#endif
+constexpr int kColPhaseBlocks = LC_COL_PHASE_BLOCKS;
+
+// PHASE = 0: the whole epoch in one workgroup (above).  PHASE = 1 .. 6 (global-spectrum kernels): ONE phase (A, B, C, B', C',
+// D) per launch on a grid (E, parts): the `parts` workgroups of an epoch share the phase's rows / columns / pixels, the
+// spectrum travels between the launches through global memory, and the launch boundaries are the synchronisation (no
+// waiting inside a kernel).  An epoch that would occupy one CU out of two then uses the whole machine, and every launch
+// holds the registers of one phase only.  The reductions of the epoch are finished by joint_epoch_finish_kernel.
+template <class C, bool AUX = false, int PHASE = 0>
+// (the second argument of __launch_bounds__ is waves per SIMD here: a workgroup of NW waves puts NW / 4 on each)
+__global__ __launch_bounds__(C::NTHR, ((C::NW + 3) / 4) * ((PHASE == 2 || PHASE == 4) ? kColPhaseBlocks : 1)) void joint_epoch_kernel(
+    JointArgs A) {
+  static_assert(PHASE == 0 || (C::GSPEC && !AUX), "one phase per launch: spectrum in global memory");
+  const int part = blockIdx.y, nparts = gridDim.y;  // workgroup of the epoch, workgroups per epoch (1, 1 for PHASE = 0)
+  constexpr int N = C::N, SS = C::SS, L = C::L, n = C::n, KH = C::KH, KS = C::KS, CREF = C::CREF;
   extern __shared__ __align__(16) float2 lds2[];
-  float2 *SPEC = C::GSPEC ? (A.spec + (size_t)blockIdx.x * N * KH) : (lds2 + C::OFF_SPEC);
-  float2 *TW = lds2 + C::OFF_TW;
-  float *RED = (float *)(lds2 + C::OFF_RED);
+  float2 *SPEC = C::GSPEC ? (A.spec + (size_t)blockIdx.x * N * KS) : (lds2 + C::OFF_SPEC);
+  constexpr bool LITE = (PHASE == 2 || PHASE == 4 || PHASE == 6);  // (JointCfg::LDS_LITE)
+  float2 *TW = lds2 + (LITE ? 0 : C::OFF_TW);
+  float *RED = (float *)(lds2 + (LITE ? C::LITE_RED : C::OFF_RED));
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int pw = part * C::NW + wid, PWS = nparts * C::NW;  // this wave among the epoch's waves, their number
   const int M = A.M;
   const float c0 = (N - 1) * 0.5f;
   const float al = A.alpha[e] * 0.017453292519943295f;
@@ -141,7 +166,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 
   LC_JSTAMP(0);
   for (int k = tid; k < L; k += C::NTHR) TW[k] = A.twid[k];
-  if constexpr (C::FOLD) {
+  if constexpr (C::FOLD && !LITE) {
     float2 *TWH = lds2 + C::OFF_TWH, *PHI = TWH + L / 2;
     for (int k = tid; k <= L / 2; k += C::NTHR) {
       if (k < L / 2) TWH[k] = A.twid[2 * k];
@@ -151,7 +176,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   }
   // separable Gaussian factors of every point source (full grid, as the oracle evaluates them), in LDS: the scene and
   // gradient loops read them per pixel, and a global table put a load latency into every one of those reads
-  {
+  if constexpr (!LITE) {
     const float nrm = 0.3989422804014327f / kSigmaG;
     for (int idx = tid; idx < M * N; idx += C::NTHR) {
       const int i = idx / N, p = idx % N;
@@ -166,7 +191,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       }
     }
   }
-  if (tid < kMaxSources) AMPL[tid] = (tid < M) ? ((A.mode == 2) ? ((tid == A.isrc) ? 1.f : 0.f) : A.a[e * M + tid]) : 0.f;
+  if (!LITE && tid < kMaxSources) AMPL[tid] = (tid < M) ? ((A.mode == 2) ? ((tid == A.isrc) ? 1.f : 0.f) : A.a[e * M + tid]) : 0.f;
   {  // per-wave reduction slots: the gradient sums of the point sources are accumulated there sweep by sweep
     constexpr int NQ0 = 4 + 3 * kMaxSources;
     if (lane < NQ0) RED[wid * NQ0 + lane] = 0.f;
@@ -186,6 +211,20 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   const int lane_mirror = qbase | fft_index_n<LPF>(LPF - 1 - l16);  // holds bins L - k for k2 != 0
   const int lane_neg = qbase | fft_index_n<LPF>(bitrev_n<LPF>((LPF - bitrev_n<LPF>(l16)) & (LPF - 1)));  // bin (L - k) mod L, k2 == 0
   float2 *wsq = lds2 + C::OFF_WS + (C::WSQ ? (wid * GPW + qid) : wid) * L;  // linear workspace (L samples)
+  // Spectrum rows in global memory: a lane of a row transform holds bins N2 b + k2 (b = its block index), so in bin order one
+  // store instruction wrote 8-byte elements N2 apart - a different cache line per lane, and with 200+ workgroups the
+  // request rate of L2 is what the row phases wait for.  The row is therefore kept in SLOT order: bin N2 b + k2 < L/2 sits
+  // at slot k2 LPF/2 + b (the Nyquist bin stays at L/2), which makes the lanes of one instruction neighbours.  The column
+  // phases walk slots and only need the bin of a slot to find its PSF spectrum.
+  constexpr bool SLOTS = C::GSPEC && (N2 * (LPF / 2) == L / 2);
+  const int bidx = bitrev_n<LPF>(l16);
+  auto slot_of = [&](int k) { return SLOTS ? ((k < L / 2) ? (k % N2) * (LPF / 2) + k / N2 : L / 2) : k; };
+  auto bin_of = [&](int s) { return SLOTS ? ((s < L / 2) ? (s % (LPF / 2)) * N2 + s / (LPF / 2) : L / 2) : s; };
+  // slot of bin kbase + k2 <= L/2 of this lane, and of bin L - (kbase + k2) for kbase + k2 > L/2 (k2 is a compile-time index)
+  auto slot_own = [&](int k2) { return SLOTS ? ((bidx == LPF / 2) ? L / 2 : k2 * (LPF / 2) + bidx) : kbase + k2; };
+  auto slot_neg = [&](int k2) {
+    return SLOTS ? ((k2 == 0) ? LPF - bidx : (N2 - k2) * (LPF / 2) + (LPF - 1 - bidx)) : L - (kbase + k2);
+  };
 
   // Translated epochs (alpha = 0: every fit of the reference): scene pixel (u, v) samples h at (u + iyc + fyc, v + ixc + fxc)
   // with ONE integer offset and ONE pair of fractional weights for the whole epoch, so scene rows u0, u0 + 1 read the
@@ -278,8 +317,9 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       const float2 zc = (k2 == 0) ? shfl2(x[0], lane_neg) : shfl2(x[(N2 - k2) % N2], lane_mirror);
       const int k = kbase + k2;
       if (active && k <= L / 2) {
-        SPEC[u0 * KH + k] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-        SPEC[(u0 + 1) * KH + k] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+        const int sk = slot_own(k2);
+        SPEC[u0 * KS + sk] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+        SPEC[(u0 + 1) * KS + sk] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
       }
     }
   };
@@ -291,10 +331,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       float2 z = make_float2(0.f, 0.f);
       if (active) {
         if (k <= L / 2) {
-          const float2 x1 = SPEC[u0 * KH + k], x2 = SPEC[(u0 + 1) * KH + k];
+          const int sk = slot_own(k2);
+          const float2 x1 = SPEC[u0 * KS + sk], x2 = SPEC[(u0 + 1) * KS + sk];
           z = make_float2(x1.x - x2.y, x1.y + x2.x);
         } else {
-          const float2 x1 = SPEC[u0 * KH + (L - k)], x2 = SPEC[(u0 + 1) * KH + (L - k)];
+          const int sn = slot_neg(k2);
+          const float2 x1 = SPEC[u0 * KS + sn], x2 = SPEC[(u0 + 1) * KS + sn];
           z = make_float2(x1.x + x2.y, x2.x - x1.y);
         }
       }
@@ -313,8 +355,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       const int r = l16 + LPF * n2 - row_off;
       float2 v = make_float2(0.f, 0.f);
       if (active && r >= 0 && r < N) {
-        v = SPEC[r * KH + kc];
-        if (kc == 0) v.y = SPEC[r * KH + L / 2].x;
+        v = SPEC[r * KS + kc];
+        if (kc == 0) v.y = SPEC[r * KS + L / 2].x;
       }
       x[n2] = v;
     }
@@ -325,10 +367,10 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       const int r = l16 + LPF * n2 - row_off;
       if (active && r >= 0 && r < N) {
         if (kc == 0) {
-          SPEC[r * KH] = make_float2(x[n2].x, 0.f);
-          SPEC[r * KH + L / 2] = make_float2(x[n2].y, 0.f);
+          SPEC[r * KS] = make_float2(x[n2].x, 0.f);
+          SPEC[r * KS + L / 2] = make_float2(x[n2].y, 0.f);
         } else {
-          SPEC[r * KH + kc] = x[n2];
+          SPEC[r * KS + kc] = x[n2];
         }
       }
     }
@@ -344,7 +386,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     for (int k = 0; k < N2 / 2; ++k) {
       const int r = l16 + LPF * (2 * k + qid) - row_off;
       lc_f4a8 v = {0.f, 0.f, 0.f, 0.f};
-      if (active && r >= 0 && r < N) v = *(const lc_f4a8 *)(SPEC + r * KH + c0);
+      if (active && r >= 0 && r < N) v = *(const lc_f4a8 *)(SPEC + r * KS + c0);
       const float2 own = qid ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
       const float2 oth = qid ? make_float2(v.x, v.y) : make_float2(v.z, v.w);
       const float2 rec = make_float2(__shfl_xor(oth.x, 32, 64), __shfl_xor(oth.y, 32, 64));
@@ -362,13 +404,13 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         lc_f4a8 o;
         if (qid) o = (lc_f4a8){rec.x, rec.y, xo.x, xo.y};
         else o = (lc_f4a8){xo.x, xo.y, rec.x, rec.y};
-        *(lc_f4a8 *)(SPEC + r * KH + c0) = o;
+        *(lc_f4a8 *)(SPEC + r * KS + c0) = o;
       }
     }
   };
   // LDS-tile form of the column access (GSPEC kernels built with TILECOLS): columns kt .. kt + CPS - 1 of the global spectrum
   // <-> tile, by every thread (the DC / Nyquist pair is packed into column 0 on the way in and separated on the way out)
-  float2 *TILE = lds2 + C::OFF_TILE;
+  float2 *TILE = lds2 + (LITE ? C::LITE_TILE : C::OFF_TILE);
   constexpr int CPS = C::CPS, TP = C::TP;
   constexpr int TPT = (N * CPS + C::NTHR - 1) / C::NTHR;  // tile elements per thread
   auto tile_in = [&](int kt) {
@@ -377,13 +419,13 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     for (int q = 0; q < TPT; ++q) {  // all loads first: one latency per tile
       const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS, kc = kt + c;
       v[q] = make_float2(0.f, 0.f);
-      if (i < N * CPS && kc < NCOL) v[q] = SPEC[r * KH + kc];
+      if (i < N * CPS && kc < NCOL) v[q] = SPEC[r * KS + kc];
     }
     if (kt == 0) {
 #pragma unroll
       for (int q = 0; q < TPT; ++q) {
         const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS;
-        if (i < N * CPS && c == 0) v[q].y = SPEC[r * KH + L / 2].x;
+        if (i < N * CPS && c == 0) v[q].y = SPEC[r * KS + L / 2].x;
       }
     }
 #pragma unroll
@@ -399,10 +441,10 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       if (i < N * CPS && kc < NCOL) {
         const float2 v = TILE[r * TP + c];
         if (kc == 0) {
-          SPEC[r * KH] = make_float2(v.x, 0.f);
-          SPEC[r * KH + L / 2] = make_float2(v.y, 0.f);
+          SPEC[r * KS] = make_float2(v.x, 0.f);
+          SPEC[r * KS + L / 2] = make_float2(v.y, 0.f);
         } else {
-          SPEC[r * KH + kc] = v;
+          SPEC[r * KS + kc] = v;
         }
       }
     }
@@ -463,10 +505,20 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   float4 hpre[NPRE];
 #pragma unroll
   for (int q = 0; q < NPRE; ++q) hpre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // (declared here for every phase: the accumulators and pointers a later phase or the reductions use)
+  float acc_chi = 0.f, acc_mean = 0.f, acc_fis = 0.f;
+  float acc_dx = 0.f, acc_dy = 0.f, acc_hx = 0.f, acc_hy = 0.f;
+  const float *de = A.data + (size_t)e * n * n, *we = A.wgt + (size_t)e * n * n;
+  const float2 *Ste = A.St + (size_t)e * KH * L;
+  // scene-gradient rows overwrite the spectrum rows they were computed from (row u: N floats inside the
+  // KH float2 of spectrum row u), so the T^T gather below reads LDS, not global memory
+  float *GSl = (float *)SPEC;
+  constexpr int GST = 2 * KS;
+  if constexpr (PHASE == 0 || PHASE == 1) {
   if constexpr (!AUX && C::ROWPIPE) {
-    if (use_h && translated) fetch_rows(2 * (wid * GPW + qid), wid * GPW + qid < N / 2, hpre);
+    if (use_h && translated) fetch_rows(2 * (pw * GPW + qid), pw * GPW + qid < N / 2, hpre);
   }
-  for (int rp0 = wid * GPW; rp0 < N / 2; rp0 += C::NW * GPW) {
+  for (int rp0 = pw * GPW; rp0 < N / 2; rp0 += PWS * GPW) {
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
     float2 x[N2];
@@ -476,8 +528,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         if constexpr (C::ROWPIPE) {
           put_rows(u0, active, hpre);
           wave_lds_sync();
-          const int rpn = rp + C::NW * GPW;
-          if (rp0 + C::NW * GPW < N / 2) fetch_rows(2 * rpn, rpn < N / 2, hpre);
+          const int rpn = rp + PWS * GPW;
+          if (rp0 + PWS * GPW < N / 2) fetch_rows(2 * rpn, rpn < N / 2, hpre);
         } else {
           stage_rows(u0, active);
           wave_lds_sync();
@@ -530,6 +582,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     group_fft_fwd<L, LPF>(x, l16, TW);
     unpack_rows(x, u0, active);
   }
+  }  // phase A
   __syncthreads();
   LC_JSTAMP(2);
   if constexpr (AUX) {
@@ -553,15 +606,15 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
           }
         } else if (active) {
 #pragma unroll
-          for (int k2 = 0; k2 < N2; ++k2) So[(size_t)kcs * L + kbase + k2] = make_float2(sc * x[k2].x, sc * x[k2].y);
+          for (int k2 = 0; k2 < N2; ++k2) So[(size_t)bin_of(kcs) * L + kbase + k2] = make_float2(sc * x[k2].x, sc * x[k2].y);
         }
       }
       return;
     }
   }
   // ---- phase B: columns: FFT, multiply by the PSF spectrum, inverse FFT, keep the 'same' window ----
-  const float2 *Ste = A.St + (size_t)e * KH * L;
-  for (int kt = 0; kt < NCOL; kt += C::NW * GPW) {  // one sweep: NW * GPW consecutive columns
+  if constexpr (PHASE == 0 || PHASE == 2) {
+  for (int kt = part * C::NW * GPW; kt < NCOL; kt += PWS * GPW) {  // one sweep: NW * GPW consecutive columns
     const int kc0 = kt + wid * GPW;
     if (!C::TILECOLS && kc0 >= NCOL) break;  // (the tile form has workgroup barriers inside: every wave makes every sweep)
     const int kc = kc0 + qid;
@@ -570,7 +623,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     float2 x[N2], sv[N2];
     LC_JSTAMP(9);
 #pragma unroll
-    for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)kcs * L + kbase + k2];
+    for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)bin_of(kcs) * L + kbase + k2];
     const bool paired = PAIRCOL && kc0 != 0;  // (the packed DC / Nyquist column takes the element-wise form)
     constexpr bool tiled = C::TILECOLS;
     if (tiled) {
@@ -601,6 +654,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     }
     LC_JSTAMP(14);
   }
+  }  // phase B
   __syncthreads();
   LC_JSTAMP(3);
   if constexpr (AUX) {  // mode 3: inverse rows, 'same' window of the convolution at full resolution
@@ -623,8 +677,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     return;
   }
   // ---- phase C: inverse rows -> model, residuals; forward rows of the up-sampled weighted residual ----
-  float acc_chi = 0.f, acc_mean = 0.f, acc_fis = 0.f;
-  const float *de = A.data + (size_t)e * n * n, *we = A.wgt + (size_t)e * n * n;
+  if constexpr (PHASE == 0 || PHASE == 3) {
   if constexpr (C::FOLD) {
     // Binned rows.  Data row I is the sum of scene rows 2 I, 2 I + 1 (add their half spectra), shifted by CREF, added to
     // its right neighbour and decimated by two along x: in Fourier space a multiplication by phi and the fold
@@ -635,13 +688,14 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     const float2 *TWH = lds2 + C::OFF_TWH, *PHI = TWH + LH;
     const int kbh = N2H * bitrev_n<LPF>(l16);
     auto folded = [&](int r0, int m) {  // D[m], 0 <= m <= KQ, of the data row made of scene rows r0, r0 + 1
-      const float2 a0 = SPEC[r0 * KH + m], a1 = SPEC[(r0 + 1) * KH + m];
-      const float2 b0 = SPEC[r0 * KH + LH - m], b1 = SPEC[(r0 + 1) * KH + LH - m];
+      const int sa_ = slot_of(m), sb_ = slot_of(LH - m);
+      const float2 a0 = SPEC[r0 * KS + sa_], a1 = SPEC[(r0 + 1) * KS + sa_];
+      const float2 b0 = SPEC[r0 * KS + sb_], b1 = SPEC[(r0 + 1) * KS + sb_];
       const float2 ga = cmul(make_float2(a0.x + a1.x, a0.y + a1.y), PHI[m]);
       const float2 gb = cmul(make_float2(b0.x + b1.x, b0.y + b1.y), PHI[LH - m]);
       return make_float2(ga.x + gb.x, ga.y - gb.y);
     };
-    for (int t0 = wid * GPW; t0 < n / 2; t0 += C::NW * GPW) {
+    for (int t0 = pw * GPW; t0 < n / 2; t0 += PWS * GPW) {
       const int t = t0 + qid, I0 = 2 * t, I1 = I0 + 1;
       const bool active = t < n / 2;
       float2 x[N2H];
@@ -699,22 +753,23 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
             const float2 pa = PHI[k], pb = PHI[LH - k];
             const float2 u0a = cmul_conj(R0, pa), u1a = cmul_conj(R1, pa);
             const float2 u0b = cmul_conj(make_float2(R0.x, -R0.y), pb), u1b = cmul_conj(make_float2(R1.x, -R1.y), pb);
-            SPEC[(2 * I0) * KH + k] = u0a;
-            SPEC[(2 * I0 + 1) * KH + k] = u0a;
-            SPEC[(2 * I1) * KH + k] = u1a;
-            SPEC[(2 * I1 + 1) * KH + k] = u1a;
+            const int ska = slot_of(k), skb = slot_of(LH - k);
+            SPEC[(2 * I0) * KS + ska] = u0a;
+            SPEC[(2 * I0 + 1) * KS + ska] = u0a;
+            SPEC[(2 * I1) * KS + ska] = u1a;
+            SPEC[(2 * I1 + 1) * KS + ska] = u1a;
             if (k != KQ) {
-              SPEC[(2 * I0) * KH + LH - k] = u0b;
-              SPEC[(2 * I0 + 1) * KH + LH - k] = u0b;
-              SPEC[(2 * I1) * KH + LH - k] = u1b;
-              SPEC[(2 * I1 + 1) * KH + LH - k] = u1b;
+              SPEC[(2 * I0) * KS + skb] = u0b;
+              SPEC[(2 * I0 + 1) * KS + skb] = u0b;
+              SPEC[(2 * I1) * KS + skb] = u1b;
+              SPEC[(2 * I1 + 1) * KS + skb] = u1b;
             }
           }
         }
       }
     }
   } else {
-  for (int rp0 = wid * GPW; rp0 < N / 2; rp0 += C::NW * GPW) {
+  for (int rp0 = pw * GPW; rp0 < N / 2; rp0 += PWS * GPW) {
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
     float2 x[N2];
@@ -809,7 +864,22 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     wave_lds_sync();
   }
   }
-  if (A.mode != 0) {
+  }  // phase C
+  if constexpr (PHASE == 3) {  // this workgroup's share of chi2 and of the sky-level gradient
+    constexpr int NQP = 4 + 3 * kMaxSources;
+    const float s0 = wave_sum(acc_chi), s1 = wave_sum(acc_mean);
+    if (lane == 0) {
+      RED[wid * NQP + 0] = s0;
+      RED[wid * NQP + 1] = s1;
+    }
+    __syncthreads();
+    if (tid < 2) {
+      float acc = 0.f;
+      for (int w = 0; w < C::NW; ++w) acc += RED[w * NQP + tid];
+      A.part[((size_t)e * nparts + part) * NQP + tid] = acc;
+    }
+  }
+  if (PHASE == 0 && A.mode != 0) {
     const float v0 = wave_sum((A.mode == 2) ? acc_fis : acc_chi);
     if (lane == 0) RED[wid] = v0;
     __syncthreads();
@@ -824,7 +894,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   __syncthreads();
   LC_JSTAMP(4);
   // ---- phase B': adjoint columns (rows sit at offset CREF), multiply by conj(spectrum) ------------
-  for (int kt = 0; kt < NCOL; kt += C::NW * GPW) {
+  if constexpr (PHASE == 0 || PHASE == 4) {
+  for (int kt = part * C::NW * GPW; kt < NCOL; kt += PWS * GPW) {
     const int kc0 = kt + wid * GPW;
     if (!C::TILECOLS && kc0 >= NCOL) break;
     const int kc = kc0 + qid;
@@ -832,7 +903,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     const int kcs = active ? kc : 1;
     float2 x[N2], sv[N2];
 #pragma unroll
-    for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)kcs * L + kbase + k2];
+    for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)bin_of(kcs) * L + kbase + k2];
     const bool paired = PAIRCOL && kc0 != 0;
     constexpr bool tiled = C::TILECOLS;
     if (tiled) {
@@ -858,15 +929,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       store_column(x, kcs, active, 0);
     }
   }
+  }  // phase B'
   __syncthreads();
   LC_JSTAMP(5);
   // ---- phase C': adjoint inverse rows -> scene gradient rows; parameter gradients ------------------
-  float acc_dx = 0.f, acc_dy = 0.f, acc_hx = 0.f, acc_hy = 0.f;
-  // scene-gradient rows overwrite the spectrum rows they were computed from (row u: N floats inside the
-  // KH float2 of spectrum row u), so the T^T gather below reads LDS, not global memory
-  float *GSl = (float *)SPEC;
-  constexpr int GST = 2 * KH;
-  for (int rp0 = wid * GPW; rp0 < N / 2; rp0 += C::NW * GPW) {
+  if constexpr (PHASE == 0 || PHASE == 5) {
+  for (int rp0 = pw * GPW; rp0 < N / 2; rp0 += PWS * GPW) {
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
     float2 x[N2];
@@ -943,11 +1011,27 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       }
     }
   }
+  }  // phase C'
   LC_JSTAMP(6);
   acc_dx = fmaf(-(float)SS, acc_hx, acc_dx);
   acc_dy = fmaf(-(float)SS, acc_hy, acc_dy);
+  if constexpr (PHASE == 5) {  // this workgroup's share of the shift gradients and of the sums of the point sources
+    constexpr int NQP = 4 + 3 * kMaxSources;
+    const int nqp = 4 + 3 * M;
+    const float s2 = wave_sum(acc_dx), s3 = wave_sum(acc_dy);
+    if (lane == 0) {
+      RED[wid * NQP + 2] = s2;
+      RED[wid * NQP + 3] = s3;
+    }
+    __syncthreads();
+    if (tid >= 2 && tid < nqp) {
+      float acc = 0.f;
+      for (int w = 0; w < C::NW; ++w) acc += RED[w * NQP + tid];
+      A.part[((size_t)e * nparts + part) * NQP + tid] = acc;
+    }
+  }
   // reductions: lanes by shuffles, the four waves in fixed order
-  {
+  if constexpr (PHASE == 0) {
     constexpr int NQ = 4 + 3 * kMaxSources;
     const int nq = 4 + 3 * M;  // quantities in use: the sums of the sources already sit in the waves' slots
     {
@@ -987,7 +1071,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   }
   LC_JSTAMP(7);
   // ---- phase D: T_e^T of the scene gradient by an exact, ordered gather -----------------------------
-  if (use_h && A.need_hgrad) {
+  if ((PHASE == 0 || PHASE == 6) && use_h && A.need_hgrad) {
     __syncthreads();  // scene gradient of this epoch complete in LDS
     float *HGe = A.HG + (size_t)e * N * N;
     const float asa = fabsf(sa);
@@ -1004,7 +1088,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     if (translated) {
       // four consecutive pixels of a row per thread: two rows of five scene-gradient samples, one 16-byte store
       const float w00 = (1.f - fyc) * (1.f - fxc), w01 = (1.f - fyc) * fxc, w10 = fyc * (1.f - fxc), w11 = fyc * fxc;
-      for (int c = tid; c < N * (N / 4); c += C::NTHR) {
+      for (int c = part * C::NTHR + tid; c < N * (N / 4); c += nparts * C::NTHR) {
         const int ky = c / (N / 4), kx0 = 4 * (c % (N / 4));
         if (ky == 0 || ky == N - 1) continue;
         const int r0 = ky - iyc, q0 = kx0 - ixc;
@@ -1031,7 +1115,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       }
     }
     const int n_rows = 2 * marg * N, n_cols = 2 * marg * NI;
-    for (int q = tid; q < n_rows + n_cols; q += C::NTHR) {
+    for (int q = part * C::NTHR + tid; q < n_rows + n_cols; q += nparts * C::NTHR) {
       int ky, kx;
       if (q < n_rows) {
         const int r = q / N;
@@ -1089,6 +1173,39 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     }
   }
   LC_JSTAMP(8);
+}
+
+// Phased launches: the totals of an epoch are the sums of its workgroups' partial sums (in workgroup order); the outputs are
+// those of the reductions at the end of the one-workgroup kernel.  One block of 64 threads per epoch.
+__global__ void joint_epoch_finish_kernel(JointArgs A, int SS, int nparts) {
+  constexpr int NQ = 4 + 3 * kMaxSources;
+  __shared__ float TOT[NQ];
+  const int e = blockIdx.x, tid = threadIdx.x, M = A.M, nq = 4 + 3 * M;
+  if (tid < nq) {
+    float acc = 0.f;
+    for (int p = 0; p < nparts; ++p) acc += A.part[((size_t)e * nparts + p) * NQ + tid];
+    TOT[tid] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float al = A.alpha[e] * 0.017453292519943295f;
+    const float ca = cosf(al), sa = sinf(al);
+    const float *t = TOT;
+    A.chi2_e[e] = t[0];
+    A.g_mean[e] = t[1];
+    float gdx = t[2], gdy = t[3];
+    for (int i = 0; i < M; ++i) {
+      const float ai = A.a[e * M + i];
+      const float gX = ai * t[5 + 3 * i], gY = ai * t[6 + 3 * i];
+      A.g_a[e * M + i] = t[4 + 3 * i];
+      gdx += SS * gX;
+      gdy += SS * gY;
+      A.g_cx_e[e * M + i] = SS * (ca * gX + sa * gY);
+      A.g_cy_e[e * M + i] = SS * (ca * gY - sa * gX);
+    }
+    A.g_dx[e] = gdx;
+    A.g_dy[e] = gdy;
+  }
 }
 
 // ---- kernel 2: ordered reduction over the epochs of this rank -------------------------------------

@@ -15,10 +15,17 @@ from tests.test_joint_gpu import _setup
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def global_kernels(ctx):
+@pytest.fixture(params=['1', '3', None], ids=['one-workgroup', 'three-workgroups', 'default-split'])
+def global_kernels(ctx, request, monkeypatch):
+    """Small stamps through the global-spectrum kernels, in each launch form: one workgroup per epoch (one kernel), or
+    the epoch spread over several workgroups with one launch per phase (LCMI_EPOCH_PARTS; unset: as many as leave no
+    CU idle, at most four - what these few-epoch problems get by default)."""
     from lightcurver_amd import _lib
     lib = _lib.lib()
+    if request.param is None:
+        monkeypatch.delenv('LCMI_EPOCH_PARTS', raising=False)
+    else:
+        monkeypatch.setenv('LCMI_EPOCH_PARTS', request.param)
     lib.lc_joint_set_debug_global(1)
     yield
     lib.lc_joint_set_debug_global(0)

@@ -143,6 +143,19 @@ def test_tiled_column_passes_equal_the_direct_ones(ctx):
     _compare(a, b, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 12, 1e-4)
 
 
+@pytest.mark.parametrize('parts', ['2', '4'])
+def test_epoch_spread_over_workgroups_equals_the_one_workgroup_kernel(ctx, parts):
+    """128 x 128 ROIs with fewer epochs than CUs: the six phases of an epoch become six launches on a grid
+    (epochs, workgroups per epoch) with the spectrum in global memory between them (LCMI_EPOCH_PARTS forces the count;
+    1 = the single kernel).  Same arithmetic per element; only the partial sums of chi2 and of the parameter gradients
+    are added in a different order."""
+    ds = make_roi_dataset(E=3, M=4, n=128, ss=2, seed=105)
+    a = _fit(ctx, ds, 4, 12, env={'LCMI_EPOCH_PARTS': '1'})
+    b = _fit(ctx, ds, 4, 12, env={'LCMI_EPOCH_PARTS': parts})
+    assert np.max(np.abs(a[0] - b[0]) / np.abs(b[0])) < 1e-6
+    _compare(a, b, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 12, 1e-4)
+
+
 def test_update_waits_for_a_regulariser_chain_that_runs_late(ctx):
     """The fused update reads the regulariser's completion flag in the kernel.  Normally the chain is done before the
     epoch kernel ends and nothing waits; LCMI_REG_DELAY_US holds the second stream back by 300 us per iteration (five epoch
