@@ -127,12 +127,6 @@ struct JointCfg {
   static_assert(LDS_BYTES <= 163840, "LDS");
 };
 
-// Workgroups of a column phase the compiler leaves register room for on one CU.  Two (128 registers; 31 - 74 of them spilled)
-// measured slower than one at every split of the C5 shard (125 epochs: 367 - 405 us per iteration against 338).
-#ifndef LC_COL_PHASE_BLOCKS
-#define LC_COL_PHASE_BLOCKS 1
-#endif
-constexpr int kColPhaseBlocks = LC_COL_PHASE_BLOCKS;
 
 // PHASE = 0: the whole epoch in one workgroup (above).  PHASE = 1 .. 6 (global-spectrum kernels): ONE phase (A, B, C, B', C',
 // D) per launch on a grid (E, parts): the `parts` workgroups of an epoch share the phase's rows / columns / pixels, the
@@ -140,11 +134,15 @@ constexpr int kColPhaseBlocks = LC_COL_PHASE_BLOCKS;
 // waiting inside a kernel).  An epoch that would occupy one CU out of two then uses the whole machine, and every launch
 // holds the registers of one phase only.  The reductions of the epoch are finished by joint_epoch_finish_kernel.
 template <class C, bool AUX = false, int PHASE = 0>
-// (the second argument of __launch_bounds__ is waves per SIMD here: a workgroup of NW waves puts NW / 4 on each)
-__global__ __launch_bounds__(C::NTHR, ((C::NW + 3) / 4) * ((PHASE == 2 || PHASE == 4) ? kColPhaseBlocks : 1)) void joint_epoch_kernel(
-    JointArgs A) {
+// (Column phases built for two workgroups per CU - 128 registers, 31 to 74 of them spilled - measured slower than one at every
+//  split of the C5 shard: 367 - 405 us per iteration against 338.)
+__global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   static_assert(PHASE == 0 || (C::GSPEC && !AUX), "one phase per launch: spectrum in global memory");
-  const int part = blockIdx.y, nparts = gridDim.y;  // workgroup of the epoch, workgroups per epoch (1, 1 for PHASE = 0)
+  // workgroup of the epoch, workgroups per epoch.  (0, 1 in the one-kernel form: compile-time constants for the LDS-spectrum
+  // kernels; the global-spectrum build reads them from the grid there too - with run-time sweep strides the compiler keeps
+  // fewer values in flight and its 256 registers hold everything, with constants it spilled 64 - 110 of them.)
+  constexpr bool ONE = (PHASE == 0) && !C::GSPEC;
+  const int part = ONE ? 0 : (int)blockIdx.y, nparts = ONE ? 1 : (int)gridDim.y;
   constexpr int N = C::N, SS = C::SS, L = C::L, n = C::n, KH = C::KH, KS = C::KS, CREF = C::CREF;
   extern __shared__ __align__(16) float2 lds2[];
   float2 *SPEC = C::GSPEC ? (A.spec + (size_t)blockIdx.x * N * KS) : (lds2 + C::OFF_SPEC);

@@ -42,25 +42,32 @@ __device__ __forceinline__ int mr_row(int reg, int h) { return (reg & 3) + 8 * (
 // the k range [h HK, (h + 1) HK) of every product (one k per half and MFMA step), so that all operands are contiguous
 // per lane.  The intermediate S M^T passes through LDS once ([HK][64] image per product: step s reads 64 consecutive
 // floats).  All 64 * N / 32 threads must call.
+// The operands taken from M are read from its TRANSPOSE MT (the operators are kept in both forms): an MFMA operand wants the
+// matrix row in the lane index and k in the step, so from M itself every lane of a load touched a line of its own (rows are
+// N floats apart); from MT the 32 lanes of a half read 128 consecutive bytes.  Same values, same order of the sums.
+#ifndef MR_UNROLL
+#define MR_UNROLL 16
+#endif
 template <int N, int NP, class SRow>
-__device__ __forceinline__ void mr_two_sided(SRow &&srow, const float *const (&M)[NP], int b0, float *ylds, int lane, int wid,
+__device__ __forceinline__ void mr_two_sided(SRow &&srow, const float *const (&MT)[NP], int b0, float *ylds, int lane, int wid,
                                              mr_acc (&acc)[NP]) {
   constexpr int HK = N / 2;
   const int i = lane & 31, h = lane >> 5;
   mr_acc y[NP];
-  const float4 *m1[NP];
+  const float *m1[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) y[p][r] = 0.f;
-    m1[p] = (const float4 *)(M[p] + (size_t)(b0 + i) * N + h * HK);
+    m1[p] = MT[p] + (size_t)(h * HK) * N + b0 + i;  // M[b0 + i][h HK + k] = MT[h HK + k][b0 + i]
   }
-#pragma unroll
+#pragma unroll MR_UNROLL
   for (int q = 0; q < HK / 4; ++q) {
     const float4 a4 = srow(q);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const float4 b4 = m1[p][q];
+      const float *mq = m1[p] + (size_t)(4 * q) * N;
+      const float4 b4 = make_float4(mq[0], mq[N], mq[2 * N], mq[3 * N]);
       y[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, y[p], 0, 0, 0);
       y[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, y[p], 0, 0, 0);
       y[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, y[p], 0, 0, 0);
@@ -75,18 +82,19 @@ __device__ __forceinline__ void mr_two_sided(SRow &&srow, const float *const (&M
       ylds[p * HK * 64 + (k % HK) * 64 + i + 32 * (k / HK)] = y[p][r];
     }
   __syncthreads();
-  const float4 *m2[NP];
+  const float *m2[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-    m2[p] = (const float4 *)(M[p] + (size_t)(32 * wid + i) * N + h * HK);
+    m2[p] = MT[p] + (size_t)(h * HK) * N + 32 * wid + i;
   }
-#pragma unroll
+#pragma unroll MR_UNROLL
   for (int q = 0; q < HK / 4; ++q) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const float4 a4 = m2[p][q];
+      const float *mq = m2[p] + (size_t)(4 * q) * N;
+      const float4 a4 = make_float4(mq[0], mq[N], mq[2 * N], mq[3 * N]);
       const float *yp = ylds + p * HK * 64 + (4 * q) * 64 + lane;
       acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, yp[0], acc[p], 0, 0, 0);
       acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, yp[64], acc[p], 0, 0, 0);
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(MregCfg<N>::NTHR) void mreg_forward_kernel(MregArgs
   const int j = pts ? 1 : s + 1;
   const float *S = pts ? A.P : A.X;
   float *dst = A.C + (size_t)(pts ? A.J + 1 : j) * N * N;
-  const float *const M[1] = {A.A + (size_t)j * N * N};
+  const float *const M[1] = {A.AT + (size_t)j * N * N};  // the product uses A_j; mr_two_sided reads it from its transpose
   const float4 *sp = (const float4 *)(S + (size_t)(32 * wid + i) * N + h * HK);
   mr_acc acc[1];
   mr_two_sided<N, 1>([&](int q) { return sp[q]; }, M, b0, mr_lds, lane, wid, acc);
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(MregCfg<N>::NTHR) void mreg_adjoint_kernel(MregArgs
   };
   float *Zs = A.Z + (size_t)s * NN;
   if (j == 0) {  // A_0 = I: the first product is q itself
-    const float *const M[1] = {A.AT + (size_t)NN};
+    const float *const M[1] = {A.A + (size_t)NN};  // (products with A_1^T, read from A_1)
     mr_acc acc[1];
     mr_two_sided<N, 1>(qrow, M, b0, mr_lds, lane, wid, acc);
     const float l1_rows = l1;
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(MregCfg<N>::NTHR) void mreg_adjoint_kernel(MregArgs
     }
     l1 = l1_rows;  // the second pass over this block's own pixels does not count twice
   } else {
-    const float *const M[2] = {A.AT + (size_t)j * NN, A.AT + (size_t)(j + 1) * NN};
+    const float *const M[2] = {A.A + (size_t)j * NN, A.A + (size_t)(j + 1) * NN};
     mr_acc acc[2];
     mr_two_sided<N, 2>(qrow, M, b0, mr_lds, lane, wid, acc);
 #pragma unroll
