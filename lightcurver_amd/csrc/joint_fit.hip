@@ -313,7 +313,8 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
       LC_HIP(j->ctx, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
       hipLaunchKernelGGL(pk, dim3(j->E, np), dim3(v->e_thr), plds, j->ctx->stream, A);
     }
-    hipLaunchKernelGGL(joint_epoch_finish_kernel, dim3(j->E), dim3(64), 0, j->ctx->stream, A, j->ss, parts);
+    if (!(A.h_active && A.need_hgrad))  // (phase D's first workgroup of an epoch adds up the partial sums otherwise)
+      hipLaunchKernelGGL(joint_epoch_finish_kernel, dim3(j->E), dim3(64), 0, j->ctx->stream, A, j->ss, parts);
     LC_HIP(j->ctx, hipGetLastError());
     return A.need_hgrad;
   }

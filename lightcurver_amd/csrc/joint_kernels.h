@@ -128,6 +128,38 @@ struct JointCfg {
 };
 
 
+// Phased launches: the totals of an epoch are the sums of its workgroups' partial sums (in workgroup order); the outputs are
+// those of the reductions at the end of the one-workgroup kernel.  Every thread of the workgroup calls (barrier inside); TOT: LDS.
+__device__ __forceinline__ void joint_epoch_totals(const JointArgs &A, int e, int tid, int SS, int nparts, float *TOT) {
+  constexpr int NQ = 4 + 3 * kMaxSources;
+  const int M = A.M, nq = 4 + 3 * M;
+  if (tid < nq) {
+    float acc = 0.f;
+    for (int p = 0; p < nparts; ++p) acc += A.part[((size_t)e * nparts + p) * NQ + tid];
+    TOT[tid] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float al = A.alpha[e] * 0.017453292519943295f;
+    const float ca = cosf(al), sa = sinf(al);
+    const float *t = TOT;
+    A.chi2_e[e] = t[0];
+    A.g_mean[e] = t[1];
+    float gdx = t[2], gdy = t[3];
+    for (int i = 0; i < M; ++i) {
+      const float ai = A.a[e * M + i];
+      const float gX = ai * t[5 + 3 * i], gY = ai * t[6 + 3 * i];
+      A.g_a[e * M + i] = t[4 + 3 * i];
+      gdx += SS * gX;
+      gdy += SS * gY;
+      A.g_cx_e[e * M + i] = SS * (ca * gX + sa * gY);
+      A.g_cy_e[e * M + i] = SS * (ca * gY - sa * gX);
+    }
+    A.g_dx[e] = gdx;
+    A.g_dy[e] = gdy;
+  }
+}
+
 // PHASE = 0: the whole epoch in one workgroup (above).  PHASE = 1 .. 6 (global-spectrum kernels): ONE phase (A, B, C, B', C',
 // D) per launch on a grid (E, parts): the `parts` workgroups of an epoch share the phase's rows / columns / pixels, the
 // spectrum travels between the launches through global memory, and the launch boundaries are the synchronisation (no
@@ -1070,6 +1102,9 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   LC_JSTAMP(7);
   // ---- phase D: T_e^T of the scene gradient by an exact, ordered gather -----------------------------
   if ((PHASE == 0 || PHASE == 6) && use_h && A.need_hgrad) {
+    if constexpr (PHASE == 6) {  // (launched with the workgroup count of the row phases, whose partial sums these are)
+      if (part == 0) joint_epoch_totals(A, e, tid, SS, nparts, RED);
+    }
     __syncthreads();  // scene gradient of this epoch complete in LDS
     float *HGe = A.HG + (size_t)e * N * N;
     const float asa = fabsf(sa);
@@ -1173,37 +1208,10 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   LC_JSTAMP(8);
 }
 
-// Phased launches: the totals of an epoch are the sums of its workgroups' partial sums (in workgroup order); the outputs are
-// those of the reductions at the end of the one-workgroup kernel.  One block of 64 threads per epoch.
+// the totals as a launch of their own (one block of 64 threads per epoch): when phase D, which computes them otherwise, does not run
 __global__ void joint_epoch_finish_kernel(JointArgs A, int SS, int nparts) {
-  constexpr int NQ = 4 + 3 * kMaxSources;
-  __shared__ float TOT[NQ];
-  const int e = blockIdx.x, tid = threadIdx.x, M = A.M, nq = 4 + 3 * M;
-  if (tid < nq) {
-    float acc = 0.f;
-    for (int p = 0; p < nparts; ++p) acc += A.part[((size_t)e * nparts + p) * NQ + tid];
-    TOT[tid] = acc;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const float al = A.alpha[e] * 0.017453292519943295f;
-    const float ca = cosf(al), sa = sinf(al);
-    const float *t = TOT;
-    A.chi2_e[e] = t[0];
-    A.g_mean[e] = t[1];
-    float gdx = t[2], gdy = t[3];
-    for (int i = 0; i < M; ++i) {
-      const float ai = A.a[e * M + i];
-      const float gX = ai * t[5 + 3 * i], gY = ai * t[6 + 3 * i];
-      A.g_a[e * M + i] = t[4 + 3 * i];
-      gdx += SS * gX;
-      gdy += SS * gY;
-      A.g_cx_e[e * M + i] = SS * (ca * gX + sa * gY);
-      A.g_cy_e[e * M + i] = SS * (ca * gY - sa * gX);
-    }
-    A.g_dx[e] = gdx;
-    A.g_dy[e] = gdy;
-  }
+  __shared__ float TOT[4 + 3 * kMaxSources];
+  joint_epoch_totals(A, blockIdx.x, threadIdx.x, SS, nparts, TOT);
 }
 
 // ---- kernel 2: ordered reduction over the epochs of this rank -------------------------------------
