@@ -296,7 +296,7 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   if (v->ek_phase[0] && mode == 0 && j->part) {
     parts = std::min(kMaxParts, std::max(1, j->ctx->n_cu / std::max(j->E, 1)));
     if (const char *ep = std::getenv("LCMI_EPOCH_PARTS")) parts = std::min(kMaxParts, std::max(1, std::atoi(ep)));
-    parts_col = (parts == 2) ? 3 : parts;
+    parts_col = parts;
     if (const char *ep = std::getenv("LCMI_EPOCH_PARTS_COL")) parts_col = std::min(2 * kMaxParts, std::max(1, std::atoi(ep)));
   }
   const bool phased = parts > 1;

@@ -116,10 +116,10 @@ struct JointCfg {
   static constexpr int CPS = NW * GPW, TP = CPS + 1;
   static constexpr int OFF_TILE = OFF_TWH + SZ_TWH;
   static constexpr int SZ_TILE = TILECOLS ? N * TP : 0;
-  static constexpr int LDS_BYTES = (OFF_TILE + SZ_TILE) * 8;
+  static constexpr int LDS_BYTES = (OFF_TILE + 2 * SZ_TILE) * 8;  // (two tiles: see column_sweeps)
   // phased launches: the column phases and phase D use neither the row workspace nor the tables of the point sources; their
   // workgroups allocate [ twiddles | reduction scratch | tile ] only, so that several of them fit on a CU
-  static constexpr int LITE_RED = L, LITE_TILE = L + SZ_RED, LDS_LITE = (LITE_TILE + SZ_TILE) * 8;
+  static constexpr int LITE_RED = L, LITE_TILE = L + SZ_RED, LDS_LITE = (LITE_TILE + 2 * SZ_TILE) * 8;  // (two tiles: see column_sweeps)
   static_assert(!WSQ || 2 * L >= 3 * N, "row buffer holds three rows of h");
   static constexpr int CREF = (N - 1) / 2;
   static_assert(N % 2 == 0, "row pairs");
@@ -531,6 +531,75 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     }
   };
 
+  // Column phase of a phased launch in its LDS-tile build: the tile of the NEXT sweep is requested before this sweep's
+  // transforms (16 registers per thread in flight) and dropped into the other of two LDS tiles afterwards, so the global
+  // load latency hides behind the transforms and a sweep has two workgroup barriers instead of three.
+  auto column_sweeps = [&](const float2 *Ste_, bool conj, int off_in, int off_out) {
+    const int kt0 = part * C::NW * GPW, kstep = PWS * GPW;
+    float2 pre[TPT];
+    auto fetch = [&](int kt) {
+#pragma unroll
+      for (int q = 0; q < TPT; ++q) {
+        const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS, kc = kt + c;
+        pre[q] = make_float2(0.f, 0.f);
+        if (i < N * CPS && kc < NCOL) pre[q] = SPEC[r * KS + kc];
+      }
+      if (kt == 0) {
+#pragma unroll
+        for (int q = 0; q < TPT; ++q) {
+          const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS;
+          if (i < N * CPS && c == 0) pre[q].y = SPEC[r * KS + L / 2].x;
+        }
+      }
+    };
+    if (kt0 < NCOL) fetch(kt0);
+    int buf = 0;
+    for (int kt = kt0; kt < NCOL; kt += kstep, buf ^= 1) {
+      float2 *T = TILE + buf * C::SZ_TILE;
+      const int kc = kt + wid * GPW + qid;
+      const bool active = kc < NCOL;
+      const int kcs = active ? kc : 1;
+      float2 x[N2], sv[N2];
+#pragma unroll
+      for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste_[(size_t)bin_of(kcs) * L + kbase + k2];
+#pragma unroll
+      for (int q = 0; q < TPT; ++q) {
+        const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS;
+        if (i < N * CPS) T[r * TP + c] = pre[q];
+      }
+      __syncthreads();
+      if (kt + kstep < NCOL) fetch(kt + kstep);
+#pragma unroll
+      for (int n2 = 0; n2 < N2; ++n2) {
+        const int r = l16 + LPF * n2 - off_in;
+        x[n2] = (active && r >= 0 && r < N) ? T[r * TP + wid * GPW + qid] : make_float2(0.f, 0.f);
+      }
+      group_fft_fwd<L, LPF, true>(x, l16, TW);
+      times_spectrum(x, sv, Ste_, kcs, conj);
+      group_fft_inv<L, LPF, true>(x, l16, TW);
+#pragma unroll
+      for (int n2 = 0; n2 < N2; ++n2) {
+        const int r = l16 + LPF * n2 - off_out;
+        if (active && r >= 0 && r < N) T[r * TP + wid * GPW + qid] = x[n2];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < TPT; ++q) {
+        const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS, kq = kt + c;
+        if (i < N * CPS && kq < NCOL) {
+          const float2 v = T[r * TP + c];
+          if (kq == 0) {
+            SPEC[r * KS] = make_float2(v.x, 0.f);
+            SPEC[r * KS + L / 2] = make_float2(v.y, 0.f);
+          } else {
+            SPEC[r * KS + kq] = v;
+          }
+        }
+      }
+    }
+  };
+  constexpr bool PIPED = C::TILECOLS && !AUX;
+
   // ---- phase A: scene rows, two real rows per complex FFT ---------------------------------------
   float4 hpre[NPRE];
 #pragma unroll
@@ -643,7 +712,9 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     }
   }
   // ---- phase B: columns: FFT, multiply by the PSF spectrum, inverse FFT, keep the 'same' window ----
-  if constexpr (PHASE == 0 || PHASE == 2) {
+  if constexpr (PIPED && (PHASE == 0 || PHASE == 2)) {
+    column_sweeps(Ste, false, 0, CREF);
+  } else if constexpr (PHASE == 0 || PHASE == 2) {
   for (int kt = part * C::NW * GPW; kt < NCOL; kt += PWS * GPW) {  // one sweep: NW * GPW consecutive columns
     const int kc0 = kt + wid * GPW;
     if (!C::TILECOLS && kc0 >= NCOL) break;  // (the tile form has workgroup barriers inside: every wave makes every sweep)
@@ -924,7 +995,9 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   __syncthreads();
   LC_JSTAMP(4);
   // ---- phase B': adjoint columns (rows sit at offset CREF), multiply by conj(spectrum) ------------
-  if constexpr (PHASE == 0 || PHASE == 4) {
+  if constexpr (PIPED && (PHASE == 0 || PHASE == 4)) {
+    column_sweeps(Ste, true, CREF, 0);
+  } else if constexpr (PHASE == 0 || PHASE == 4) {
   for (int kt = part * C::NW * GPW; kt < NCOL; kt += PWS * GPW) {
     const int kc0 = kt + wid * GPW;
     if (!C::TILECOLS && kc0 >= NCOL) break;
