@@ -289,9 +289,9 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   // the LDS-tile variant of the column passes wins (128 x 128 ROIs: 32 epochs +1.4 %, 64 +-0, 125 -1 %, 160 -7 %, 200 -16 %,
   // 1000 -15 %; LCMI_TILE_COLS=0/1 overrides the choice)
   // ... and an epoch that would leave CUs idle is spread over several workgroups, one launch per phase (LCMI_EPOCH_PARTS)
-  // (C5 shard, 125 epochs: 425 us per iteration as one kernel, 338 us with two workgroups per epoch, 328 us with three in the
-  //  column phases; 64 epochs 409 -> 231 us with four; 150 epochs and up: the single kernel, whose workgroups overlap each
-  //  other's phases, is faster - 200 epochs 470 against 613 us)
+  // (C5 shard, 125 epochs: 425 us per iteration as one kernel, 295 us with two workgroups per epoch; 64 epochs 409 -> 198 us
+  //  with four; 150 epochs and up: the single kernel, whose workgroups overlap each other's phases, is as fast or faster -
+  //  200 epochs 451 against 469 us.  LCMI_EPOCH_PARTS_COL: the count for the column phases alone, a tuning switch.)
   int parts = 1, parts_col = 1;
   if (v->ek_phase[0] && mode == 0 && j->part) {
     parts = std::min(kMaxParts, std::max(1, j->ctx->n_cu / std::max(j->E, 1)));
