@@ -549,7 +549,11 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
       A.g_cy_e = j->g_cy_e;
       A.chi2_e = j->chi2_e;
       A.shared_w = j->shared;
-      const int tiles = j->flag_sync ? 2 : 1;
+      // (16-pixel tiles per block; 256 x 256 grids: four - 4096 one-tile blocks spend more on block turnover than on the
+      //  sums, C5 shard 294 -> 287 us per iteration; LCMI_UPDATE_TILES overrides)
+      int tiles = j->flag_sync ? 2 : (NN / kRedPix >= 4096 ? 4 : 1);
+      if (const char *tl = std::getenv("LCMI_UPDATE_TILES")) tiles = std::max(1, std::atoi(tl));
+      if ((NN / kRedPix) % tiles) tiles = 1;
       const int nimg = NN / kRedPix / tiles;
       hipLaunchKernelGGL(joint_reduce_update_kernel, dim3(nimg + 2), dim3(kRedThreads), 0, stream, A, j->N, j->HG, tiles);
       LC_HIP(j->ctx, hipGetLastError());
