@@ -354,21 +354,20 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     }
   };
   // two half spectra -> Z[k] = X1[k] + i X2[k] over all L bins (Hermitian extension), block layout
+  // (One address per lane and element, then both loads and a sign: with the two halves of the spectrum in the two arms of a
+  //  branch the loads of an arm were consumed inside it, so every element cost the wave two dependent memory round trips -
+  //  24 per row pair; from a single block all of them are in flight at once.  Multiplying by +-1 is exact: same values.)
   auto pack_rows = [&](float2 (&x)[N2], int u0, bool active) {
 #pragma unroll
     for (int k2 = 0; k2 < N2; ++k2) {
       const int k = kbase + k2;
+      const bool lo = (k <= L / 2);
+      const int sidx = lo ? slot_own(k2) : slot_neg(k2);
+      const float sgn = lo ? -1.f : 1.f;
       float2 z = make_float2(0.f, 0.f);
       if (active) {
-        if (k <= L / 2) {
-          const int sk = slot_own(k2);
-          const float2 x1 = SPEC[u0 * KS + sk], x2 = SPEC[(u0 + 1) * KS + sk];
-          z = make_float2(x1.x - x2.y, x1.y + x2.x);
-        } else {
-          const int sn = slot_neg(k2);
-          const float2 x1 = SPEC[u0 * KS + sn], x2 = SPEC[(u0 + 1) * KS + sn];
-          z = make_float2(x1.x + x2.y, x2.x - x1.y);
-        }
+        const float2 x1 = SPEC[u0 * KS + sidx], x2 = SPEC[(u0 + 1) * KS + sidx];
+        z = make_float2(fmaf(sgn, x2.y, x1.x), fmaf(-sgn, x1.y, x2.x));
       }
       x[k2] = z;
     }
