@@ -634,6 +634,25 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         }
       }
     }
+    // (translated epochs: the N / LPF pixels of a lane in ONE straight block - the staged rows are read for idle groups too,
+    //  their results dropped by a select - so that the LDS reads of all pixels are in flight together; with a test per
+    //  pixel every pixel waited for its own reads)
+    static_assert(N % LPF == 0, "pixels per lane");
+    const bool fast_rows = !AUX && use_h && translated;
+    if (fast_rows) {
+#pragma unroll
+      for (int n2 = 0; n2 < N2; ++n2) {
+        float2 z = make_float2(0.f, 0.f);
+        if (n2 < N / LPF) {
+          float top[3], dif[3];
+          rows_at(l16 + LPF * n2, top, dif);
+          const float s0 = fmaf(fyc, top[1] - top[0], top[0]), s1 = fmaf(fyc, top[2] - top[1], top[1]);
+          z = make_float2(active ? s0 : 0.f, active ? s1 : 0.f);
+        }
+        x[n2] = z;
+      }
+    }
+    if (!fast_rows) {
 #pragma unroll
     for (int n2 = 0; n2 < N2; ++n2) {
       const int v = l16 + LPF * n2;
@@ -645,12 +664,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         }
       } else if (active && v < N) {
         float s0 = 0.f, s1 = 0.f;
-        if (use_h && translated) {
-          float top[3], dif[3];
-          rows_at(v, top, dif);
-          s0 += fmaf(fyc, top[1] - top[0], top[0]);
-          s1 += fmaf(fyc, top[2] - top[1], top[1]);
-        } else if (use_h) {
+        if (use_h) {
           float Xs, Ys, t0, t1;
           sample_coords(u0, v, c0, ca, sa, sdx, sdy, Xs, Ys);
           s0 += bilinear_h<N>(A.h, Xs, Ys, t0, t1);
@@ -660,6 +674,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         z = make_float2(s0, s1);
       }
       x[n2] = z;
+    }
     }
     if constexpr (!AUX) {
       // point sources: flux times the row factor of the quarter's two rows, then one LDS read per pixel pair
