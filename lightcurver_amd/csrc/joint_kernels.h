@@ -1095,13 +1095,40 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         }
       }
     }
+    // (one straight block for the lane's pixels, as in phase A - in the global-spectrum builds only: the N = 128 kernel has
+    //  no registers left for it, 29 spilled)
+    if (C::GSPEC && use_h && translated) {
+      float hx = 0.f, hy = 0.f;
+#pragma unroll
+      for (int n2 = 0; n2 < N / LPF; ++n2) {
+        // d scene / d dx = -SS dH/dx, d scene / d dy = -SS dH/dy (the factor joins after the loop)
+        const float2 g = x[n2];
+        float top[3], dif[3];
+        rows_at(l16 + LPF * n2, top, dif);
+        hx = fmaf(g.x, fmaf(fyc, dif[1] - dif[0], dif[0]), hx);
+        hx = fmaf(g.y, fmaf(fyc, dif[2] - dif[1], dif[1]), hx);
+        hy = fmaf(g.x, top[1] - top[0], hy);
+        hy = fmaf(g.y, top[2] - top[1], hy);
+      }
+      if (active) {  // (an idle group read stale rows: its sums are dropped whole)
+        acc_hx += hx;
+        acc_hy += hy;
+        if (A.need_hgrad) {
+#pragma unroll
+          for (int n2 = 0; n2 < N / LPF; ++n2) {
+            const int v = l16 + LPF * n2;
+            GSl[u0 * GST + v] = x[n2].x;
+            GSl[(u0 + 1) * GST + v] = x[n2].y;
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int n2 = 0; n2 < N2; ++n2) {
       const int v = l16 + LPF * n2;
       if (active && v < N) {
         const float2 g = x[n2];
         if (use_h && translated) {
-          // d scene / d dx = -SS dH/dx, d scene / d dy = -SS dH/dy (the factor joins after the loop)
           float top[3], dif[3];
           rows_at(v, top, dif);
           acc_hx = fmaf(g.x, fmaf(fyc, dif[1] - dif[0], dif[0]), acc_hx);
@@ -1126,6 +1153,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
           }
         }
       }
+    }
     }
   }
   }  // phase C'
