@@ -378,14 +378,19 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   // frequency domain by Hermitian symmetry.  That leaves L/2 column transforms instead of L/2 + 1: with 4 * NW
   // transforms per sweep (a power of two) the odd one out used to cost a whole extra sweep.
   constexpr int NCOL = L / 2;
+  // Binned rows (FOLD): the residual spectra phase C hands to phase B' are the same for scene rows 2 I and 2 I + 1, so only
+  // the even row is stored and the adjoint column loads (the ones with row_off = CREF) read row r & ~1 - half the stores of
+  // phase C; the tile form also fetches half the rows.
+  constexpr int RMASK_ADJ = C::FOLD ? ~1 : ~0;
   auto load_column = [&](float2 (&x)[N2], int kc, bool active, int row_off) {
+    const int rmask = (row_off != 0) ? RMASK_ADJ : ~0;
 #pragma unroll
     for (int n2 = 0; n2 < N2; ++n2) {
       const int r = l16 + LPF * n2 - row_off;
       float2 v = make_float2(0.f, 0.f);
       if (active && r >= 0 && r < N) {
-        v = SPEC[r * KS + kc];
-        if (kc == 0) v.y = SPEC[r * KS + L / 2].x;
+        v = SPEC[(r & rmask) * KS + kc];
+        if (kc == 0) v.y = SPEC[(r & rmask) * KS + L / 2].x;
       }
       x[n2] = v;
     }
@@ -411,11 +416,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   typedef float lc_f4a8 __attribute__((ext_vector_type(4), aligned(8)));
   constexpr bool PAIRCOL = C::GSPEC && (GPW == 2) && (N2 % 2 == 0);
   auto pair_load_columns = [&](float2 (&x)[N2], int c0, bool active, int row_off) {
+    const int rmask = (row_off != 0) ? RMASK_ADJ : ~0;
 #pragma unroll
     for (int k = 0; k < N2 / 2; ++k) {
       const int r = l16 + LPF * (2 * k + qid) - row_off;
       lc_f4a8 v = {0.f, 0.f, 0.f, 0.f};
-      if (active && r >= 0 && r < N) v = *(const lc_f4a8 *)(SPEC + r * KS + c0);
+      if (active && r >= 0 && r < N) v = *(const lc_f4a8 *)(SPEC + (r & rmask) * KS + c0);
       const float2 own = qid ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
       const float2 oth = qid ? make_float2(v.x, v.y) : make_float2(v.z, v.w);
       const float2 rec = make_float2(__shfl_xor(oth.x, 32, 64), __shfl_xor(oth.y, 32, 64));
@@ -479,10 +485,11 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     }
   };
   auto tile_load_column = [&](float2 (&x)[N2], int c, bool active, int row_off) {
+    const int rmask = (row_off != 0) ? RMASK_ADJ : ~0;
 #pragma unroll
     for (int n2 = 0; n2 < N2; ++n2) {
       const int r = l16 + LPF * n2 - row_off;
-      x[n2] = (active && r >= 0 && r < N) ? TILE[r * TP + c] : make_float2(0.f, 0.f);
+      x[n2] = (active && r >= 0 && r < N) ? TILE[(r & rmask) * TP + c] : make_float2(0.f, 0.f);
     }
   };
   auto tile_store_column = [&](const float2 (&x)[N2], int c, bool active, int row_off) {
@@ -535,19 +542,22 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   // load latency hides behind the transforms and a sweep has two workgroup barriers instead of three.
   auto column_sweeps = [&](const float2 *Ste_, bool conj, int off_in, int off_out) {
     const int kt0 = part * C::NW * GPW, kstep = PWS * GPW;
+    // (adjoint pass of the binned-row builds: only the even rows exist - half the tile is fetched, row r sits at r & ~1)
+    const bool half_in = C::FOLD && off_in != 0;
+    const int rstep = half_in ? 2 : 1, nfetch = half_in ? (N / 2) * CPS : N * CPS, rmask = half_in ? ~1 : ~0;
     float2 pre[TPT];
     auto fetch = [&](int kt) {
 #pragma unroll
       for (int q = 0; q < TPT; ++q) {
-        const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS, kc = kt + c;
+        const int i = tid + q * C::NTHR, r = rstep * (i / CPS), c = i % CPS, kc = kt + c;
         pre[q] = make_float2(0.f, 0.f);
-        if (i < N * CPS && kc < NCOL) pre[q] = SPEC[r * KS + kc];
+        if (i < nfetch && kc < NCOL) pre[q] = SPEC[r * KS + kc];
       }
       if (kt == 0) {
 #pragma unroll
         for (int q = 0; q < TPT; ++q) {
-          const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS;
-          if (i < N * CPS && c == 0) pre[q].y = SPEC[r * KS + L / 2].x;
+          const int i = tid + q * C::NTHR, r = rstep * (i / CPS), c = i % CPS;
+          if (i < nfetch && c == 0) pre[q].y = SPEC[r * KS + L / 2].x;
         }
       }
     };
@@ -563,15 +573,15 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste_[(size_t)bin_of(kcs) * L + kbase + k2];
 #pragma unroll
       for (int q = 0; q < TPT; ++q) {
-        const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS;
-        if (i < N * CPS) T[r * TP + c] = pre[q];
+        const int i = tid + q * C::NTHR, r = rstep * (i / CPS), c = i % CPS;
+        if (i < nfetch) T[r * TP + c] = pre[q];
       }
       __syncthreads();
       if (kt + kstep < NCOL) fetch(kt + kstep);
 #pragma unroll
       for (int n2 = 0; n2 < N2; ++n2) {
         const int r = l16 + LPF * n2 - off_in;
-        x[n2] = (active && r >= 0 && r < N) ? T[r * TP + wid * GPW + qid] : make_float2(0.f, 0.f);
+        x[n2] = (active && r >= 0 && r < N) ? T[(r & rmask) * TP + wid * GPW + qid] : make_float2(0.f, 0.f);
       }
       group_fft_fwd<L, LPF, true>(x, l16, TW);
       times_spectrum(x, sv, Ste_, kcs, conj);
@@ -869,15 +879,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
             const float2 u0a = cmul_conj(R0, pa), u1a = cmul_conj(R1, pa);
             const float2 u0b = cmul_conj(make_float2(R0.x, -R0.y), pb), u1b = cmul_conj(make_float2(R1.x, -R1.y), pb);
             const int ska = slot_of(k), skb = slot_of(LH - k);
+            // (rows 2 I + 1 would hold the same values: the adjoint column loads read row r & ~1 instead)
             SPEC[(2 * I0) * KS + ska] = u0a;
-            SPEC[(2 * I0 + 1) * KS + ska] = u0a;
             SPEC[(2 * I1) * KS + ska] = u1a;
-            SPEC[(2 * I1 + 1) * KS + ska] = u1a;
             if (k != KQ) {
               SPEC[(2 * I0) * KS + skb] = u0b;
-              SPEC[(2 * I0 + 1) * KS + skb] = u0b;
               SPEC[(2 * I1) * KS + skb] = u1b;
-              SPEC[(2 * I1 + 1) * KS + skb] = u1b;
             }
           }
         }
