@@ -110,9 +110,9 @@ struct JointCfg {
   static constexpr int OFF_TWH = OFF_TAB + SZ_TAB;
   static constexpr int SZ_TWH = FOLD ? (L / 2 + L / 2 + 1) : 0;
   // GSPEC: the column passes can stage the NW * GPW spectrum columns of a sweep through an LDS tile [N][CPS + 1]: every
-  // global access then moves whole 128-byte lines instead of 8 or 16 bytes of a line per lane.  Three more barriers per
-  // sweep: slower while few workgroups run (C5 shard, 125 epochs: +3 %), faster once the column traffic of 200+
-  // workgroups saturates L2 / Infinity Cache: a kernel variant of its own (TILECOLS), chosen by the host from the epoch count.
+  // global access then moves whole 128-byte lines instead of 8 or 16 bytes of a line per lane.  Two workgroup barriers per
+  // sweep: no gain while few workgroups run, faster once the column traffic of ~100 and more workgroups saturates L2 /
+  // Infinity Cache: a kernel variant of its own (TILECOLS), chosen by the host from the number of workgroups.
   static constexpr int CPS = NW * GPW, TP = CPS + 1;
   static constexpr int OFF_TILE = OFF_TWH + SZ_TWH;
   static constexpr int SZ_TILE = TILECOLS ? N * TP : 0;
@@ -443,62 +443,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       }
     }
   };
-  // LDS-tile form of the column access (GSPEC kernels built with TILECOLS): columns kt .. kt + CPS - 1 of the global spectrum
-  // <-> tile, by every thread (the DC / Nyquist pair is packed into column 0 on the way in and separated on the way out)
+  // LDS-tile form of the column access (GSPEC kernels built with TILECOLS; column_sweeps below): columns kt .. kt + CPS - 1 of
+  // the global spectrum <-> tile, by every thread (the DC / Nyquist pair is packed into column 0 on the way in and separated
+  // on the way out)
   float2 *TILE = lds2 + (LITE ? C::LITE_TILE : C::OFF_TILE);
   constexpr int CPS = C::CPS, TP = C::TP;
   constexpr int TPT = (N * CPS + C::NTHR - 1) / C::NTHR;  // tile elements per thread
-  auto tile_in = [&](int kt) {
-    float2 v[TPT];
-#pragma unroll
-    for (int q = 0; q < TPT; ++q) {  // all loads first: one latency per tile
-      const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS, kc = kt + c;
-      v[q] = make_float2(0.f, 0.f);
-      if (i < N * CPS && kc < NCOL) v[q] = SPEC[r * KS + kc];
-    }
-    if (kt == 0) {
-#pragma unroll
-      for (int q = 0; q < TPT; ++q) {
-        const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS;
-        if (i < N * CPS && c == 0) v[q].y = SPEC[r * KS + L / 2].x;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < TPT; ++q) {
-      const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS;
-      if (i < N * CPS) TILE[r * TP + c] = v[q];
-    }
-  };
-  auto tile_out = [&](int kt) {
-#pragma unroll
-    for (int q = 0; q < TPT; ++q) {
-      const int i = tid + q * C::NTHR, r = i / CPS, c = i % CPS, kc = kt + c;
-      if (i < N * CPS && kc < NCOL) {
-        const float2 v = TILE[r * TP + c];
-        if (kc == 0) {
-          SPEC[r * KS] = make_float2(v.x, 0.f);
-          SPEC[r * KS + L / 2] = make_float2(v.y, 0.f);
-        } else {
-          SPEC[r * KS + kc] = v;
-        }
-      }
-    }
-  };
-  auto tile_load_column = [&](float2 (&x)[N2], int c, bool active, int row_off) {
-    const int rmask = (row_off != 0) ? RMASK_ADJ : ~0;
-#pragma unroll
-    for (int n2 = 0; n2 < N2; ++n2) {
-      const int r = l16 + LPF * n2 - row_off;
-      x[n2] = (active && r >= 0 && r < N) ? TILE[(r & rmask) * TP + c] : make_float2(0.f, 0.f);
-    }
-  };
-  auto tile_store_column = [&](const float2 (&x)[N2], int c, bool active, int row_off) {
-#pragma unroll
-    for (int n2 = 0; n2 < N2; ++n2) {
-      const int r = l16 + LPF * n2 - row_off;
-      if (active && r >= 0 && r < N) TILE[r * TP + c] = x[n2];
-    }
-  };
   // x (block layout) *= PSF spectrum of column kc (conjugated for the adjoint); the packed column first splits
   // into its two Hermitian parts, each multiplied by its own spectrum column, and is packed again
   auto times_spectrum = [&](float2 (&x)[N2], const float2 (&sv)[N2], const float2 *Ste, int kc, bool conj) {
@@ -741,7 +691,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   } else if constexpr (PHASE == 0 || PHASE == 2) {
   for (int kt = part * C::NW * GPW; kt < NCOL; kt += PWS * GPW) {  // one sweep: NW * GPW consecutive columns
     const int kc0 = kt + wid * GPW;
-    if (!C::TILECOLS && kc0 >= NCOL) break;  // (the tile form has workgroup barriers inside: every wave makes every sweep)
+    if (kc0 >= NCOL) break;
     const int kc = kc0 + qid;
     const bool active = kc < NCOL;
     const int kcs = active ? kc : 1;
@@ -750,12 +700,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 #pragma unroll
     for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)bin_of(kcs) * L + kbase + k2];
     const bool paired = PAIRCOL && kc0 != 0;  // (the packed DC / Nyquist column takes the element-wise form)
-    constexpr bool tiled = C::TILECOLS;
-    if (tiled) {
-      tile_in(kt);
-      __syncthreads();
-      tile_load_column(x, wid * GPW + qid, active, 0);
-    } else if (paired) {
+    if (paired) {
       pair_load_columns(x, kc0, active, 0);
     } else {
       load_column(x, kcs, active, 0);
@@ -767,12 +712,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     LC_JSTAMP(12);
     group_fft_inv<L, LPF, true>(x, l16, TW);
     LC_JSTAMP(13);
-    if (tiled) {
-      tile_store_column(x, wid * GPW + qid, active, CREF);
-      __syncthreads();
-      tile_out(kt);
-      __syncthreads();
-    } else if (paired) {
+    if (paired) {
       pair_store_columns(x, kc0, active, CREF);
     } else {
       store_column(x, kcs, active, CREF);
@@ -1021,7 +961,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   } else if constexpr (PHASE == 0 || PHASE == 4) {
   for (int kt = part * C::NW * GPW; kt < NCOL; kt += PWS * GPW) {
     const int kc0 = kt + wid * GPW;
-    if (!C::TILECOLS && kc0 >= NCOL) break;
+    if (kc0 >= NCOL) break;
     const int kc = kc0 + qid;
     const bool active = kc < NCOL;
     const int kcs = active ? kc : 1;
@@ -1029,12 +969,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 #pragma unroll
     for (int k2 = 0; k2 < N2; ++k2) sv[k2] = Ste[(size_t)bin_of(kcs) * L + kbase + k2];
     const bool paired = PAIRCOL && kc0 != 0;
-    constexpr bool tiled = C::TILECOLS;
-    if (tiled) {
-      tile_in(kt);
-      __syncthreads();
-      tile_load_column(x, wid * GPW + qid, active, CREF);
-    } else if (paired) {
+    if (paired) {
       pair_load_columns(x, kc0, active, CREF);
     } else {
       load_column(x, kcs, active, CREF);
@@ -1042,12 +977,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     group_fft_fwd<L, LPF, true>(x, l16, TW);
     times_spectrum(x, sv, Ste, kcs, true);
     group_fft_inv<L, LPF, true>(x, l16, TW);
-    if (tiled) {
-      tile_store_column(x, wid * GPW + qid, active, 0);
-      __syncthreads();
-      tile_out(kt);
-      __syncthreads();
-    } else if (paired) {
+    if (paired) {
       pair_store_columns(x, kc0, active, 0);
     } else {
       store_column(x, kcs, active, 0);
