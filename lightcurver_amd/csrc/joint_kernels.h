@@ -778,20 +778,33 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         }
         x[k2] = z;
       }
+      // data and weights of the two rows: requested before the transform (used inside the per-pixel test below, each pixel
+      // would wait for its own four loads)
+      constexpr int NDH = (n + LPF - 1) / LPF;
+      float pw0[NDH], pw1[NDH], pd0[NDH], pd1[NDH];
+#pragma unroll
+      for (int t = 0; t < NDH; ++t) {
+        const int jd = l16 + LPF * t;
+        const bool ok = active && jd < n;
+        pw0[t] = ok ? we[I0 * n + jd] : 0.f;
+        pw1[t] = ok ? we[I1 * n + jd] : 0.f;
+        pd0[t] = ok ? de[I0 * n + jd] : 0.f;
+        pd1[t] = ok ? de[I1 * n + jd] : 0.f;
+      }
       group_fft_inv<LH, LPF>(x, l16, TWH);
 #pragma unroll
       for (int n2 = 0; n2 < N2H; ++n2) {
         const int jd = l16 + LPF * n2;
         float2 rw = make_float2(0.f, 0.f);
-        if (active && jd < n) {
+        if (n2 < NDH && active && jd < n) {
           const float2 y = x[n2];
-          const float w0 = we[I0 * n + jd], w1 = we[I1 * n + jd];
+          const float w0 = pw0[n2 < NDH ? n2 : 0], w1 = pw1[n2 < NDH ? n2 : 0];
           if (A.mode == 2) {
             acc_fis = fmaf(w0 * y.x, y.x, acc_fis);
             acc_fis = fmaf(w1 * y.y, y.y, acc_fis);
           } else {
             const float m0 = y.x + meane, m1 = y.y + meane;
-            const float r0 = m0 - de[I0 * n + jd], r1 = m1 - de[I1 * n + jd];
+            const float r0 = m0 - pd0[n2 < NDH ? n2 : 0], r1 = m1 - pd1[n2 < NDH ? n2 : 0];
             rw = make_float2(w0 * r0, w1 * r1);
             acc_chi = fmaf(rw.x, r0, acc_chi);
             acc_chi = fmaf(rw.y, r1, acc_chi);
