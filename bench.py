@@ -320,13 +320,15 @@ def sharded_joint_fit(ctx, rank, world, iters=500):
     return {'workload': f'C4 sharded: {E} epochs x {n}x{n} ROI over {world} ranks, {transport} of the shared block '
                         f'({n * ss * n * ss + 4 * M + 2} floats) once per iteration, {iters} iterations',
             'value': E * iters / dt, 'unit': 'cutouts/sec', 'us_per_iteration': dt * 1e6 / iters, 'scaling': 'strong',
-            'rccl_ranks': world, 'device_collective': bool(opt._dev), 'loss_finite': bool(np.all(np.isfinite(hist)))}
+            # what RCCL saw: the size of the nccl group the block was reduced over, 0 when the collective was gloo's
+            'rccl_ranks': dist.get_world_size(group) if opt._dev else 0, 'collective': 'rccl' if opt._dev else 'gloo',
+            'device_collective': bool(opt._dev), 'ranks': world, 'loss_finite': bool(np.all(np.isfinite(hist)))}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=50)   # 50 steps of ~40 ms: a timed region of about two seconds
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -18,7 +18,7 @@
 
 using namespace lc;
 
-constexpr int kMaxParts = 4;  // workgroups per epoch of the phased launches
+constexpr int kMaxParts = 16;  // workgroups per epoch of the phased launches
 typedef void (*epoch_fn)(JointArgs);
 typedef void (*update_fn)(JointUpdArgs);
 struct JointVariant {
@@ -35,6 +35,7 @@ struct JointVariant {
   epoch_fn ek_phase[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   epoch_fn ek_phase_tile[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int e_lds_lite = 0, e_lds_lite_tile = 0;  // LDS of the column phases and of phase D (JointCfg::LDS_LITE)
+  int lpf = 16;                             // lanes per transform (JointCfg::LPF)
 };
 
 typedef void (*mreg_fn)(MregArgs);
@@ -122,6 +123,7 @@ JointVariant make_jv_gm() {
   typedef JointCfg<N, SS, L, NW, true, LPF, true> CT;
   JointVariant v{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, nullptr, 0, 0, true, joint_epoch_kernel<C, true>,
                  joint_epoch_kernel<CT>, CT::LDS_BYTES};
+  v.lpf = LPF;
   v.ek_phase[0] = joint_epoch_kernel<C, false, 1>;
   v.ek_phase[1] = joint_epoch_kernel<C, false, 2>;
   v.ek_phase[2] = joint_epoch_kernel<C, false, 3>;
@@ -135,7 +137,8 @@ JointVariant make_jv_gm() {
   return v;
 }
 int g_debug_global = 0;  // lc_joint_set_debug_global: small stamps through the large-grid kernels (parity tests)
-const JointVariant *find_jv(int n, int ss) {
+// E, n_cu: epochs of the fit and compute units of the device (0: the default kernel of the stamp size)
+const JointVariant *find_jv(int n, int ss, int E = 0, int n_cu = 0) {
   if (g_debug_global) {
     static const JointVariant dbg[] = {
         make_jv_gm<32, 2, 48, 4>(),
@@ -143,6 +146,20 @@ const JointVariant *find_jv(int n, int ss) {
     };
     for (const auto &v : dbg)
       if (v.n == n && v.ss == ss) return &v;
+  }
+  // n = 64 (C4) with the epoch spread over several workgroups, one launch per phase, spectrum in global memory - the form
+  // the n = 128 kernels take below 129 epochs.  Built, tested (tests/test_joint_gpu.py, test_joint_paths_gpu.py) and NOT the
+  // default: measured on MI355X at the epoch counts a sharded C4 leaves per GPU it loses to one workgroup per epoch at every
+  // count (25 epochs: 72 against 68 us per iteration, 50: 85 / 69, 100: 107 / 71; with two-wave workgroups 80 / 99 / 142).
+  // rocprofv3: each of the six phase launches takes 8 - 11 us for 1 - 2 us of transforms (parameters -> tables -> rows ->
+  // transform -> store is a chain of dependent memory round trips per launch), 58 us per iteration against 55 us for the
+  // whole epoch in one workgroup.  LCMI_N128_SPLIT=1 selects it.
+  if (n == 64 && ss == 2 && E > 0) {
+    const char *sp = std::getenv("LCMI_N128_SPLIT");
+    if (sp && std::atoi(sp) != 0) {
+      static const JointVariant gm4 = make_jv_gm<128, 2, 192, 4, 16>();
+      return &gm4;
+    }
   }
   static const JointVariant table[] = {
       // FFT length L = 16 * N2, the smallest of 2^m and 3 * 2^m that keeps the 'same' window alias free (>= 3N/2)
@@ -294,10 +311,16 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   //  200 epochs 451 against 469 us.  LCMI_EPOCH_PARTS_COL: the count for the column phases alone, a tuning switch.)
   int parts = 1, parts_col = 1;
   if (v->ek_phase[0] && mode == 0 && j->part) {
-    parts = std::min(kMaxParts, std::max(1, j->ctx->n_cu / std::max(j->E, 1)));
+    // as many workgroups per epoch as leave no CU idle, and no more than one sweep of a phase has work for: the row phases
+    // of an epoch are N / 2 row pairs, its column phases L / 2 columns, a workgroup takes e_thr / LPF of them per sweep
+    const int per_wg = v->e_thr / v->lpf;
+    const int cap_row = std::max(1, (j->N / 2 + per_wg - 1) / per_wg), cap_col = std::max(1, (j->L / 2 + per_wg - 1) / per_wg);
+    const int fit = std::max(1, j->ctx->n_cu / std::max(j->E, 1));
+    parts = std::min({kMaxParts, fit, cap_row});
     if (const char *ep = std::getenv("LCMI_EPOCH_PARTS")) parts = std::min(kMaxParts, std::max(1, std::atoi(ep)));
-    parts_col = parts;
-    if (const char *ep = std::getenv("LCMI_EPOCH_PARTS_COL")) parts_col = std::min(2 * kMaxParts, std::max(1, std::atoi(ep)));
+    parts_col = (parts > 1) ? std::min({kMaxParts, std::max(fit, parts), cap_col}) : 1;
+    if (std::getenv("LCMI_EPOCH_PARTS")) parts_col = parts;
+    if (const char *ep = std::getenv("LCMI_EPOCH_PARTS_COL")) parts_col = std::min(kMaxParts, std::max(1, std::atoi(ep)));
   }
   const bool phased = parts > 1;
   bool tile = v->ek_tile && j->E * parts >= 96;
@@ -623,7 +646,7 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
     return LC_ERR_INVALID;
   }
   if (M > kMaxSources) LC_FAIL(ctx, LC_ERR_UNSUPPORTED, "at most 8 point sources");
-  const JointVariant *v = find_jv(n, ss);
+  const JointVariant *v = find_jv(n, ss, E, ctx->n_cu);
   if (!v) LC_FAIL(ctx, LC_ERR_UNSUPPORTED, "no joint-fit kernel instantiated for this stamp size");
   LC_HIP(ctx, hipSetDevice(ctx->device));
   lc_joint *j = new lc_joint();
@@ -1229,6 +1252,10 @@ int lc_joint_run_lbfgs(lc_joint *j, int maxiter, const float *const lower[LC_P_C
     }
   } guard{buf, &order_dev};
   LC_HIP(j->ctx, hipMalloc((void **)&order_dev, kLbMem * sizeof(int)));
+  // hipMalloc hands back recycled bytes: nothing below reads a vector before writing it, and the work space starts from
+  // zeros all the same (LCMI_LBFGS_POISON, a test hook, fills it with NaN patterns instead: the results must not change)
+  LC_HIP(j->ctx, hipMemsetAsync(buf, std::getenv("LCMI_LBFGS_POISON") ? 0xFF : 0, (nvec * D + kLbMem + 8) * sizeof(float), q));
+  LC_HIP(j->ctx, hipMemsetAsync(order_dev, 0, kLbMem * sizeof(int), q));
   LbfgsDev L;
   L.D = D;
   L.x = buf;
@@ -1277,8 +1304,7 @@ int lc_joint_run_lbfgs(lc_joint *j, int maxiter, const float *const lower[LC_P_C
   int rc;
   if ((rc = pack(j->par, L.x))) return rc;
   // start inside the box
-  hipLaunchKernelGGL(lb_trial_kernel, dim3(1), dim3(kLbThreads), 0, q, L, 0.f);
-  LC_HIP(j->ctx, hipMemcpyAsync(L.x, L.xt, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, q));
+  hipLaunchKernelGGL(lb_clip_kernel, dim3(1), dim3(kLbThreads), 0, q, L);
   if ((rc = unpack(L.x))) return rc;
   float f = 0.f;
   if ((rc = evaluate(L.g, f))) return rc;

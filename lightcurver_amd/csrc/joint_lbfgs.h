@@ -144,6 +144,11 @@ __global__ __launch_bounds__(kLbThreads) void lb_trial_kernel(LbfgsDev L, float 
   if (tid == 0) L.scal[3] = dec;
 }
 
+// starting point into the box: x = clip(x), in place (reads nothing but x and the bounds)
+__global__ __launch_bounds__(kLbThreads) void lb_clip_kernel(LbfgsDev L) {
+  for (int i = threadIdx.x; i < L.D; i += kLbThreads) L.x[i] = fminf(fmaxf(L.x[i], L.lo[i]), L.hi[i]);
+}
+
 // accepted step: (s, y) into ring slot `slot`, x <- xt, g <- gt; scal[4] = s . y, scal[5] = |s|^2, scal[6] = |y|^2
 __global__ __launch_bounds__(kLbThreads) void lb_accept_kernel(LbfgsDev L, int slot) {
   __shared__ float sh[kLbThreads / 64];

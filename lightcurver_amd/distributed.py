@@ -58,7 +58,8 @@ class ShardedJointOptimizer:
 
     def _agree_flux_reference(self):
         """The flux moments of the shared block are centred on one reference flux per source (include/lcmi.h):
-        every rank must use the same one, so the epoch-weighted mean of the local references is all-reduced once."""
+        every rank must use the same one, so the epoch-weighted mean of the local references is all-reduced (M + 1 numbers,
+        at the start of every run)."""
         self._ref_agreed = True
         if not (hasattr(self.fit, 'get_flux_reference') and hasattr(self.fit, 'set_flux_reference')):
             return
@@ -115,8 +116,9 @@ class ShardedJointOptimizer:
 
     def run(self, n_iter, **adabelief_cfg):
         on_device = bool(self._device_collective())
-        if not self._ref_agreed:
-            self._agree_flux_reference()
+        # agreed at the start of EVERY run: set_params(a=...) between two runs resets the local reference to the local
+        # mean (lc_joint_set_param), and ranks centring their flux moments on different references corrupt the reduced sums
+        self._agree_flux_reference()
         for _ in range(int(n_iter)):
             self.fit.step_local()
             if on_device:

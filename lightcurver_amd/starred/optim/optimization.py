@@ -43,9 +43,10 @@ class Optimizer:
             fit.run_adabelief(n_iter, **cfg)       # one call: the whole loop stays on the device
         elif n_iter > 0:
             # the parameter vector after every update (return_param_history) and / or the early stop need the host in
-            # the loop: the iterations run in chunks (1 for the history, 10 for the early stop alone); the optimiser
-            # state and the iteration count live on the device, so chunking does not change the trajectory
-            chunk = 1 if return_param_history else 10
+            # the loop: one iteration per call, so that the fit stops AT the update that raised the loss, as the host loop
+            # this replaces does; the optimiser state and the iteration count live on the device, so chunking does not
+            # change the trajectory
+            chunk = 1
             min_it = 0 if min_iterations is None else int(min_iterations)
             done = 0
             while done < n_iter:

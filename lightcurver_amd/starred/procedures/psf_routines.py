@@ -210,7 +210,18 @@ def _fit_with_distortion(images, data, weight, norms, stars, moffat, S_list, coo
             star_b.set_stars(st.reshape(F * S, 1, 4))
             return q
 
+        failure = []
+
         def evaluate(_user, Xp, Fp, Gp):
+            # (ctypes swallows an exception raised in a callback and returns 0: caught here, reported as a non-zero status so
+            #  that lc_batched_lbfgs stops instead of continuing on unwritten values, and re-raised after the call)
+            try:
+                return _evaluate(Xp, Fp, Gp)
+            except BaseException as exc:  # noqa: BLE001
+                failure.append(exc)
+                return 1
+
+        def _evaluate(Xp, Fp, Gp):
             X = np.ctypeslib.as_array(Xp, shape=(F, D)).copy()
             q = push(X)
             out = star_b.evaluate()
@@ -238,6 +249,8 @@ def _fit_with_distortion(images, data, weight, norms, stars, moffat, S_list, coo
         rc = lib.lc_batched_lbfgs(F, D, xf.ctypes.data_as(dp), np.ascontiguousarray(lo).ctypes.data_as(dp),
                                   np.ascontiguousarray(hi).ctypes.data_as(dp), n_iter_analytic, cb, None,
                                   fl.ctypes.data_as(dp), C.byref(nev))
+        if failure:
+            raise failure[0]
         if rc:
             raise _lib.LcError(f'lc_batched_lbfgs failed with status {rc}')
         push(xf)

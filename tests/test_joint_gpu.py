@@ -48,9 +48,30 @@ def _setup(ctx, E, M, n, ss, seed, alpha_sigma=0.0, with_h=True):
 @pytest.mark.parametrize('E,M,n,ss,alpha', [(3, 1, 16, 1, 0.0), (4, 2, 16, 2, 0.0), (3, 2, 16, 2, 2.0),
                                             (3, 3, 24, 2, 0.5), (2, 2, 32, 2, 0.3), (2, 2, 64, 2, 0.3),
                                             (3, 2, 64, 2, 0.0)])
-def test_model_loss_and_gradients(ctx, E, M, n, ss, alpha):
+def test_model_loss_and_gradients(ctx, E, M, n, ss, alpha, monkeypatch):
     # n = 64 is the instantiation BASELINE.json configs[3] (C4) runs: joint_epoch_kernel<JointCfg<128,2,192,...>> +
     # joint_update_kernel<128,16>; alpha = 0.3 exercises the ordered-gather T^T, alpha = 0 the 4-tap translation path
+    monkeypatch.delenv('LCMI_N128_SPLIT', raising=False)
+    _check_model_loss_and_gradients(ctx, E, M, n, ss, alpha)
+
+
+@pytest.mark.parametrize('parts', ['1', '4', '8', None])
+@pytest.mark.parametrize('E,M,alpha', [(3, 2, 0.0), (2, 2, 0.3)])
+def test_n64_epoch_spread_over_workgroups(ctx, monkeypatch, parts, E, M, alpha):
+    """BASELINE.json configs[3] sharded over GPUs leaves 25 - 100 epochs per GPU.  The 64 x 64 fit can spread an epoch
+    over several 4-wave workgroups, one launch per phase, spectrum in global memory (LCMI_N128_SPLIT=1; csrc/joint_fit.hip
+    find_jv - measured slower than one workgroup per epoch at every epoch count, so it is not the default;
+    LCMI_EPOCH_PARTS forces the count, 1 = one kernel, unset = what the device gets).  Same oracle, same tolerances as the
+    one-workgroup kernel."""
+    monkeypatch.setenv('LCMI_N128_SPLIT', '1')
+    if parts is None:
+        monkeypatch.delenv('LCMI_EPOCH_PARTS', raising=False)
+    else:
+        monkeypatch.setenv('LCMI_EPOCH_PARTS', parts)
+    _check_model_loss_and_gradients(ctx, E, M, 64, 2, alpha)
+
+
+def _check_model_loss_and_gradients(ctx, E, M, n, ss, alpha):
     ds, j, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 100 + n + M, alpha_sigma=alpha)
     N = n * ss
     W = om.propagate_noise_deconv(sig2, psf, ss)

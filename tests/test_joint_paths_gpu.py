@@ -156,6 +156,21 @@ def test_epoch_spread_over_workgroups_equals_the_one_workgroup_kernel(ctx, parts
     _compare(a, b, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 12, 1e-4)
 
 
+@pytest.mark.parametrize('parts', [None, '8', '4', '1'])
+def test_n64_fit_spread_over_workgroups_equals_the_one_workgroup_kernel(ctx, parts):
+    """64 x 64 ROIs (BASELINE.json configs[3]) with few epochs per GPU: the device loop through the phased launches of the
+    split form (LCMI_N128_SPLIT=1) against the one-workgroup LDS-spectrum kernel (the default).  Separate kernel builds,
+    partial sums added in another order."""
+    ds = make_roi_dataset(E=6, M=2, n=64, ss=2, seed=104)
+    env = {'LCMI_N128_SPLIT': '1'}
+    if parts:
+        env['LCMI_EPOCH_PARTS'] = parts
+    a = _fit(ctx, ds, 2, 15, env={'LCMI_N128_SPLIT': '0'})
+    b = _fit(ctx, ds, 2, 15, env=env)
+    assert np.max(np.abs(a[0] - b[0]) / np.abs(b[0])) < 2e-6
+    _compare(a, b, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 15, 1e-4)
+
+
 def test_update_waits_for_a_regulariser_chain_that_runs_late(ctx):
     """The fused update reads the regulariser's completion flag in the kernel.  Normally the chain is done before the
     epoch kernel ends and nothing waits; LCMI_REG_DELAY_US holds the second stream back by 300 us per iteration (five epoch

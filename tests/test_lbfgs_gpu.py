@@ -94,3 +94,27 @@ def test_bounds_are_respected_and_facade_takes_the_device_path(ctx):
     assert 'evaluations' in out[''][2] and 'scipy_result' in out['1'][2]
     assert abs(out[''][1] - out['1'][1]) / out['1'][1] < 1e-4
     assert np.abs(out[''][0] - out['1'][0]).max() < 5e-3 * max(np.abs(out['1'][0]).max(), 1.0)
+
+
+def test_recycled_work_space_does_not_reach_the_results(ctx, monkeypatch):
+    """lc_joint_run_lbfgs allocates its vectors per call; hipMalloc returns recycled bytes.  With the work space filled with
+    0xFF (NaN patterns, LCMI_LBFGS_POISON) instead of zeros, an unbounded fit with the background free - the case in which
+    a NaN read before the first write would move the starting point - must give the same iterates bit for bit."""
+    E, M, n, ss = 6, 2, 16, 2
+    out = []
+    for poison in (False, True):
+        ds, p, j = _problem(ctx, E, M, n, ss, seed=63)
+        j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0)
+        j.set_free(['a', 'dx', 'dy', 'h'])
+        if poison:
+            monkeypatch.setenv('LCMI_LBFGS_POISON', '1')
+        hist, nit, nev = j.run_lbfgs(15)                      # no bounds at all
+        monkeypatch.delenv('LCMI_LBFGS_POISON', raising=False)
+        got = j.get_params()
+        assert np.all(np.isfinite(hist)) and all(np.all(np.isfinite(v)) for v in got.values())
+        out.append((hist, nit, nev, got))
+        j.close()
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    assert np.array_equal(out[0][0], out[1][0])
+    for k in out[0][3]:
+        assert np.array_equal(out[0][3][k], out[1][3][k]), k

@@ -7,8 +7,9 @@ What is asserted, and why the chi2 bound differs between the cases:
 
 * default star photometry (point sources only, smooth loss): fluxes, shifts 1e-4 and chi2 1e-5 - the north-star numbers.
 * fits with the l1-starlet-regularised pixel grid / background (PSF stage B, ROI stage 2): fluxes and the positions the
-  data constrain within 1e-4 - the north-star numbers - and chi2 within 1e-4 (ROI stage 2; measured 6e-6) / 5e-4 (PSF
-  pixel grid).  tests/test_psf_cpu_port_cpu.py
+  data constrain within 1e-4 - the north-star numbers - and chi2 within 1e-4 (ROI stage 2; measured 6e-6); for the PSF
+  pixel grid the chi2 of the HIP path must be no further from the float64 result than the same fit run by two other
+  fp32 implementations (tests/golden/psf_converged_f32.npz: torch float32 oracle 8e-5 .. 2.5e-4, fp32 C port 4e-5 .. 6e-5).  tests/test_psf_cpu_port_cpu.py
   (test_two_float64_implementations_agree_but_fp32_trajectories_drift) shows where that floor comes from: two
   independent float64 implementations of the same fit agree to 1e-9 after 1000 iterations, while the fp32 build of one
   of them, on identical inputs, ends 1e-5 .. 1e-4 away in the loss - AdaBelief with eps = 1e-16 amplifies rounding at
@@ -42,15 +43,29 @@ def test_psf_fit_end_results_at_3000_iterations(ctx):
     stars = b.get_stars()
     res = b.results()
     hist = b.loss_history()
+    # the same fit by two other fp32 implementations (torch float32 oracle, fp32 build of oracle/psf_cpu.c; made by
+    # tests/golden/make_converged_f32_golden.py): how far fp32 lands from the float64 end result
+    g32 = np.load(os.path.join(GOLD, 'psf_converged_f32.npz'))
+    rel = lambda a, b: np.abs(np.asarray(a, np.float64) - b) / b
+    # spread of the fp32 end losses over both implementations and all frames (the per-frame draws scatter by 100 x)
+    loss_spread = max(rel(g32['loss_torch_f32'], g['loss_final']).max(), rel(g32['loss_c_f32'], g['loss_final']).max())
     for f in range(g['data'].shape[0]):
         flux = H.rel_err(stars[f][:, 0], g['a'][f])
         dx0, dy0 = np.abs(stars[f][:, 1] - g['x0'][f]).max(), np.abs(stars[f][:, 2] - g['y0'][f]).max()
         dchi = abs(res['chi2'][f] - g['chi2'][f]) / g['chi2'][f]
         dloss = abs(hist[f, -1] - g['loss_final'][f]) / g['loss_final'][f]
-        print('psf: flux', flux, 'x0', dx0, 'y0', dy0, 'chi2', dchi, 'loss', dloss)
+        dchi_t = abs(g32['chi2_torch_f32'][f] - g['chi2'][f]) / g['chi2'][f]
+        dchi_c = abs(g32['chi2_c_f32'][f] - g['chi2'][f]) / g['chi2'][f]
+        dloss_t = abs(g32['loss_torch_f32'][f] - g['loss_final'][f]) / g['loss_final'][f]
+        dloss_c = abs(g32['loss_c_f32'][f] - g['loss_final'][f]) / g['loss_final'][f]
+        print('psf: flux', flux, 'x0', dx0, 'y0', dy0, 'chi2', dchi, '(torch fp32', dchi_t, 'C fp32', dchi_c, ') loss', dloss,
+              '(torch fp32', dloss_t, 'C fp32', dloss_c, ')')
         assert flux < 1e-4                       # north-star level
         assert dx0 < 1e-4 and dy0 < 1e-4         # north-star level (data pixels)
-        assert dchi < 5e-4 and dloss < 5e-4      # fp32 floor of the l1 / AdaBelief trajectory, see the module docstring
+        # chi2: the HIP result is no further from the float64 end result than other fp32 implementations of the same fit
+        # (the reference computes in fp32 too); 1e-5 where the bracket itself allows it
+        assert dchi <= max(dchi_t, dchi_c, 1e-5), (dchi, dchi_t, dchi_c)
+        assert dloss <= max(loss_spread, 1e-5), (dloss, loss_spread)
 
 
 def test_joint_roi_fit_end_results_at_2000_iterations(ctx):

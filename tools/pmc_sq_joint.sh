@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out/pmc_joint_${E}_${n}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-LCMI_PTS=0.01 LCMI_FU=10 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/p1 -- python3 $REPO/tools/joint_speed.py $E $n $M 100 > $OUT/p1.log 2>&1
+LCMI_EVENT_SYNC=1 LCMI_PTS=0.01 LCMI_FU=10 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/p1 -- python3 $REPO/tools/joint_speed.py $E $n $M 100 > $OUT/p1.log 2>&1
 cd $REPO
 python3 - <<PY
 import csv, glob, collections
