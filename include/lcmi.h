@@ -222,6 +222,28 @@ int lc_joint_run_lbfgs(lc_joint *j, int maxiter, const float *const lower[LC_P_C
                        int *n_iterations, int *n_evaluations);
 int lc_joint_get_loss_history(lc_joint *j, float *history, int count);
 int lc_joint_iterations_done(lc_joint *j);
+/* Optimizer.minimize(..., return_param_history=True) - what the reference's own call sites pass
+ * (lightcurver/processes/star_photometry.py:115-122, roi_modelling.py:326-334).  begin: from now on every AdaBelief update
+ * also stores the free parameter blocks (in block order a, c_x, c_y, dx, dy, h, mean; *n_params = their total length) into
+ * a device-resident history of `capacity` rows, so the loop of lc_joint_run_adabelief stays on the device; updates past
+ * the capacity are not recorded.  get: rows [first, first + count) -> out [count][n_params] (one D2H copy, whenever the
+ * caller first looks at the history).  end: releases the buffer (also done by begin, set_free and destroy). */
+int lc_joint_param_history_begin(lc_joint *j, int capacity, int *n_params);
+int lc_joint_param_history_rows(lc_joint *j);
+int lc_joint_param_history_get(lc_joint *j, int first, int count, float *out);
+int lc_joint_param_history_end(lc_joint *j);
+/* Batched star photometry.  The reference fits its reference stars one after the other (the loop at
+ * lightcurver/processes/star_photometry.py:257 over do_one_star_forward_modelling, :23-151): G independent joint fits
+ * without a background, each over its own epochs.  Here they are ONE object: star g owns epochs_per_group[g] consecutive
+ * epochs of data / sigma2 / psf ([sum E_g][..]), M point sources with its own c_x, c_y (parameter blocks c_x, c_y have
+ * G * M entries, star-major; a, dx, dy, mean follow the epochs), and every AdaBelief iteration is one kernel pair for all
+ * stars (grid over (star, epoch), then one block per star for its reduction and update).  Each star's trajectory is bit
+ * for bit that of lc_joint_create + lc_joint_run_adabelief on that star alone.  h and alpha stay fixed; no weight cube,
+ * prior or point-source starlet term.  set/get_param, set_free, set_loss, run_adabelief, model, fisher_flux_sigma and
+ * iterations_done work as on a plain object; the loss history is per star. */
+int lc_joint_create_groups(lc_ctx *ctx, int G, const int32_t *epochs_per_group, int M, int n, int ss, const float *data,
+                           const float *sigma2, const float *psf, lc_joint **out);
+int lc_joint_get_group_loss_history(lc_joint *j, float *history /* [G][count_per_group] */, int count_per_group);
 /* FisherCovariance(diagonal_only=True) with only `a` free -> sigma(a) [E*M]
  * (lightcurver/utilities/starred_utilities.py:36-38). */
 int lc_joint_fisher_flux_sigma(lc_joint *j, float *sigma_a);
@@ -239,6 +261,30 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg); /* regularis
 /* host-staged access to the shared block (gloo / CPU collectives: D2H, all-reduce, H2D) */
 int lc_joint_shared_get(lc_joint *j, float *host, int count);
 int lc_joint_shared_set(lc_joint *j, const float *host, int count);
+/* The sharded loop without the host language in it: n_iter times { lc_joint_step_local; allreduce(user, block, count,
+ * stream); lc_joint_step_update }, enqueued from C++.  `allreduce` must sum-all-reduce the `count` floats at `dev_buf`
+ * over the ranks in place, ordered on `hip_stream` (= lc_ctx_stream: e.g. ncclAllReduce enqueued there, or
+ * lc_peer_allreduce below with user = the peer group), and return 0.  Every rank must have agreed on the flux reference
+ * (lc_joint_set_flux_reference) beforehand. */
+typedef int (*lc_allreduce_fn)(void *user, void *dev_buf, int count, void *hip_stream);
+int lc_joint_run_sharded(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg, lc_allreduce_fn allreduce, void *user);
+
+/* ---- peer group: one-shot all-reduce of the shared block through peer memory (xGMI, one hop) -------------------------------
+ * The block is 64 - 256 KiB and latency bound: every rank publishes it in an exchange buffer that the others map with HIP
+ * IPC, reads the N - 1 peers directly and adds in rank order (the same bits on every rank).  csrc/peer.hip.
+ *   create   count = lc_joint_shared_buffer_dev's count; rank / world of this process
+ *   export   this rank's IPC handle (64 bytes used of handle_bytes) - the caller carries the handles between the processes
+ *            (e.g. torch.distributed.all_gather_object)
+ *   connect  handles [world][handle_bytes], own entry ignored
+ *   lc_peer_allreduce   has the signature of lc_allreduce_fn with user = the group; all ranks must call it equally often
+ *   status   LC_ERR_DEVICE if a rank did not show up within ~2 s in some call (the kernels never wait longer) */
+typedef struct lc_peer_group lc_peer_group;
+int lc_peer_group_create(lc_ctx *ctx, int count, int rank, int world, lc_peer_group **out);
+int lc_peer_group_export(lc_peer_group *g, void *handle_out, int handle_bytes);
+int lc_peer_group_connect(lc_peer_group *g, const void *handles, int handle_bytes);
+int lc_peer_allreduce(void *group, void *dev_buf, int count, void *hip_stream);
+int lc_peer_group_status(lc_peer_group *g);
+void lc_peer_group_destroy(lc_peer_group *g);
 
 #ifdef __cplusplus
 }

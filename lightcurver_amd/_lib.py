@@ -22,6 +22,8 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int32)
 vp = C.c_void_p
 LBFGS_EVAL = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp, dp)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+IPC_HANDLE_BYTES = 64
 
 
 class AdabeliefCfg(C.Structure):
@@ -82,6 +84,8 @@ SIGNATURES = {
     'lc_joint_supported': (C.c_int, [C.c_int, C.c_int]),
     'lc_joint_set_debug_global': (C.c_int, [C.c_int]),
     'lc_joint_create': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.POINTER(vp)]),
+    'lc_joint_create_groups': (C.c_int, [vp, C.c_int, ip, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.POINTER(vp)]),
+    'lc_joint_get_group_loss_history': (C.c_int, [vp, fp, C.c_int]),
     'lc_joint_destroy': (None, [vp]),
     'lc_joint_set_param': (C.c_int, [vp, C.c_int, fp, C.c_int]),
     'lc_joint_get_param': (C.c_int, [vp, C.c_int, fp, C.c_int]),
@@ -97,12 +101,23 @@ SIGNATURES = {
     'lc_joint_run_lbfgs': (C.c_int, [vp, C.c_int, C.POINTER(fp), C.POINTER(fp), fp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'lc_joint_get_loss_history': (C.c_int, [vp, fp, C.c_int]),
     'lc_joint_iterations_done': (C.c_int, [vp]),
+    'lc_joint_param_history_begin': (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
+    'lc_joint_param_history_rows': (C.c_int, [vp]),
+    'lc_joint_param_history_get': (C.c_int, [vp, C.c_int, C.c_int, fp]),
+    'lc_joint_param_history_end': (C.c_int, [vp]),
     'lc_joint_fisher_flux_sigma': (C.c_int, [vp, fp]),
     'lc_joint_step_local': (C.c_int, [vp]),
     'lc_joint_shared_buffer_dev': (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int)]),
     'lc_joint_step_update': (C.c_int, [vp, C.POINTER(AdabeliefCfg)]),
     'lc_joint_shared_get': (C.c_int, [vp, fp, C.c_int]),
     'lc_joint_shared_set': (C.c_int, [vp, fp, C.c_int]),
+    'lc_joint_run_sharded': (C.c_int, [vp, C.c_int, C.POINTER(AdabeliefCfg), C.c_void_p, vp]),
+    'lc_peer_group_create': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    'lc_peer_group_export': (C.c_int, [vp, C.c_void_p, C.c_int]),
+    'lc_peer_group_connect': (C.c_int, [vp, C.c_void_p, C.c_int]),
+    'lc_peer_allreduce': (C.c_int, [vp, vp, C.c_int, vp]),
+    'lc_peer_group_status': (C.c_int, [vp]),
+    'lc_peer_group_destroy': (None, [vp]),
 }
 
 _lib = None

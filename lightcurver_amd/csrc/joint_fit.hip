@@ -86,6 +86,17 @@ struct lc_joint {
   bool flag_sync = false;            // this iteration's update checks reg_flag itself instead of waiting for evReg
   bool fuse_full = false;  // lc_joint_run_adabelief, background free: reduction over the epochs and update in one launch
   bool pts_pending = false;  // the point-source starlet term of this iteration was evaluated by the stream-B launch  // lc_joint_run_adabelief: scalar reduction fused into the update
+  // batched star photometry (lc_joint_create_groups): G stars, star g owns the epochs [gstart[g], gstart[g + 1]) and its own
+  // shared positions c_x, c_y [g * M ..]; the update runs one block per star (joint_update_groups_kernel)
+  int G = 0;
+  std::vector<int> gstart;
+  int *group_dev = nullptr;
+  JointUpdArgs *views_dev = nullptr;
+  float *ghist = nullptr, *shared_g = nullptr, *a_ref_g = nullptr, *out_loss_g = nullptr;
+  int ghist_cap = 0;
+  // return_param_history: device-resident [phist_cap][phist_P] rows of the free blocks, one per AdaBelief update
+  float *phist = nullptr;
+  int phist_cap = 0, phist_P = 0, phist_rows = 0, phist_off[LC_P_COUNT] = {};
   std::vector<float> h_sigma2, h_psf;  // host copies for the one-time noise propagation
   std::vector<void *> allocs;
 };
@@ -282,6 +293,7 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   A.model_out = model_out;
   A.part = j->part;
   A.fisher_out = j->fisher;
+  A.group = j->group_dev;
   // no background in the scene: separable Gaussian filtering of the epoch PSFs instead of the FFT pipeline
   if (!A.h_active && j->M > 0 && j->psf_dev && !std::getenv("LCMI_JOINT_FFT_ONLY")) {
     ps_fn pk = nullptr;
@@ -302,6 +314,7 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
       return 0;
     }
   }
+  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "batched star photometry runs the point-source-only kernel (LCMI_JOINT_FFT_ONLY is set?)");
   // global-spectrum kernels: with many workgroups in flight the 8 / 16-byte column accesses saturate L2 / Infinity Cache and
   // the LDS-tile variant of the column passes wins (128 x 128 ROIs: 32 epochs +1.4 %, 64 +-0, 125 -1 %, 160 -7 %, 200 -16 %,
   // 1000 -15 %; LCMI_TILE_COLS=0/1 overrides the choice)
@@ -555,6 +568,11 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   A.prior_cy_sigma = j->prior + 3 * j->M;
   if (cfg) A.ab = *cfg; else lc_adabelief_defaults(&A.ab);
   adabelief_schedule(A.ab, t, A.lr, A.bc1, A.bc2);
+  if (mode == 1 && reg_mode != 1 && j->phist && j->phist_rows < j->phist_cap) {
+    A.phist = j->phist + (size_t)j->phist_rows * j->phist_P;
+    for (int k = 0; k < LC_P_COUNT; ++k) A.poff[k] = j->phist_off[k];
+    j->phist_rows += 1;
+  }
   // the multi-block update serves the large grids always, and the LDS variants whenever nothing is left for one
   // workgroup to do alone (h regulariser already evaluated on the second stream, no point-source starlet term):
   // N^2 / 256 blocks finish the AdaBelief sweep of h in a fraction of the single-workgroup latency
@@ -639,12 +657,35 @@ int lc_joint_set_debug_global(int on) {
   return LC_OK;
 }
 
+static int joint_create_impl(lc_ctx *ctx, int E, int M, int n, int ss, const float *data, const float *sigma2,
+                             const float *psf, int G, const int32_t *epochs_per_group, lc_joint **out);
 int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data, const float *sigma2,
                     const float *psf, lc_joint **out) {
+  return joint_create_impl(ctx, E, M, n, ss, data, sigma2, psf, 0, nullptr, out);
+}
+int lc_joint_create_groups(lc_ctx *ctx, int G, const int32_t *epochs_per_group, int M, int n, int ss, const float *data,
+                           const float *sigma2, const float *psf, lc_joint **out) {
+  if (!ctx || G <= 0 || !epochs_per_group) {
+    if (ctx) ctx->err = "lc_joint_create_groups: invalid argument";
+    return LC_ERR_INVALID;
+  }
+  long long E = 0;
+  for (int g = 0; g < G; ++g) {
+    if (epochs_per_group[g] <= 0) LC_FAIL(ctx, LC_ERR_INVALID, "lc_joint_create_groups: every star needs at least one epoch");
+    E += epochs_per_group[g];
+  }
+  if (E > (1 << 24)) LC_FAIL(ctx, LC_ERR_INVALID, "lc_joint_create_groups: too many epochs");
+  if (M <= 0) LC_FAIL(ctx, LC_ERR_INVALID, "lc_joint_create_groups: at least one point source per star");
+  return joint_create_impl(ctx, (int)E, M, n, ss, data, sigma2, psf, G, epochs_per_group, out);
+}
+static int joint_create_impl(lc_ctx *ctx, int E, int M, int n, int ss, const float *data, const float *sigma2,
+                             const float *psf, int G, const int32_t *epochs_per_group, lc_joint **out) {
   if (!ctx || !out || !data || !sigma2 || !psf || E <= 0 || M < 0) {
     if (ctx) ctx->err = "lc_joint_create: invalid argument";
     return LC_ERR_INVALID;
   }
+  // grouped objects run the point-source-only kernel and nothing else: no spectra, no background work space
+  const bool lean = G > 0;
   if (M > kMaxSources) LC_FAIL(ctx, LC_ERR_UNSUPPORTED, "at most 8 point sources");
   const JointVariant *v = find_jv(n, ss, E, ctx->n_cu);
   if (!v) LC_FAIL(ctx, LC_ERR_UNSUPPORTED, "no joint-fit kernel instantiated for this stamp size");
@@ -668,7 +709,9 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
     lc_joint_destroy(j);   \
     return rc;             \
   }
-  const int sizes[LC_P_COUNT] = {E * M, M, M, E, E, E, (int)NN, E};
+  const int GM = std::max(G, 1) * M;
+  const int sizes[LC_P_COUNT] = {E * M, GM, GM, E, E, E, (int)NN, E};
+  j->G = G;
   for (int k = 0; k < LC_P_COUNT; ++k) {
     j->psize[k] = sizes[k];
     TRY(dmalloc(j, &j->par[k], sizes[k]));
@@ -678,10 +721,10 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   }
   TRY(dmalloc(j, &j->data, E * nn));
   TRY(dmalloc(j, &j->wgt, E * nn));
-  TRY(dmalloc(j, &j->St, (size_t)E * KH * L));
+  if (!lean) TRY(dmalloc(j, &j->St, (size_t)E * KH * L));
   TRY(dmalloc(j, &j->twid, L));
-  TRY(dmalloc(j, &j->tabs, (size_t)E * 4 * std::max(M, 1) * N));
-  TRY(dmalloc(j, &j->HG, E * NN));
+  if (!lean) TRY(dmalloc(j, &j->tabs, (size_t)E * 4 * std::max(M, 1) * N));
+  if (!lean) TRY(dmalloc(j, &j->HG, E * NN));
   TRY(dmalloc(j, &j->chi2_e, E));
   TRY(dmalloc(j, &j->g_a, E * M));
   TRY(dmalloc(j, &j->g_cx_e, E * M));
@@ -693,15 +736,29 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   TRY(dmalloc(j, &j->fisher, E * M));
   j->shared_count = (int)NN + 4 * M + 2;
   TRY(dmalloc(j, &j->shared, j->shared_count));
-  TRY(dmalloc(j, &j->W, (size_t)(j->J + 1) * NN));
+  TRY(dmalloc(j, &j->W, lean ? 1 : (size_t)(j->J + 1) * NN));
   TRY(dmalloc(j, &j->norms, j->J + 1));
-  TRY(dmalloc(j, &j->qscr, (size_t)(j->J + 1) * NN));
+  TRY(dmalloc(j, &j->qscr, lean ? 1 : (size_t)(j->J + 1) * NN));
   TRY(dmalloc(j, &j->out_loss, 4));
   TRY(dmalloc(j, &j->greg, NN));
   TRY(dmalloc(j, &j->regs, 4 + 3 * kMaxSources + 4));
-  if (v->gspec) TRY(dmalloc(j, &j->spec, (size_t)E * N * ((KH + 15) / 16 * 16)));  // rows padded to 128-byte lines (JointCfg::KS)
-  if (v->gspec) TRY(dmalloc(j, &j->part, (size_t)E * kMaxParts * (4 + 3 * kMaxSources)));
-  if (!v->uk) {
+  if (v->gspec && !lean) TRY(dmalloc(j, &j->spec, (size_t)E * N * ((KH + 15) / 16 * 16)));  // rows padded to 128-byte lines (JointCfg::KS)
+  if (v->gspec && !lean) TRY(dmalloc(j, &j->part, (size_t)E * kMaxParts * (4 + 3 * kMaxSources)));
+  if (lean) {
+    std::vector<int> grp(E);
+    j->gstart.assign(G + 1, 0);
+    for (int g = 0; g < G; ++g) {
+      j->gstart[g + 1] = j->gstart[g] + epochs_per_group[g];
+      for (int e = j->gstart[g]; e < j->gstart[g + 1]; ++e) grp[e] = g;
+    }
+    TRY(dmalloc(j, &j->group_dev, E));
+    TRY(h2d(j, j->group_dev, grp.data(), grp.size() * sizeof(int)));
+    TRY(dmalloc(j, &j->views_dev, G));
+    TRY(dmalloc(j, &j->shared_g, (size_t)G * (4 * M + 2)));
+    TRY(dmalloc(j, &j->a_ref_g, (size_t)G * kMaxSources));
+    TRY(dmalloc(j, &j->out_loss_g, G));
+  }
+  if (!v->uk && !lean) {
     const size_t nb = (NN + kGmThreads - 1) / kGmThreads;
     TRY(dmalloc(j, &j->gm_c, NN));
     TRY(dmalloc(j, &j->gm_t, NN));
@@ -712,7 +769,7 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
     TRY(dmalloc(j, &j->gm_pts, 8 + nb * 3 * kMaxSources));
     TRY(dmalloc(j, &j->gm_edge, (size_t)N * 4));
   }
-  j->mreg = find_mreg(N);
+  j->mreg = lean ? nullptr : find_mreg(N);
   if (j->mreg) {
     const size_t nb = (NN + kGmThreads - 1) / kGmThreads;
     std::vector<float> A, AT;
@@ -735,7 +792,7 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   LC_HIP(ctx, hipEventCreateWithFlags(&j->evReg, hipEventDisableTiming));
   LC_HIP(ctx, hipEventCreateWithFlags(&j->evUpd, hipEventDisableTiming));
   LC_HIP(ctx, hipEventRecord(j->evUpd, ctx->stream));
-  TRY(dmalloc(j, &j->scene2, 2 * NN));
+  TRY(dmalloc(j, &j->scene2, lean ? 1 : 2 * NN));
   TRY(dmalloc(j, &j->prior, 4 * std::max(M, 1)));
   TRY(dmalloc(j, &j->a_ref, kMaxSources));
   TRY(ensure_hist(j, 64));
@@ -764,10 +821,19 @@ int lc_joint_create(lc_ctx *ctx, int E, int M, int n, int ss, const float *data,
   }
   {
     // PSF spectra: FFT2 of the zero-padded narrow PSF, stored transposed and pre-divided by L^2
-    j->h_psf.assign(psf, psf + E * NN);
+    if (!lean) j->h_psf.assign(psf, psf + E * NN);
     TRY(dmalloc(j, &j->psf_dev, (size_t)E * NN));
     TRY(h2d(j, j->psf_dev, psf, (size_t)E * NN * sizeof(float)));
-    if (!std::getenv("LCMI_SPECTRA_HOST")) {
+    if (lean) {
+      ps_fn pk = nullptr;
+      int plds = 0;
+      find_ps_kernel(N, ss, &pk, &plds);
+      if (!pk) {
+        ctx->err = "lc_joint_create_groups: no point-source kernel for this stamp size";
+        lc_joint_destroy(j);
+        return LC_ERR_UNSUPPORTED;
+      }
+    } else if (!std::getenv("LCMI_SPECTRA_HOST")) {
       // on the device: the row / column FFT passes of the epoch kernel in its spectrum mode
       TRY(launch_aux(j, 4, j->psf_dev, nullptr, j->St, nullptr));
     } else {
@@ -812,6 +878,8 @@ void lc_joint_destroy(lc_joint *j) {
   if (j->evUpd) hipEventDestroy(j->evUpd);
   for (void *p : j->allocs) hipFree(p);
   if (j->hist) hipFree(j->hist);
+  if (j->ghist) hipFree(j->ghist);
+  if (j->phist) hipFree(j->phist);
   delete j;
 }
 
@@ -827,7 +895,19 @@ int lc_joint_set_param(lc_joint *j, int which, const float *values, int count) {
         break;
       }
   }
-  if (which == LC_P_A && j->M > 0) {
+  if (j->G > 0 && which == LC_P_H && j->h_nonzero)
+    LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "batched star photometry has no background: h must stay zero");
+  if (j->G > 0 && which == LC_P_A) {  // one reference per star and source: the mean over that star's epochs
+    std::vector<float> ref((size_t)j->G * kMaxSources, 0.f);
+    for (int g = 0; g < j->G; ++g)
+      for (int i = 0; i < j->M; ++i) {
+        double acc = 0.0;
+        for (int e = j->gstart[g]; e < j->gstart[g + 1]; ++e) acc += values[(size_t)e * j->M + i];
+        ref[(size_t)g * kMaxSources + i] = (float)(acc / (j->gstart[g + 1] - j->gstart[g]));
+      }
+    int rc = h2d(j, j->a_ref_g, ref.data(), ref.size() * sizeof(float));
+    if (rc) return rc;
+  } else if (which == LC_P_A && j->M > 0) {
     // reference fluxes of the centred flux moments: the mean of the values set here (a sharded fit overrides them
     // with one reference for all ranks, lc_joint_set_flux_reference)
     float ref[kMaxSources] = {};
@@ -865,7 +945,9 @@ int lc_joint_set_free(lc_joint *j, const int32_t *free_mask) {
   if (!j || !free_mask) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
   if (free_mask[LC_P_ALPHA]) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "alpha is never optimised (roi_modelling.py:221-222)");
+  if (j->G > 0 && free_mask[LC_P_H]) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "batched star photometry has no background grid");
   for (int k = 0; k < LC_P_COUNT; ++k) j->free_mask[k] = free_mask[k] ? 1 : 0;
+  lc_joint_param_history_end(j);  // (its row layout follows the free blocks)
   // a new optimisation starts: reset the moments and the iteration counter
   for (int k = 0; k < LC_P_COUNT; ++k) {
     LC_HIP(j->ctx, hipMemsetAsync(j->pm[k], 0, (size_t)std::max(j->psize[k], 1) * sizeof(float), j->ctx->stream));
@@ -877,6 +959,8 @@ int lc_joint_set_free(lc_joint *j, const int32_t *free_mask) {
 int lc_joint_set_loss(lc_joint *j, const lc_joint_loss_cfg *cfg, const float *W) {
   if (!j || !cfg) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
+  if (j->G > 0 && (cfg->lam_pts_source != 0.f || cfg->n_prior > 0 || W))
+    LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "batched star photometry: no point-source starlet term, prior or weight cube");
   j->cfg = *cfg;
   j->n_prior = 0;
   if (cfg->n_prior > 0) {
@@ -942,6 +1026,7 @@ int propagate_noise_device(lc_joint *j) {
 int lc_joint_propagate_noise(lc_joint *j, float *W_out) {
   if (!j) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
+  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_propagate_noise: not available on a batched star-photometry object");
   const int N = j->N, n = j->n, ss = j->ss, E = j->E, c = (N - 1) / 2;
   const size_t NN = (size_t)N * N, nn = (size_t)n * n;
   if (!std::getenv("LCMI_NOISE_HOST")) {
@@ -995,6 +1080,7 @@ int lc_joint_propagate_noise(lc_joint *j, float *W_out) {
 int lc_joint_step_local(lc_joint *j) {
   if (!j) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
+  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_step_local: not available on a batched star-photometry object");
   j->reg_pending = false;
   // inside lc_joint_run_adabelief (one GPU: the mean fluxes are all local) the point-source starlet term, which depends
   // on the current a, c_x, c_y only, is evaluated with the background regulariser on the second stream
@@ -1039,6 +1125,7 @@ int lc_joint_shared_set(lc_joint *j, const float *host, int count) {
 int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   if (!j) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
+  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_step_update: not available on a batched star-photometry object");
   int rc = ensure_hist(j, j->iters_done + 2);
   if (rc) return rc;
   // the regulariser chain of this iteration was enqueued (second stream) before the epoch kernel.  The fused update checks
@@ -1061,9 +1148,24 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   return LC_OK;
 }
 
+int lc_joint_run_sharded(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg, lc_allreduce_fn allreduce, void *user) {
+  if (!j || n_iter < 0 || !allreduce) return LC_ERR_INVALID;
+  int rc = ensure_hist(j, j->iters_done + n_iter + 2);
+  for (int it = 0; it < n_iter && !rc; ++it) {
+    if ((rc = lc_joint_step_local(j))) break;
+    if (allreduce(user, j->shared, j->shared_count, (void *)j->ctx->stream)) {
+      j->ctx->err = "lc_joint_run_sharded: the all-reduce callback failed";
+      return LC_ERR_DEVICE;
+    }
+    rc = lc_joint_step_update(j, cfg);
+  }
+  return rc;
+}
+
 int lc_joint_loss_grad(lc_joint *j, float *loss, float *const grads[LC_P_COUNT]) {
   if (!j) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
+  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_loss_grad: not available on a batched star-photometry object");
   const bool want_h = grads && grads[LC_P_H];
   int need = launch_epochs(j, 0, 0, want_h, nullptr);
   if (need < 0) return need;
@@ -1093,6 +1195,7 @@ int lc_joint_model(lc_joint *j, float *model, float *chi2_per_epoch) {
 int lc_joint_deconvolved(lc_joint *j, int epoch, float *scene, float *background) {
   if (!j || epoch < 0 || epoch >= j->E) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
+  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_deconvolved: not available on a batched star-photometry object");
   const size_t NN = (size_t)j->N * j->N;
   hipLaunchKernelGGL(joint_scene_kernel, dim3(64), dim3(256), 0, j->ctx->stream, j->N, j->ss, j->M, epoch, j->par[LC_P_A],
                      j->par[LC_P_CX], j->par[LC_P_CY], j->par[LC_P_DX], j->par[LC_P_DY], j->par[LC_P_ALPHA],
@@ -1115,7 +1218,7 @@ static int run_adabelief_persistent(lc_joint *j, int n_iter, const lc_adabelief_
                        j->n_prior > 0;
   const bool any_free = j->free_mask[LC_P_A] || j->free_mask[LC_P_DX] || j->free_mask[LC_P_DY] || j->free_mask[LC_P_MEAN];
   if (coupled || !any_free || j->M <= 0 || j->M > kMaxSources || !j->psf_dev || std::getenv("LCMI_JOINT_FFT_ONLY") ||
-      std::getenv("LCMI_PS_LOOP"))
+      std::getenv("LCMI_PS_LOOP") || (j->phist && j->phist_rows + n_iter > j->phist_cap))
     return LC_OK;
   ps_fn pk = nullptr;
   int plds = 0;
@@ -1175,6 +1278,15 @@ static int run_adabelief_persistent(lc_joint *j, int n_iter, const lc_adabelief_
   P.pm_mean = j->pm[LC_P_MEAN];
   P.ps_mean = j->ps[LC_P_MEAN];
   P.hist_e = d_hist_e;
+  if (j->phist) {  // return_param_history: the kernel writes the rows of its iterations itself
+    P.phist = j->phist + (size_t)j->phist_rows * j->phist_P;
+    P.phist_P = j->phist_P;
+    P.poff_a = j->phist_off[LC_P_A];
+    P.poff_dx = j->phist_off[LC_P_DX];
+    P.poff_dy = j->phist_off[LC_P_DY];
+    P.poff_mean = j->phist_off[LC_P_MEAN];
+    j->phist_rows += n_iter;
+  }
   LC_HIP(j->ctx, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
   hipLaunchKernelGGL(pk, dim3(j->E), dim3(kPsThreads), plds, q, P);
   hipLaunchKernelGGL(joint_ps_hist_kernel, dim3(n_iter), dim3(64), 0, q, j->E, n_iter, d_hist_e, j->hist + j->iters_done);
@@ -1185,9 +1297,100 @@ static int run_adabelief_persistent(lc_joint *j, int n_iter, const lc_adabelief_
   return LC_OK;
 }
 
+// ---- batched star photometry: every star of the batch advances by one iteration per kernel pair ----------------------------
+namespace {
+int ensure_group_hist(lc_joint *j, int needed) {
+  if (needed <= j->ghist_cap) return LC_OK;
+  const int nc = std::max(needed, 2 * j->ghist_cap + 64);
+  float *nh = nullptr;
+  LC_HIP(j->ctx, hipMalloc((void **)&nh, (size_t)j->G * nc * sizeof(float)));
+  LC_HIP(j->ctx, hipMemsetAsync(nh, 0, (size_t)j->G * nc * sizeof(float), j->ctx->stream));
+  if (j->ghist) {
+    LC_HIP(j->ctx, hipMemcpy2DAsync(nh, (size_t)nc * sizeof(float), j->ghist, (size_t)j->ghist_cap * sizeof(float),
+                                    (size_t)j->ghist_cap * sizeof(float), j->G, hipMemcpyDeviceToDevice, j->ctx->stream));
+    LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+    hipFree(j->ghist);
+  }
+  j->ghist = nh;
+  j->ghist_cap = nc;
+  return LC_OK;
+}
+// the per-star views of the update arguments (pointers offset to the star's epochs), uploaded before a run
+int upload_group_views(lc_joint *j, const lc_adabelief_cfg *cfg) {
+  const int M = j->M;
+  std::vector<JointUpdArgs> views(j->G);
+  for (int g = 0; g < j->G; ++g) {
+    JointUpdArgs &A = views[g];
+    std::memset(&A, 0, sizeof(A));
+    const int e0 = j->gstart[g];
+    A.E = j->gstart[g + 1] - e0;
+    A.M = M;
+    A.ss = j->ss;
+    A.fuse_scalar_reduce = 1;
+    const size_t off[LC_P_COUNT] = {(size_t)e0 * M, (size_t)g * M, (size_t)g * M, (size_t)e0, (size_t)e0, (size_t)e0, 0, (size_t)e0};
+    for (int k = 0; k < LC_P_COUNT; ++k) {
+      A.free_mask[k] = j->free_mask[k];
+      A.par[k] = j->par[k] + off[k];
+      A.pm[k] = j->pm[k] + off[k];
+      A.ps[k] = j->ps[k] + off[k];
+    }
+    A.shared = A.shared_w = j->shared_g + (size_t)g * (4 * M + 2);
+    A.a_ref = j->a_ref_g + (size_t)g * kMaxSources;
+    A.g_a = j->g_a + (size_t)e0 * M;
+    A.g_cx_e = j->g_cx_e + (size_t)e0 * M;
+    A.g_cy_e = j->g_cy_e + (size_t)e0 * M;
+    A.g_dx = j->g_dx + e0;
+    A.g_dy = j->g_dy + e0;
+    A.g_mean = j->g_mean + e0;
+    A.chi2_e = j->chi2_e + e0;
+    A.hist = j->ghist + (size_t)g * j->ghist_cap;
+    A.out_loss = j->out_loss_g + g;
+    A.lam_pos_ps = j->cfg.lam_positivity_ps;
+    A.lam_fu = j->cfg.lam_flux_uniformity;
+    if (cfg) A.ab = *cfg; else lc_adabelief_defaults(&A.ab);
+  }
+  return h2d(j, j->views_dev, views.data(), views.size() * sizeof(JointUpdArgs));
+}
+int group_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg) {
+  lc_adabelief_cfg ab;
+  if (cfg) ab = *cfg; else lc_adabelief_defaults(&ab);
+  float lr, bc1, bc2;
+  adabelief_schedule(ab, t, lr, bc1, bc2);
+  hipLaunchKernelGGL(joint_update_groups_kernel, dim3(j->G), dim3(kGmThreads), 0, j->ctx->stream, j->views_dev, mode, t, lr, bc1, bc2);
+  LC_HIP(j->ctx, hipGetLastError());
+  return LC_OK;
+}
+int run_adabelief_groups(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg) {
+  int rc = ensure_group_hist(j, j->iters_done + n_iter + 2);
+  if (rc || (rc = upload_group_views(j, cfg))) return rc;
+  for (int it = 0; it < n_iter; ++it) {
+    int need = launch_epochs(j, 0, 0, false, nullptr);
+    if (need < 0) return need;
+    if ((rc = group_update(j, 1, j->iters_done, cfg))) return rc;
+    j->iters_done += 1;
+  }
+  return LC_OK;
+}
+}  // namespace
+
+int lc_joint_get_group_loss_history(lc_joint *j, float *history, int count_per_group) {
+  if (!j || !history || j->G <= 0 || count_per_group < j->iters_done + 1) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
+  int rc = ensure_group_hist(j, j->iters_done + 2);
+  if (rc || (rc = upload_group_views(j, nullptr))) return rc;
+  int need = launch_epochs(j, 0, 0, false, nullptr);  // loss of the final parameters -> hist[g][T]
+  if (need < 0) return need;
+  if ((rc = group_update(j, 0, j->iters_done, nullptr))) return rc;
+  LC_HIP(j->ctx, hipMemcpy2DAsync(history, (size_t)count_per_group * sizeof(float), j->ghist, (size_t)j->ghist_cap * sizeof(float),
+                                  (size_t)(j->iters_done + 1) * sizeof(float), j->G, hipMemcpyDeviceToHost, j->ctx->stream));
+  LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+  return LC_OK;
+}
+
 int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg) {
   if (!j || n_iter <= 0) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
+  if (j->G > 0) return run_adabelief_groups(j, n_iter, cfg);
   int rc = ensure_hist(j, j->iters_done + n_iter + 2);
   if (rc) return rc;
   bool done = false;
@@ -1215,11 +1418,51 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
 }
 int lc_joint_iterations_done(lc_joint *j) { return j ? j->iters_done : LC_ERR_INVALID; }
 
+int lc_joint_param_history_end(lc_joint *j) {
+  if (!j) return LC_ERR_INVALID;
+  if (j->phist) {
+    LC_ENTER(j->ctx);
+    LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+    (void)hipFree(j->phist);
+  }
+  j->phist = nullptr;
+  j->phist_cap = j->phist_P = j->phist_rows = 0;
+  return LC_OK;
+}
+int lc_joint_param_history_begin(lc_joint *j, int capacity, int *n_params) {
+  if (!j || capacity <= 0) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
+  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_param_history_begin: not available on a batched star-photometry object");
+  int rc = lc_joint_param_history_end(j);
+  if (rc) return rc;
+  int P = 0;
+  for (int k = 0; k < LC_P_COUNT; ++k) {
+    j->phist_off[k] = j->free_mask[k] ? P : -1;
+    if (j->free_mask[k]) P += j->psize[k];
+  }
+  if (n_params) *n_params = P;
+  if (P == 0) return LC_OK;
+  LC_HIP(j->ctx, hipMalloc((void **)&j->phist, (size_t)capacity * P * sizeof(float)));
+  j->phist_cap = capacity;
+  j->phist_P = P;
+  j->phist_rows = 0;
+  return LC_OK;
+}
+int lc_joint_param_history_rows(lc_joint *j) { return j ? j->phist_rows : LC_ERR_INVALID; }
+int lc_joint_param_history_get(lc_joint *j, int first, int count, float *out) {
+  if (!j || !out || first < 0 || count < 0) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
+  if (first + count > j->phist_rows) LC_FAIL(j->ctx, LC_ERR_INVALID, "lc_joint_param_history_get: rows not recorded");
+  if (count == 0) return LC_OK;
+  return d2h(j, out, j->phist + (size_t)first * j->phist_P, (size_t)count * j->phist_P * sizeof(float));
+}
+
 // ---- bounded L-BFGS with the vectors on the device (csrc/joint_lbfgs.h) ------------------------------------------------
 int lc_joint_run_lbfgs(lc_joint *j, int maxiter, const float *const lower[LC_P_COUNT], const float *const upper[LC_P_COUNT],
                        float *loss_history, int history_capacity, int *n_iterations, int *n_evaluations) {
   if (!j || maxiter < 0) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
+  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_run_lbfgs: not available on a batched star-photometry object");
   int D = 0, off[LC_P_COUNT] = {};
   for (int k = 0; k < LC_P_COUNT; ++k) {
     off[k] = D;
@@ -1380,6 +1623,7 @@ int lc_joint_run_lbfgs(lc_joint *j, int maxiter, const float *const lower[LC_P_C
 int lc_joint_get_loss_history(lc_joint *j, float *history, int count) {
   if (!j || !history || count < j->iters_done + 1) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
+  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_get_loss_history (use lc_joint_get_group_loss_history): not available on a batched star-photometry object");
   int rc = ensure_hist(j, j->iters_done + 2);
   if (rc) return rc;
   int need = launch_epochs(j, 0, 0, false, nullptr);  // loss of the final parameters -> hist[T]

@@ -261,6 +261,7 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
       A.par[LC_P_A][idx] = av;
       A.pm[LC_P_A][idx] = pmv;
       A.ps[LC_P_A][idx] = psv;
+      phist_put(A, LC_P_A, idx, av);
     }
   };
   if (parts & 1) {
@@ -284,6 +285,7 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
       float pv_ = A.par[which][e];
       adabelief_step(pv_, A.pm[which][e], A.ps[which][e], gv, lr, bc1, bc2, A.ab);
       A.par[which][e] = pv_;
+      phist_put(A, which, e, pv_);
     }
   }
   if (!(parts & 1)) return;
@@ -305,6 +307,7 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
     } else if (A.free_mask[which]) {
       adabelief_step(cv, A.pm[which][i], A.ps[which][i], gv, lr, bc1, bc2, A.ab);
       A.par[which][i] = cv;
+      phist_put(A, which, i, cv);
     }
   }
   // loss = 0.5 chi2 + l1 + positivity + positivity of fluxes + flux uniformity + prior
@@ -349,10 +352,31 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
       A.h[k] = hv;
       A.mh[k] = m;
       A.sh[k] = s;
+      phist_put(A, LC_P_H, k, hv);
     }
   }
   if (blockIdx.x != 0) return;
   gm_small_blocks(A, N, lr, bc1, bc2, A.shared + NN, 3);
+}
+
+// Batched star photometry (lightcurver/processes/star_photometry.py:257: the reference fits its <= 30 stars one after the
+// other): block g applies to star g - the epochs [e0, e1) of the batch, through the pointers of views[g] - exactly what the
+// one-block launch of joint_update_gm_kernel applies to a fit of that star alone: the same scalar reduction over its
+// epochs, the same gradient rules, the same AdaBelief step, its own loss history.  Same operands in the same order, so a
+// star of the batch ends bit for bit where its separate fit ends (tests/test_star_batch_gpu.py).
+__global__ __launch_bounds__(kGmThreads) void joint_update_groups_kernel(const JointUpdArgs *views, int mode, int t, float lr,
+                                                                         float bc1, float bc2) {
+  __shared__ double lanes[kGmThreads];
+  JointUpdArgs A = views[blockIdx.x];  // (block-uniform: scalar loads)
+  A.mode = mode;
+  A.t = t;
+  A.lr = lr;
+  A.bc1 = bc1;
+  A.bc2 = bc2;
+  __shared__ float scl[4 * kMaxSources + 2];  // (the sums also go to LDS: the rules below read them without a trip through L2)
+  reduce_scalars(A.E, A.M, 0, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.a_ref, A.shared_w, lanes, threadIdx.x, scl);
+  __syncthreads();
+  gm_small_blocks(A, 0, lr, bc1, bc2, scl, 3);
 }
 
 // The reduction over the epochs and the update in ONE launch (the device loop of a single GPU, where nothing has to
@@ -388,6 +412,7 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointU
         A.h[px] = hv;
         A.mh[px] = m;
         A.sh[px] = sv;
+        phist_put(A, LC_P_H, px, hv);
       }
       __syncthreads();  // the partial sums in LDS are rewritten by the next tile
     }

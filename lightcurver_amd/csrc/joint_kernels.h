@@ -46,6 +46,8 @@ struct JointArgs {
   const float *scene_in;      // [E][N][N]
   float2 *St_out;             // [E][L/2+1][L]
   float *conv_out;            // [E][N][N]
+  // batched star photometry (point-source-only kernel): epoch -> star; the shared positions are cx[group[e] * M + i]
+  const int *group;           // [E] or null
 };
 
 __device__ __forceinline__ void sample_coords(int u, int v, float c0, float ca, float sa, float sdx, float sdy,
@@ -1423,7 +1425,16 @@ struct JointUpdArgs {
   const unsigned int *wait_flag;
   unsigned int wait_seq;
   unsigned int *wait_err;
+  // return_param_history (reference call sites star_photometry.py:115-122, roi_modelling.py:326-334): the row of the
+  // device-resident history [iterations][P] this update fills - every free block at its offset poff[which] (-1: fixed),
+  // written where the parameter itself is stored, so the loop stays on the device
+  float *phist;
+  int poff[LC_P_COUNT];
 };
+// (one extra store next to the store of an updated parameter)
+__device__ __forceinline__ void phist_put(const JointUpdArgs &A, int which, int idx, float v) {
+  if (A.phist && A.poff[which] >= 0) A.phist[A.poff[which] + idx] = v;
+}
 
 // All threads of a block: block until *flag has reached seq (thread 0 polls, bounded: ~0.2 s).  No acquire fence follows: an
 // agent-scope acquire invalidates the L2 of the XCD, and a thousand blocks doing that cost 33 us; the few values the
@@ -1659,6 +1670,8 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
       *(float4 *)(A.h + pix + 4 * q) = make_float4(hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]);
       *(float4 *)(A.mh + pix + 4 * q) = m;
       *(float4 *)(A.sh + pix + 4 * q) = s;
+      if (A.phist && A.poff[LC_P_H] >= 0)
+        *(float4 *)(A.phist + A.poff[LC_P_H] + pix + 4 * q) = make_float4(hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]);
     }
   }
   // ---- per-epoch parameters: a (E*M), dx, dy, mean (E) ----
@@ -1683,6 +1696,7 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
     } else if (A.free_mask[LC_P_A]) {
       adabelief_step(av, A.pm[LC_P_A][idx], A.ps[LC_P_A][idx], ga, lr, bc1, bc2, A.ab);
       A.par[LC_P_A][idx] = av;
+      phist_put(A, LC_P_A, idx, av);
     }
   }
   for (int idx = tid; idx < 3 * E; idx += NTHR) {
@@ -1695,6 +1709,7 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
       float pv_ = A.par[which][e];
       adabelief_step(pv_, A.pm[which][e], A.ps[which][e], gv, lr, bc1, bc2, A.ab);
       A.par[which][e] = pv_;
+      phist_put(A, which, e, pv_);
     }
   }
   // ---- shared point-source positions ----
@@ -1713,6 +1728,7 @@ __global__ __launch_bounds__(N *N / PX) void joint_update_kernel(JointUpdArgs A)
     } else if (A.free_mask[which]) {
       adabelief_step(cv, A.pm[which][i], A.ps[which][i], gv, lr, bc1, bc2, A.ab);
       A.par[which][i] = cv;
+      phist_put(A, which, i, cv);
     }
   }
   // ---- loss (positivity of fluxes reduced here) ----

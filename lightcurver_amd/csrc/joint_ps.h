@@ -53,6 +53,9 @@ struct JointPsArgs {
   float *par_a, *par_dx, *par_dy, *par_mean;  // [E*M], [E], [E], [E]: read at the start, written at the end
   float *pm_a, *ps_a, *pm_dx, *ps_dx, *pm_dy, *ps_dy, *pm_mean, *ps_mean;  // AdaBelief moments, same shapes
   float *hist_e;                       // [E][T] this epoch's share of the loss before every update
+  // return_param_history: rows [T][phist_P] of the device-resident history; offsets of the free blocks in a row (-1: fixed)
+  float *phist;
+  int phist_P, poff_a, poff_dx, poff_dy, poff_mean;
 };
 
 // PERSIST: when every free parameter belongs to one epoch (fluxes, shifts, sky levels; the shared positions c_x, c_y held
@@ -107,11 +110,22 @@ __global__ __launch_bounds__(kPsThreads) void joint_ps_kernel(JointPsArgs P) {
     meane = PP[M + 2];
   }
   auto flux = [&](int i) { return PERSIST ? PP[i] : A.a[e * M + i]; };
+  // One point source (every star-photometry fit): the filter outputs of a thread's pixels stay in its registers from the
+  // column pass to the residuals, instead of travelling through the global scratch F and back (3 n^2 floats each way per
+  // epoch and iteration: half of the memory traffic of a batch of thousands of epochs).
+  constexpr int LSF = 4, NITF = ((n / LSF) * n + kPsThreads - 1) / kPsThreads;
+  const bool single = (M == 1);
+  float fvr[NITF][LSF], fxr[NITF][LSF], fyr[NITF][LSF];
+#pragma unroll
+  for (int t = 0; t < NITF; ++t)
+#pragma unroll
+    for (int jj = 0; jj < LSF; ++jj) fvr[t][jj] = fxr[t][jj] = fyr[t][jj] = 0.f;
   for (int i = 0; i < M; ++i) {
     __syncthreads();  // PSF tile loaded; previous source's passes done with TAP / R
     if (tid < 2 * NT) {
       const int ax = tid / NT, k = tid % NT;
-      const float X = SS * (ca * A.cx[i] - sa * A.cy[i] + dxe), Y = SS * (sa * A.cx[i] + ca * A.cy[i] + dye);
+      const int gi = (A.group ? A.group[e] : 0) * M + i;  // (batched star photometry: the positions of this epoch's star)
+      const float X = SS * (ca * A.cx[gi] - sa * A.cy[gi] + dxe), Y = SS * (sa * A.cx[gi] + ca * A.cy[gi] + dye);
       float tap, dtap;
       int bq;
       ps_tap<N, SS, NT>((ax == 0 ? X : Y) + c_off, k, tap, dtap, bq);
@@ -121,39 +135,82 @@ __global__ __launch_bounds__(kPsThreads) void joint_ps_kernel(JointPsArgs P) {
     }
     __syncthreads();
     const int bqx = BQ[0], bqy = BQ[1];
-    // row pass fused with the column down-sampling: R[r][a] = sum_k tx[k] s[r][SS (a - bqx) - k]
-    for (int it = tid; it < N * n; it += kPsThreads) {
-      const int r = it / n, a = it % n;
-      const int v0 = SS * (a - bqx);
-      float acc = 0.f, accd = 0.f;
+    // (the taps of the source in registers for both passes: read from LDS per multiply-add they were three of every five
+    //  LDS reads of this kernel, which is what a batch of thousands of epochs waits for; same values, same order of the sums)
+    float tx[NT], tdx[NT], ty[NT], tdy[NT];
 #pragma unroll
-      for (int k = 0; k < NT; ++k) {
-        const int v = v0 - k;
-        const float sv = (v >= 0 && v < N) ? Sx[r * TS + v] : 0.f;
-        acc = fmaf(TAP[k], sv, acc);
-        accd = fmaf(TAP[NT + k], sv, accd);
+    for (int k = 0; k < NT; ++k) {
+      tx[k] = TAP[k];
+      tdx[k] = TAP[NT + k];
+      ty[k] = TAP[2 * NT + k];
+      tdy[k] = TAP[3 * NT + k];
+    }
+    // row pass fused with the column down-sampling: R[r][a] = sum_k tx[k] s[r][SS (a - bqx) - k].  A thread takes a strip
+    // of LS consecutive outputs of a row and reads their common window of the PSF row once (19 LDS reads for 4 outputs
+    // instead of 52); every output adds its taps in the same order as before.
+    constexpr int LS = 4, WL = SS * (LS - 1) + NT;
+    static_assert(n % LS == 0, "strips");
+    for (int it = tid; it < N * (n / LS); it += kPsThreads) {
+      const int r = it / (n / LS), a0 = (it % (n / LS)) * LS;
+      const int w0 = SS * (a0 - bqx) - (NT - 1);
+      float win[WL];
+#pragma unroll
+      for (int q = 0; q < WL; ++q) {
+        const int v = w0 + q;
+        win[q] = (v >= 0 && v < N) ? Sx[r * TS + v] : 0.f;
       }
-      R[r * RS + a] = acc;
-      Rx[r * RS + a] = accd;
+#pragma unroll
+      for (int j = 0; j < LS; ++j) {
+        float acc = 0.f, accd = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          const float sv = win[SS * j + NT - 1 - k];
+          acc = fmaf(tx[k], sv, acc);
+          accd = fmaf(tdx[k], sv, accd);
+        }
+        R[r * RS + a0 + j] = acc;
+        Rx[r * RS + a0 + j] = accd;
+      }
     }
     __syncthreads();
-    // column pass fused with the row down-sampling: value, d/dX and d/dY filter outputs of source i at every data pixel
-    for (int px = tid; px < nn; px += kPsThreads) {
-      const int I = px / n, a = px % n;
-      const int r0 = SS * (I - bqy);
-      float fv = 0.f, fx = 0.f, fy = 0.f;
+    // column pass fused with the row down-sampling: value, d/dX and d/dY filter outputs of source i at every data pixel;
+    // a thread takes LS consecutive data rows of one column (lanes = consecutive columns)
+    static_assert(LS == LSF, "strip length");
 #pragma unroll
-      for (int k = 0; k < NT; ++k) {
-        const int r = r0 - k;
+    for (int t = 0; t < NITF; ++t) {
+      const int it = tid + t * kPsThreads;
+      if (it >= (n / LS) * n) break;
+      const int I0 = (it / n) * LS, a = it % n;
+      const int w0 = SS * (I0 - bqy) - (NT - 1);
+      float wr[WL], wx[WL];
+#pragma unroll
+      for (int q = 0; q < WL; ++q) {
+        const int r = w0 + q;
         const bool ok = (r >= 0 && r < N);
-        const float rv = ok ? R[r * RS + a] : 0.f, rx = ok ? Rx[r * RS + a] : 0.f;
-        fv = fmaf(TAP[2 * NT + k], rv, fv);
-        fy = fmaf(TAP[3 * NT + k], rv, fy);
-        fx = fmaf(TAP[2 * NT + k], rx, fx);
+        wr[q] = ok ? R[r * RS + a] : 0.f;
+        wx[q] = ok ? Rx[r * RS + a] : 0.f;
       }
-      Fe[((size_t)i * 3 + 0) * nn + px] = fv;
-      Fe[((size_t)i * 3 + 1) * nn + px] = fx;
-      Fe[((size_t)i * 3 + 2) * nn + px] = fy;
+#pragma unroll
+      for (int j = 0; j < LS; ++j) {
+        float fv = 0.f, fx = 0.f, fy = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          const float rv = wr[SS * j + NT - 1 - k], rx = wx[SS * j + NT - 1 - k];
+          fv = fmaf(ty[k], rv, fv);
+          fy = fmaf(tdy[k], rv, fy);
+          fx = fmaf(ty[k], rx, fx);
+        }
+        const int px = (I0 + j) * n + a;
+        if (single) {
+          fvr[t][j] = fv;
+          fxr[t][j] = fx;
+          fyr[t][j] = fy;
+        } else {
+          Fe[((size_t)i * 3 + 0) * nn + px] = fv;
+          Fe[((size_t)i * 3 + 1) * nn + px] = fx;
+          Fe[((size_t)i * 3 + 2) * nn + px] = fy;
+        }
+      }
     }
   }
   __syncthreads();  // this workgroup's filter outputs are visible to all of its threads
@@ -162,7 +219,35 @@ __global__ __launch_bounds__(kPsThreads) void joint_ps_kernel(JointPsArgs P) {
 #pragma unroll
   for (int q = 0; q < NQ; ++q) vals[q] = 0.f;
   const float *de = A.data + (size_t)e * nn, *we = A.wgt + (size_t)e * nn;
-  for (int px = tid; px < nn; px += kPsThreads) {
+  if (single) {  // the thread's own pixels, filter outputs from registers
+    const float a0f = (A.mode == 2) ? 0.f : flux(0);
+#pragma unroll
+    for (int t = 0; t < NITF; ++t) {
+      const int it = tid + t * kPsThreads;
+      if (it >= (n / LSF) * n) break;
+      const int I0 = (it / n) * LSF, a = it % n;
+#pragma unroll
+      for (int jj = 0; jj < LSF; ++jj) {
+        const int px = (I0 + jj) * n + a;
+        const float w = we[px], fv = fvr[t][jj];
+        if (A.mode == 2) {
+          vals[0] = fmaf(w * fv, fv, vals[0]);
+          continue;
+        }
+        const float model = fmaf(a0f, fv, meane);
+        if (A.model_out) A.model_out[(size_t)e * nn + px] = model;
+        const float res = model - de[px], rw = w * res;
+        vals[0] = fmaf(rw, res, vals[0]);
+        vals[1] += rw;
+        if (A.mode == 0) {
+          vals[4] = fmaf(rw, fv, vals[4]);
+          vals[5] = fmaf(rw, fxr[t][jj], vals[5]);
+          vals[6] = fmaf(rw, fyr[t][jj], vals[6]);
+        }
+      }
+    }
+  }
+  for (int px = tid; px < (single ? 0 : nn); px += kPsThreads) {
     const float w = we[px];
     if (A.mode == 2) {
       const float fv = Fe[((size_t)A.isrc * 3) * nn + px];
@@ -225,6 +310,10 @@ __global__ __launch_bounds__(kPsThreads) void joint_ps_kernel(JointPsArgs P) {
       if (my_free) {
         adabelief_step(my_p, my_m, my_s, g, P.sched[3 * iter], P.sched[3 * iter + 1], P.sched[3 * iter + 2], P.ab);
         PP[tid] = my_p;
+        if (P.phist) {
+          const int off = (k < 0) ? P.poff_a + e * M + tid : ((k == 0 ? P.poff_dx : (k == 1 ? P.poff_dy : P.poff_mean)) + e);
+          P.phist[(size_t)iter * P.phist_P + off] = my_p;
+        }
       }
     }
     continue;

@@ -42,6 +42,50 @@ def shard_kwargs(flat, n_epochs, n_sources, world_size, rank):
     return out
 
 
+class PeerGroup:
+    """One-shot peer-memory all-reduce of a fit's shared block (include/lcmi.h "peer group", csrc/peer.hip): every rank
+    publishes its block in an exchange buffer the other ranks map with HIP IPC and reads the N - 1 peers directly, adding
+    in rank order.  The IPC handles travel over ``group`` (any torch.distributed group of the same ranks, e.g. gloo)."""
+
+    def __init__(self, local_fit, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib
+        self._l = _lib.lib()
+        self.fit = local_fit
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        _, count = local_fit.shared_buffer()
+        h = C.c_void_p()
+        local_fit.ctx.check(self._l.lc_peer_group_create(local_fit.ctx.h, count, self.rank, self.world, C.byref(h)), 'lc_peer_group_create')
+        self.h = h
+        mine = C.create_string_buffer(_lib.IPC_HANDLE_BYTES)
+        local_fit.ctx.check(self._l.lc_peer_group_export(self.h, mine, _lib.IPC_HANDLE_BYTES), 'lc_peer_group_export')
+        parts = [None] * self.world
+        dist.all_gather_object(parts, bytes(mine.raw), group=group)
+        allh = C.create_string_buffer(b''.join(parts), _lib.IPC_HANDLE_BYTES * self.world)
+        local_fit.ctx.check(self._l.lc_peer_group_connect(self.h, allh, _lib.IPC_HANDLE_BYTES), 'lc_peer_group_connect')
+        dist.barrier(group=group)   # every rank has mapped every peer before anyone publishes
+
+    def callback(self):
+        """(function pointer, user pointer) for lc_joint_run_sharded: the library's own lc_peer_allreduce - no Python in the loop."""
+        import ctypes as C
+        return C.cast(self._l.lc_peer_allreduce, C.c_void_p), self.h
+
+    def check(self):
+        self.fit.ctx.check(self._l.lc_peer_group_status(self.h), 'peer all-reduce')
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self._l.lc_peer_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedJointOptimizer:
     """Drives ``n_iter`` AdaBelief iterations of a sharded joint fit.
 
@@ -50,11 +94,21 @@ class ShardedJointOptimizer:
     step_update(**adabelief_cfg).
     """
 
-    def __init__(self, local_fit, group=None):
+    def __init__(self, local_fit, group=None, peer=None):
+        """peer: a ``PeerGroup`` over the same ranks - the shared block is then reduced by the one-shot peer-memory kernel
+        instead of the process group's collective."""
         self.fit = local_fit
         self.group = group
+        self.peer = peer
         self._dev = None  # (tensor view of the shared block, torch ExternalStream of the library's stream)
         self._ref_agreed = False
+
+    @property
+    def transport(self):
+        """'peer' (one-shot peer-memory kernel), 'rccl' (in place in device memory) or 'gloo' (staged through the host)."""
+        if self.peer is not None:
+            return 'peer'
+        return 'rccl' if self._device_collective() else 'gloo'
 
     def _agree_flux_reference(self):
         """The flux moments of the shared block are centred on one reference flux per source (include/lcmi.h):
@@ -119,7 +173,35 @@ class ShardedJointOptimizer:
         # agreed at the start of EVERY run: set_params(a=...) between two runs resets the local reference to the local
         # mean (lc_joint_set_param), and ranks centring their flux moments on different references corrupt the reduced sums
         self._agree_flux_reference()
-        for _ in range(int(n_iter)):
+        if hasattr(self.fit, 'run_sharded'):
+            # the loop itself runs in C++ (lc_joint_run_sharded): per iteration step_local, this callback, step_update
+            if self.peer is not None:
+                fn, user = self.peer.callback()
+                self.fit.run_sharded(int(n_iter), fn, user, **adabelief_cfg)
+                self.peer.check()
+                return
+            failure = []
+
+            def reduce_block(_user, _buf, _count, _stream):
+                try:
+                    if on_device:
+                        self.all_reduce_device()       # RCCL, in place, ordered on the library's stream
+                    else:
+                        self.fit.shared_set(self.all_reduce(self.fit.shared_get()))
+                    return 0
+                except BaseException as exc:  # noqa: BLE001  (ctypes would swallow it)
+                    failure.append(exc)
+                    return 1
+
+            from . import _lib
+            cb = _lib.ALLREDUCE_FN(reduce_block)
+            try:
+                self.fit.run_sharded(int(n_iter), cb, None, **adabelief_cfg)
+            finally:
+                if failure:
+                    raise failure[0]
+            return
+        for _ in range(int(n_iter)):   # (objects without the entry point: the protocol stand-ins of the CPU tests)
             self.fit.step_local()
             if on_device:
                 self.all_reduce_device()

@@ -62,8 +62,10 @@ class JointFit:
         return r
 
     def set_free(self, free):
-        mask = (C.c_int32 * P_COUNT)(*[1 if name in free else 0 for name in
-                                       ('a', 'c_x', 'c_y', 'dx', 'dy', 'alpha', 'h', 'mean')])
+        self._flush_pending_history()
+        order = ('a', 'c_x', 'c_y', 'dx', 'dy', 'alpha', 'h', 'mean')
+        self._free_names = [name for name in order if name in free]
+        mask = (C.c_int32 * P_COUNT)(*[1 if name in free else 0 for name in order])
         self._chk(self._l.lc_joint_set_free(self.h, mask), 'set_free')
 
     def set_loss(self, W=None, lam_scales=0.0, lam_hf=0.0, lam_positivity=0.0, lam_positivity_ps=0.0,
@@ -132,6 +134,36 @@ class JointFit:
         self._chk(self._l.lc_joint_run_lbfgs(self.h, int(maxiter), lo, hi, ptr(hist), cap, C.byref(nit), C.byref(nev)), 'run_lbfgs')
         return hist[:max(nit.value, 1)].copy(), nit.value, nev.value
 
+    # return_param_history=True of the reference's call sites: rows of the free blocks, kept on the device
+    def param_history_begin(self, capacity):
+        """Record the free parameter blocks after every AdaBelief update into a device-resident history of
+        ``capacity`` rows (lc_joint_param_history_begin); returns the row length."""
+        self._flush_pending_history()
+        n = C.c_int()
+        self._chk(self._l.lc_joint_param_history_begin(self.h, int(capacity), C.byref(n)), 'param_history_begin')
+        return n.value
+
+    def _flush_pending_history(self):
+        """A history handed out lazily (starred/optim/optimization.py) comes to the host before its buffer goes away."""
+        pending = getattr(self, '_pending_param_history', None)
+        if pending is not None:
+            self._pending_param_history = None
+            pending.materialize()
+
+    def param_history(self, first=0, count=None):
+        rows = self._l.lc_joint_param_history_rows(self.h)
+        count = rows - first if count is None else int(count)
+        # (row length: the free blocks as set_free left them)
+        P = sum(self.sizes[k] for k in self._free_names) if getattr(self, '_free_names', None) is not None else None
+        if P is None:
+            raise _lib.LcError('param_history: set_free was not called through this object')
+        out = np.empty((max(count, 0), P), np.float32)
+        self._chk(self._l.lc_joint_param_history_get(self.h, int(first), int(count), ptr(out)), 'param_history_get')
+        return out
+
+    def param_history_end(self):
+        self._chk(self._l.lc_joint_param_history_end(self.h), 'param_history_end')
+
     @property
     def iterations_done(self):
         return self._l.lc_joint_iterations_done(self.h)
@@ -167,12 +199,23 @@ class JointFit:
         buf = f32(buf)
         self._chk(self._l.lc_joint_shared_set(self.h, ptr(buf), buf.size), 'shared_set')
 
+    def run_sharded(self, n_iter, allreduce, user=None, **cfg):
+        """n_iter iterations of { step_local; allreduce(user, block, count, stream); step_update } enqueued from C++
+        (lc_joint_run_sharded).  allreduce: a ctypes function of type _lib.ALLREDUCE_FN or a raw function pointer."""
+        c = _lib.adabelief_cfg(**cfg)
+        fn = allreduce if isinstance(allreduce, C.c_void_p) else C.cast(allreduce, C.c_void_p)
+        self._chk(self._l.lc_joint_run_sharded(self.h, int(n_iter), C.byref(c), fn, user), 'run_sharded')
+
     def step_update(self, **cfg):
         c = _lib.adabelief_cfg(**cfg)
         self._chk(self._l.lc_joint_step_update(self.h, C.byref(c)), 'step_update')
 
     def close(self):
         if getattr(self, 'h', None):
+            try:
+                self._flush_pending_history()
+            except Exception:
+                pass
             self._l.lc_joint_destroy(self.h)
             self.h = None
 
@@ -181,3 +224,54 @@ class JointFit:
             self.close()
         except Exception:
             pass
+
+
+class StarPhotometryBatch(JointFit):
+    """G independent point-source fits (the reference's loop over its reference stars, star_photometry.py:257) as ONE
+    device object (lc_joint_create_groups): ``stacks`` is a list of (data, sigma2, psf) per star, each over that star's
+    own epochs ((E_g, n, n), (E_g, n, n), (E_g, N, N)); M point sources per star (1 in the reference).  Parameter arrays
+    are the per-star arrays concatenated: a (sum E_g * M), c_x / c_y (G * M), dx / dy / mean (sum E_g).  Every AdaBelief
+    iteration is one kernel pair for all stars; each star's trajectory is bit for bit that of its own JointFit."""
+
+    def __init__(self, stacks, ss, M=1, ctx=None):
+        datas = [f32(d) for d, _, _ in stacks]
+        sig2s = [f32(s2) for _, s2, _ in stacks]
+        psfs = [f32(p) for _, _, p in stacks]
+        if not datas:
+            raise ValueError('at least one star')
+        self.G = len(datas)
+        self.epochs = np.array([d.shape[0] for d in datas], dtype=np.int32)
+        self.starts = np.concatenate([[0], np.cumsum(self.epochs)]).astype(int)
+        self.n = datas[0].shape[-1]
+        self.ss, self.M = int(ss), int(M)
+        self.N = self.n * self.ss
+        for d, s2, p in zip(datas, sig2s, psfs):
+            if d.shape[1:] != (self.n, self.n) or s2.shape != d.shape or p.shape != (d.shape[0], self.N, self.N):
+                raise ValueError('every star needs data, sigma2 (E_g, n, n) and psf (E_g, N, N) of one stamp size')
+        data, sig2, psf = (np.ascontiguousarray(np.concatenate(a)) for a in (datas, sig2s, psfs))
+        self.E = int(self.epochs.sum())
+        self.J = int(np.log2(self.N))
+        self.ctx = ctx or _lib.default_context()
+        self._l = _lib.lib()
+        h = C.c_void_p()
+        self.ctx.check(self._l.lc_joint_create_groups(self.ctx.h, self.G, self.epochs.ctypes.data_as(_lib.ip), self.M, self.n,
+                                                      self.ss, ptr(data), ptr(sig2), ptr(psf), C.byref(h)), 'lc_joint_create_groups')
+        self.h = h
+        self.sizes = {'a': self.E * self.M, 'c_x': self.G * self.M, 'c_y': self.G * self.M, 'dx': self.E, 'dy': self.E,
+                      'alpha': self.E, 'h': self.N * self.N, 'mean': self.E}
+        self._keep = None
+
+    def loss_history(self):
+        """(G, T + 1): per star, the loss before every update and the loss of the final parameters."""
+        T = self.iterations_done
+        hist = np.empty((self.G, T + 1), np.float32)
+        self._chk(self._l.lc_joint_get_group_loss_history(self.h, ptr(hist), T + 1), 'get_group_loss_history')
+        return hist
+
+    def split(self, flat, name):
+        """The concatenated block ``name`` as a list of per-star arrays."""
+        flat = np.asarray(flat)
+        if name in ('c_x', 'c_y'):
+            return [flat[g * self.M:(g + 1) * self.M] for g in range(self.G)]
+        k = self.M if name == 'a' else 1
+        return [flat[self.starts[g] * k:self.starts[g + 1] * k] for g in range(self.G)]

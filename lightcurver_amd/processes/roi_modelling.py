@@ -125,7 +125,7 @@ def model_roi_cutouts(data, noisemap, psf, subsampling_factor, xs_pixels, ys_pix
                 W=W, prior=prior)
     optim2 = Optimizer(loss, pars, method='adabelief')
     optim2.minimize(max_iterations=int(roi_deconv_all_iters), init_learning_rate=1e-4, schedule_learning_rate=False,
-                    restart_from_init=False, stop_at_loss_increase=False, progress_bar=True, return_param_history=False)  # the reference asks for it (True) and never reads it; False keeps the loop on the device
+                    restart_from_init=False, stop_at_loss_increase=False, progress_bar=True, return_param_history=True)   # as the reference passes it (:331): recorded on the device, copied only if read
     k_final = deepcopy(pars.best_fit_values(as_kwargs=True))
     # position of the sources in the first epoch, back in pixels (roi_modelling.py:339-340)
     x_pix = np.array(k_final['kwargs_analytic']['c_x']) + np.array(k_final['kwargs_analytic']['dx'])[0] + offset

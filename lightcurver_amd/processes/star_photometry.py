@@ -78,7 +78,7 @@ def do_one_star_forward_modelling(data, noisemap, psf, subsampling_factor, n_ite
     optim = Optimizer(loss, pars, method='adabelief')
     optim.minimize(max_iterations=n_iter, min_iterations=None, init_learning_rate=1e-3, schedule_learning_rate=True,
                    restart_from_init=True, stop_at_loss_increase=False, progress_bar=True,
-                   return_param_history=False)  # the reference asks for it (True) and never reads it; False keeps the loop on the device
+                   return_param_history=True)   # as the reference passes it (:119): recorded on the device, copied only if read
     k_final = pars.best_fit_values(as_kwargs=True)
 
     residuals = data - np.array(model.model(k_final))
@@ -98,3 +98,61 @@ def do_one_star_forward_modelling(data, noisemap, psf, subsampling_factor, n_ite
         'deconvolved_image': scale * scene,
         'starlet_background': scale * background,
     }
+
+
+def do_many_stars_forward_modelling(stacks, subsampling_factor, n_iter=2000):
+    """The reference's loop over its reference stars (star_photometry.py:257-326: ``do_one_star_forward_modelling`` once per
+    star, each a 2000-iteration fit) as ONE batched device fit (``lightcurver_amd.joint.StarPhotometryBatch``,
+    lc_joint_create_groups): every AdaBelief iteration advances all stars with one kernel pair instead of one pair per star.
+
+    stacks: list of (data, noisemap, psf) per star - (E_g, n, n), (E_g, n, n), (E_g, N, N); the epoch counts may differ
+    (each star keeps its own frame selection).  data and noisemap are rescaled IN PLACE by nanmax(data), as the one-star
+    function does.  The configuration is the reference's default (``star_photometry_starlet_global_background: false``,
+    ``star_photometry_uniform_background_per_epoch: false``, config.yaml:254-258): fluxes, the star's position and the
+    per-epoch shifts free, no background.  Returns one dictionary per star with the keys of
+    ``do_one_star_forward_modelling``; each star's numbers are bit for bit those of its own one-star fit."""
+    from ..joint import StarPhotometryBatch
+    from ..starred.deconvolution.deconvolution import nest_kwargs
+    ss = int(subsampling_factor)
+    scales, guesses, dev_stacks = [], [], []
+    for data, noisemap, psf in stacks:
+        scale = np.nanmax(data)
+        data /= scale
+        noisemap /= scale
+        scales.append(scale)
+        guesses.append(np.nansum(data, axis=(1, 2)) - data[0].size * _border_level(data))
+        dev_stacks.append((data, noisemap ** 2, psf))
+    batch = StarPhotometryBatch(dev_stacks, ss, M=1)
+    try:
+        E, G, N = batch.E, batch.G, batch.N
+        batch.set_params(a=np.concatenate(guesses), c_x=np.zeros(G), c_y=np.zeros(G), dx=np.zeros(E), dy=np.zeros(E),
+                         alpha=np.zeros(E), h=np.zeros(N * N), mean=np.zeros(E))
+        batch.set_loss(lam_scales=3.0, lam_hf=3.0)          # (constants with the background fixed at zero)
+        batch.set_free(['a', 'c_x', 'c_y', 'dx', 'dy'])
+        batch.run_adabelief(int(n_iter), init_learning_rate=1e-3, schedule_learning_rate=True)
+        final = batch.get_params()
+        hist = batch.loss_history()
+        model, _ = batch.model()
+        sigma_a = batch.fisher_flux_sigma()
+    finally:
+        batch.close()
+    out = []
+    for g, (data, noisemap, psf) in enumerate(stacks):
+        e0, e1 = batch.starts[g], batch.starts[g + 1]
+        flat = dict(a=final['a'][e0:e1], c_x=final['c_x'][g:g + 1], c_y=final['c_y'][g:g + 1], dx=final['dx'][e0:e1],
+                    dy=final['dy'][e0:e1], alpha=final['alpha'][e0:e1], h=np.zeros(N * N, np.float32), mean=final['mean'][e0:e1])
+        k_final = nest_kwargs(flat)
+        residuals = data - model[e0:e1]
+        chi2_per_frame = np.nansum(residuals ** 2 / noisemap ** 2, axis=(1, 2)) / data.shape[1] ** 2
+        scale = scales[g]
+        out.append({
+            'scale': scale,
+            'kwargs_final': k_final,
+            'fluxes': scale * np.array(k_final['kwargs_analytic']['a']),
+            'fluxes_uncertainties': scale * sigma_a[e0:e1],
+            'chi2': float(np.nanmean(chi2_per_frame)),
+            'chi2_per_frame': np.array(chi2_per_frame),
+            'loss_curve': np.asarray(hist[g, 1:], dtype=np.float64).tolist(),
+            'residuals': scale * residuals,
+        })
+    return out

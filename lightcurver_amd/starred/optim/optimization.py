@@ -39,8 +39,16 @@ class Optimizer:
         cfg = dict(init_learning_rate=init_learning_rate, schedule_learning_rate=bool(schedule_learning_rate),
                    decay_rate=decay_rate, transition_steps=transition_steps)
         param_history = []
-        if n_iter > 0 and not stop_at_loss_increase and not return_param_history:
-            fit.run_adabelief(n_iter, **cfg)       # one call: the whole loop stays on the device
+        if n_iter > 0 and not stop_at_loss_increase:
+            # one call: the whole loop stays on the device.  return_param_history=True - what the reference's own call
+            # sites pass (star_photometry.py:119, roi_modelling.py:331) - records the free blocks after every update in a
+            # device-resident history; it comes to the host when extra_fields['param_history'] is first looked at
+            if return_param_history:
+                if fit.param_history_begin(n_iter) != p.num_parameters:
+                    raise RuntimeError('parameter history: row length differs from the number of free parameters')
+            fit.run_adabelief(n_iter, **cfg)
+            if return_param_history:
+                param_history = _DeviceParamHistory(fit, n_iter)
         elif n_iter > 0:
             # the parameter vector after every update (return_param_history) and / or the early stop need the host in
             # the loop: one iteration per call, so that the fit stops AT the update that raised the loss, as the host loop
@@ -116,6 +124,38 @@ class Optimizer:
         p.set_best_fit(flat)
         self.loss_history = hist if hist else [float(res.fun)]
         return res.x, -float(res.fun), {'loss_history': np.array(self.loss_history), 'scipy_result': res}
+
+
+class _DeviceParamHistory:
+    """``extra_fields['param_history']``: the parameter vector after every update (a sequence of ``max_iterations``
+    float64 vectors in kwargs2args order).  The rows live on the device until the sequence is first read; then one copy
+    brings them over and the device buffer is released.  ``materialize()`` is also called by whatever next needs the fit."""
+
+    def __init__(self, fit, n_rows):
+        self._fit, self._n, self._rows = fit, int(n_rows), None
+        fit._pending_param_history = self
+
+    def materialize(self):
+        if self._rows is None:
+            self._rows = np.asarray(self._fit.param_history(0, self._n), dtype=np.float64)
+            self._fit.param_history_end()
+            if getattr(self._fit, '_pending_param_history', None) is self:
+                self._fit._pending_param_history = None
+            self._fit = None
+        return self._rows
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        return self.materialize()[i]
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.materialize()
+        return a if dtype is None else a.astype(dtype)
 
 
 def _nest(flat):

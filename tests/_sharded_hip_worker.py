@@ -1,7 +1,8 @@
 """One rank of the two-process HIP test (tests/test_distributed_gpu.py): fits its contiguous block of the epochs on GPU 0
 through lightcurver_amd.distributed.ShardedJointOptimizer with a real JointFit object, the shared block summed over the
-ranks by a gloo all-reduce (both ranks share the one GPU of the test box, where RCCL refuses to run two ranks).
-usage: RANK=r WORLD_SIZE=w MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/_sharded_hip_worker.py out.npz E M n T"""
+ranks by a gloo all-reduce (both ranks share the one GPU of the test box, where RCCL refuses to run two ranks) or by the
+library's one-shot peer-memory all-reduce over HIP IPC (transport 'peer'); the loop itself runs in C++ (lc_joint_run_sharded).
+usage: RANK=r WORLD_SIZE=w MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/_sharded_hip_worker.py out.npz E M n T [gloo|peer]"""
 import os
 import sys
 
@@ -13,11 +14,12 @@ sys.path.insert(0, ROOT)
 
 def main():
     out, E, M, n, T = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    transport = sys.argv[6] if len(sys.argv) > 6 else 'gloo'   # 'peer': the one-shot peer-memory all-reduce (HIP IPC)
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from lightcurver_amd import _lib
-    from lightcurver_amd.distributed import ShardedJointOptimizer, gather_epoch_blocks, shard_epochs, shard_kwargs
+    from lightcurver_amd.distributed import PeerGroup, ShardedJointOptimizer, gather_epoch_blocks, shard_epochs, shard_kwargs
     from lightcurver_amd.joint import JointFit
     from lightcurver_amd.synthetic import make_roi_dataset
     ss = 2
@@ -30,15 +32,20 @@ def main():
     j.set_params(**shard_kwargs(p, E, M, world, rank))
     j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
     j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
-    opt = ShardedJointOptimizer(j)
-    opt.run(T, init_learning_rate=1e-3)
+    peer = PeerGroup(j) if transport == 'peer' else None
+    opt = ShardedJointOptimizer(j, peer=peer)
+    opt.run(T // 2, init_learning_rate=1e-3)
+    opt.run(T - T // 2, init_learning_rate=1e-3)     # a second run continues the first (flux reference agreed again)
     ctx.synchronize()
     hist = j.loss_history()
     full = gather_epoch_blocks(j.get_params(), M)
     ref = j.get_flux_reference()
     if rank == 0:
-        np.savez(out, hist=hist, flux_reference=ref, device_collective=bool(opt._dev), **{'p_' + k: v for k, v in full.items()})
+        np.savez(out, hist=hist, flux_reference=ref, device_collective=bool(opt._dev), transport=opt.transport,
+                 **{'p_' + k: v for k, v in full.items()})
     dist.barrier()
+    if peer is not None:
+        peer.close()
     j.close()
     dist.destroy_process_group()
 

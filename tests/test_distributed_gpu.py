@@ -76,17 +76,27 @@ def test_two_hip_ranks_equal_the_unsharded_fit(ctx, tmp_path):
         full.step_local()
         full.step_update(init_learning_rate=1e-3)
     pf, hf = full.get_params(), full.loss_history()
-    out = tmp_path / 'sharded.npz'
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_sharded_hip_worker.py')
-    port = _free_port()
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, worker, str(out), str(E), str(M), str(n), str(T)], env=env))
-    for pr in procs:
-        assert pr.wait(timeout=600) == 0
-    g = np.load(out)
+    results = {}
+    for transport in ('gloo', 'peer'):
+        out = tmp_path / f'sharded_{transport}.npz'
+        port = _free_port()
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+            procs.append(subprocess.Popen([sys.executable, worker, str(out), str(E), str(M), str(n), str(T), transport], env=env))
+        for pr in procs:
+            assert pr.wait(timeout=600) == 0
+        results[transport] = np.load(out)
+    g, gp = results['gloo'], results['peer']
     assert not bool(g['device_collective'])   # gloo staging here; the RCCL path is the world-size-1 test above
+    assert str(g['transport']) == 'gloo' and str(gp['transport']) == 'peer'
+    # the one-shot peer-memory all-reduce (each rank reads the other's block through HIP IPC and adds in rank order) gives
+    # the bits of the gloo sum: two ranks, one addition per element
+    for k in g.files:
+        if k not in ('transport', 'device_collective'):
+            np.testing.assert_array_equal(gp[k], g[k], err_msg=k)
     assert np.allclose(g['flux_reference'], full.get_flux_reference(), rtol=1e-6)
     assert np.abs(g['hist'][:T] - hf[:T]).max() <= 2e-5 * np.abs(hf).max()
     assert np.abs(g['p_a'] - pf['a']).max() <= 2e-5 * np.abs(pf['a']).max()

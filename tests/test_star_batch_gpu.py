@@ -1,0 +1,123 @@
+"""Batched star photometry (lc_joint_create_groups; VERDICT r02 "missing" 6): the reference fits its reference stars one
+after the other (lightcurver/processes/star_photometry.py:257-326, up to 30 stars, 2000 iterations each); here they are one
+device object whose every iteration is one kernel pair for all stars.  Each star of the batch must end bit for bit where its
+own one-star fit ends - same kernels per epoch, same reduction order per star - and the batch must be several times faster
+than the loop."""
+import time
+
+import numpy as np
+import pytest
+
+from lightcurver_amd.synthetic import make_roi_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def _stars(G, E_list, n, seed):
+    out = []
+    for g in range(G):
+        ds = make_roi_dataset(E=E_list[g], M=1, n=n, ss=2, seed=seed + g, with_background=False)
+        out.append(ds)
+    return out
+
+
+def _start(ds, rng):
+    E = ds['data'].shape[0]
+    p = {k: np.array(v, dtype=np.float64) for k, v in ds['truth'].items()}
+    p['a'] = p['a'] * rng.uniform(0.8, 1.2, E)
+    p['c_x'] = p['c_x'] + rng.normal(0, 0.2, 1)
+    p['c_y'] = p['c_y'] + rng.normal(0, 0.2, 1)
+    p['h'] = np.zeros_like(p['h'])
+    return p
+
+
+@pytest.mark.parametrize('n,E_list,free', [(16, [5, 3, 7, 1], ('a', 'c_x', 'c_y', 'dx', 'dy')),
+                                           (32, [6, 4, 9], ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean'))])
+def test_every_star_of_a_batch_equals_its_own_fit(ctx, n, E_list, free):
+    from lightcurver_amd.joint import JointFit, StarPhotometryBatch
+    G, T = len(E_list), 60
+    stars = _stars(G, E_list, n, 400 + n)
+    rng = np.random.default_rng(3)
+    starts = [_start(ds, rng) for ds in stars]
+    cfg = dict(init_learning_rate=1e-3, schedule_learning_rate=True)
+    single = []
+    for ds, p in zip(stars, starts):
+        j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], 2, 1, ctx)
+        j.set_params(**p)
+        j.set_loss(lam_positivity_ps=2.0, lam_flux_uniformity=0.5)
+        j.set_free(list(free))
+        j.run_adabelief(T, **cfg)
+        single.append((j.get_params(), j.loss_history(), j.model(), j.fisher_flux_sigma()))
+        j.close()
+    b = StarPhotometryBatch([(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf']) for ds in stars], 2, 1, ctx)
+    cat = {k: np.concatenate([p[k] for p in starts]) for k in ('a', 'c_x', 'c_y', 'dx', 'dy', 'alpha', 'mean')}
+    b.set_params(h=starts[0]['h'], **cat)
+    b.set_loss(lam_positivity_ps=2.0, lam_flux_uniformity=0.5)
+    b.set_free(list(free))
+    b.run_adabelief(T // 2, **cfg)
+    b.run_adabelief(T - T // 2, **cfg)            # a second call continues the first
+    got, hist, (model, chi2_e), sig = b.get_params(), b.loss_history(), b.model(), b.fisher_flux_sigma()
+    assert hist.shape == (G, T + 1) and b.iterations_done == T
+    for g in range(G):
+        ps, hs, (ms, cs), ss_ = single[g]
+        for k in ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean'):
+            assert np.array_equal(b.split(got[k], k)[g], ps[k]), (g, k)
+        assert np.array_equal(hist[g], hs), g
+        e0, e1 = b.starts[g], b.starts[g + 1]
+        assert np.array_equal(model[e0:e1], ms) and np.array_equal(chi2_e[e0:e1], cs)
+        assert np.array_equal(sig[e0:e1], ss_)
+        assert hs[-1] < hs[0]
+    b.close()
+
+
+def test_what_a_batched_object_refuses(ctx):
+    from lightcurver_amd import _lib
+    from lightcurver_amd.joint import StarPhotometryBatch
+    stars = _stars(2, [3, 2], 16, 7)
+    b = StarPhotometryBatch([(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf']) for ds in stars], 2, 1, ctx)
+    with pytest.raises(_lib.LcError):
+        b.set_free(['a', 'h'])
+    with pytest.raises(_lib.LcError):
+        b.set_loss(lam_pts_source=0.1)
+    with pytest.raises(_lib.LcError):
+        b.loss_grad(('a',))
+    with pytest.raises(_lib.LcError):
+        b.propagate_noise()
+    b.close()
+
+
+def test_thirty_stars_in_one_call_against_the_loop(ctx):
+    """The size of the reference's default run: 30 stars x 100 epochs x 32 x 32, 2000 iterations (star_deconv_n_iter,
+    config.yaml:248), through the restated step function and through the batched one: same numbers per star, and the
+    batch several times faster than the loop over stars."""
+    from lightcurver_amd.processes.star_photometry import do_many_stars_forward_modelling, do_one_star_forward_modelling
+    G, E, n, T = 30, 100, 32, 2000
+    base = make_roi_dataset(E=E, M=1, n=n, ss=2, seed=77, with_background=False)
+    rng = np.random.default_rng(5)
+    stacks = []
+    for g in range(G):   # the same epochs' PSFs, another star: its own flux level and noise realisation
+        f = rng.uniform(0.3, 3.0)
+        d = (base['data'].astype(np.float64) * f + 0.01 * rng.standard_normal(base['data'].shape)) * base['scale']
+        nm = base['noisemap'].astype(np.float64) * np.sqrt(f) * base['scale']
+        stacks.append((d, nm, base['psf']))
+    loop_in = [(d.copy(), nm.copy(), p) for d, nm, p in stacks]
+    do_one_star_forward_modelling(loop_in[0][0].copy(), loop_in[0][1].copy(), loop_in[0][2], 2, n_iter=5,
+                                  starlet_global_background=False)    # warm-up (library load, first launches)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ref = [do_one_star_forward_modelling(d, nm, p, 2, n_iter=T, starlet_global_background=False) for d, nm, p in loop_in]
+    t_loop = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out = do_many_stars_forward_modelling(stacks, 2, n_iter=T)
+    t_batch = time.perf_counter() - t0
+    print(f'30 stars x 100 epochs x 32^2 x {T} iterations: loop {t_loop:.2f} s, batch {t_batch:.2f} s, ratio {t_loop / t_batch:.1f}')
+    for g in range(G):
+        assert np.array_equal(out[g]['fluxes'], ref[g]['fluxes']), g
+        assert np.array_equal(out[g]['kwargs_final']['kwargs_analytic']['c_x'], ref[g]['kwargs_final']['kwargs_analytic']['c_x'])
+        assert np.array_equal(out[g]['kwargs_final']['kwargs_analytic']['dx'], ref[g]['kwargs_final']['kwargs_analytic']['dx'])
+        assert out[g]['loss_curve'] == list(ref[g]['loss_curve']) and len(out[g]['loss_curve']) == T
+        assert np.array_equal(out[g]['fluxes_uncertainties'], ref[g]['fluxes_uncertainties'])
+        assert out[g]['chi2'] == ref[g]['chi2'] and np.array_equal(out[g]['residuals'], ref[g]['residuals'])
+    # measured on MI355X: loop 1.6 s, batch 0.19 - 0.22 s (7 - 8.5 x; 62 us per iteration for all 30 stars against 30 x 26 us:
+    # the batch is bound by the throughput of 3000 epoch workgroups, the loop by launch latency)
+    assert t_loop / t_batch >= 5.0
