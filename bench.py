@@ -238,6 +238,89 @@ def joint_workload(ctx, E, n, M, seed, iters, label):
             'loss_finite': bool(np.all(np.isfinite(hist))), 'loss_first_last': [float(hist[0]), float(hist[-1])]}
 
 
+def joint_cpu_oracle(n, M, seed, epochs=4, seconds_target=6.0):
+    """CPU figure beside a joint-fit entry: loss + full gradient of the same model by the float64 torch oracle (oracle/model.py,
+    autograd - the checker of the parity tests, kind 'oracle': not a tuned port) on `epochs` epochs of the same synthetic
+    workload, all host threads torch uses.  One evaluation = one cutout-iteration per epoch without the optimiser update."""
+    import torch
+    from oracle import model as om, optim as oo
+    from lightcurver_amd.synthetic import make_roi_dataset
+    ss = 2
+    ds = make_roi_dataset(E=epochs, M=M, n=n, ss=ss, seed=seed)
+    p = {k: om.T(v) for k, v in ds['truth'].items()}
+    p['a'] = p['a'] * 0.9
+    data, sig2, psf = om.T(ds['data']), om.T(ds['noisemap']) ** 2, om.T(ds['psf'])
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h']
+    fn = lambda q: om.deconv_loss(q, data, sig2, psf, ss, lam_scales=1.0, lam_hf=1.0, lam_pos=100.0, lam_pts=0.01, lam_fu=10.0)
+    oo.value_and_grad(fn, p, free)
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        oo.value_and_grad(fn, p, free)
+        k += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_target or k >= 200:
+            break
+    return dict(value=epochs * k / dt, unit='cutouts/sec', cores=torch.get_num_threads(), kind='oracle',
+                sample=f'{k} evaluations of loss + full gradient on {epochs} epochs x {n}x{n} of the same synthetic workload '
+                       f'({dt:.1f} s), oracle/model.py in torch float64 with autograd (the parity checker, not a tuned port)')
+
+
+def distortion_workload(ctx, iters=300):
+    """Pixel-grid stage of build_psf(field_distortion=True) (the mode the reference's integration test runs,
+    tests/test_entire_pipeline/test_run_pipeline_example_config.py:113-128) at C2's size: per iteration the pixel grid is
+    resampled for every star, the stars step, the adjoint resampling sums their gradients and the grid steps - four
+    launches per iteration, the loop in the library (lc_psf_distortion_run)."""
+    from lightcurver_amd.psf_batch import PsfBatch
+    from lightcurver_amd.starred.procedures.psf_routines import quadratic_forms
+    from lightcurver_amd.synthetic import make_psf_dataset
+    F, S, n, ss = 100, 8, 32, 2
+    ds = make_psf_dataset(F=F, S=S, n=n, ss=ss, seed=102)
+    rng = np.random.default_rng(7)
+    weight = (ds['masks'] / ds['noisemap'].astype(np.float64) ** 2).astype(np.float32)
+    g = ds['fwhm_guess']
+    f0 = np.sqrt(np.maximum(g * g - (2.0 / ss) ** 2, 1.0))
+    theta = np.zeros((F, 13))
+    theta[:, 0], theta[:, 1], theta[:, 3] = f0, f0, 2.5
+    theta[:, 4:13] = rng.uniform(-0.02, 0.02, (F, 9))         # a field distortion of a few per cent
+    xy = rng.uniform(-0.5, 0.5, (F, S, 2))
+    base = PsfBatch(ds['data'], weight, ss, ctx)
+    stars = np.zeros((F, S, 4), np.float32)
+    stars[..., 0] = (ds['data'] * ds['masks']).sum(axis=(-1, -2))
+    base.set_moffat(theta[:, 0:4])
+    base.set_stars(stars)
+    base.set_grid(None)
+    base.propagate_noise()
+    W = base.get_weights()
+    base.close()
+    star_b = PsfBatch(ds['data'].reshape(F * S, 1, n, n), weight.reshape(F * S, 1, n, n), ss, ctx)
+    frame_b = PsfBatch(np.zeros((F, 1, n, n), np.float32), np.zeros((F, 1, n, n), np.float32), ss, ctx)
+    star_b.set_grid(None)
+    star_b.set_moffat_q(quadratic_forms(theta, xy, ss).reshape(F * S, 4))
+    star_b.set_stars(stars.reshape(F * S, 1, 4))
+    star_b.set_regularization(None, 0.0, 0.0)
+    frame_b.set_moffat(theta[:, 0:4])
+    frame_b.set_grid(None)
+    frame_b.set_regularization(W, 1.0, 1.0)
+    frame_b.set_distortion(S, theta[:, 4:13], xy)
+    ab = dict(init_learning_rate=1e-4, schedule_learning_rate=True)
+    frame_b.distortion_run(star_b, 10, **ab)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    frame_b.distortion_run(star_b, iters, **ab)
+    ms = ctx.timer_stop()
+    wall = time.perf_counter() - t0
+    hist = frame_b.loss_history() + star_b.loss_history().reshape(F, S, -1).sum(axis=1)
+    star_b.close()
+    frame_b.close()
+    return {'workload': f'C2 with field_distortion=True: {F} frames x {S} stars, {n}x{n} stamps, pixel-grid stage, '
+                        f'{iters} AdaBelief iterations, four launches per iteration driven from C++ (lc_psf_distortion_run)',
+            'value': F * S * iters / (ms * 1e-3), 'unit': 'cutouts/sec', 'us_per_iteration': ms * 1e3 / iters,
+            'wall_us_per_iteration': wall * 1e6 / iters, 'loss_finite': bool(np.all(np.isfinite(hist))),
+            'loss_first_last': [float(hist[:, 0].sum()), float(hist[:, -1].sum())]}
+
+
 def c3_shard_workload(ctx, iters=200):
     """One GPU's share of BASELINE.json configs[2] (C3: 500 frames x 8 stars x 64x64 over 8 GPUs = 63 frames)."""
     from lightcurver_amd.psf_batch import PsfBatch
@@ -274,13 +357,15 @@ def c3_shard_workload(ctx, iters=200):
             'loss_finite': bool(np.all(np.isfinite(hist)))}
 
 
-def sharded_joint_fit(ctx, rank, world, iters=500):
-    """C4's 200 epochs sharded over the ranks; the shared block is all-reduced in place by RCCL every iteration
-    (lightcurver_amd/distributed.py).  Strong scaling: the total work is fixed."""
+def sharded_joint_fit(ctx, rank, world, iters=500, transport='collective'):
+    """C4's 200 epochs sharded over the ranks; the shared block is all-reduced every iteration - in place by RCCL
+    (transport 'collective'; gloo staged through the host in the one-GPU rehearsal) or by the library's one-shot
+    peer-memory kernel over HIP IPC (transport 'peer', csrc/peer.hip); the loop runs in C++ (lc_joint_run_sharded).
+    Strong scaling: the total work is fixed."""
     import datetime
     import torch
     import torch.distributed as dist
-    from lightcurver_amd.distributed import ShardedJointOptimizer, shard_epochs
+    from lightcurver_amd.distributed import PeerGroup, ShardedJointOptimizer, shard_epochs
     from lightcurver_amd.joint import JointFit
     from lightcurver_amd.synthetic import make_roi_dataset
     E, n, M, ss = 200, 64, 2, 2
@@ -294,14 +379,18 @@ def sharded_joint_fit(ctx, rank, world, iters=500):
     j.set_params(**p)
     j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
     j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
-    if os.environ.get('LCMI_BENCH_DEVICE') is not None:
+    peer = None
+    if transport == 'peer':
+        group = None
+        peer = PeerGroup(j)                 # IPC handles travel over the default (gloo) group
+    elif os.environ.get('LCMI_BENCH_DEVICE') is not None:
         # one-GPU rehearsal (every rank on the same device): RCCL refuses two ranks on one GPU, so the shared block
         # is staged through the host over the gloo group
         group = None
     else:
         torch.cuda.set_device(ctx.stream()[1])
         group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=180))
-    opt = ShardedJointOptimizer(j, group)
+    opt = ShardedJointOptimizer(j, group, peer=peer)
     ab = dict(init_learning_rate=1e-4, schedule_learning_rate=False)
     opt.run(10, **ab)
     ctx.synchronize()
@@ -315,14 +404,20 @@ def sharded_joint_fit(ctx, rank, world, iters=500):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t[0])
     hist = j.loss_history()
+    kind = opt.transport
+    if peer is not None:
+        peer.close()
     j.close()
-    transport = 'RCCL all-reduce in place in device memory' if opt._dev else 'gloo all-reduce staged through the host (one-GPU rehearsal)'
+    transport = {'peer': 'one-shot peer-memory all-reduce (HIP IPC, every rank reads the others directly)',
+                 'rccl': 'RCCL all-reduce in place in device memory',
+                 'gloo': 'gloo all-reduce staged through the host (one-GPU rehearsal)'}[kind]
     return {'workload': f'C4 sharded: {E} epochs x {n}x{n} ROI over {world} ranks, {transport} of the shared block '
                         f'({n * ss * n * ss + 4 * M + 2} floats) once per iteration, {iters} iterations',
             'value': E * iters / dt, 'unit': 'cutouts/sec', 'us_per_iteration': dt * 1e6 / iters, 'scaling': 'strong',
             # what RCCL saw: the size of the nccl group the block was reduced over, 0 when the collective was gloo's
-            'rccl_ranks': dist.get_world_size(group) if opt._dev else 0, 'collective': 'rccl' if opt._dev else 'gloo',
-            'device_collective': bool(opt._dev), 'ranks': world, 'loss_finite': bool(np.all(np.isfinite(hist)))}
+            'rccl_ranks': dist.get_world_size(group) if kind == 'rccl' else 0, 'collective': kind,
+            'device_collective': kind in ('rccl', 'peer'), 'ranks': world, 'loop': 'lc_joint_run_sharded (C++)',
+            'loss_finite': bool(np.all(np.isfinite(hist)))}
 
 
 def main():
@@ -399,12 +494,16 @@ def main():
     finite = bool(np.all(np.isfinite(hist)))
     res = b.results()
 
-    sharded = None
+    sharded = sharded_peer = None
     if world > 1 and not args.no_sharded_joint:
         try:
             sharded = sharded_joint_fit(ctx, rank, world)
         except Exception as e:
             sharded = {'error': repr(e)}
+        try:   # the same fit with the one-shot peer-memory all-reduce instead of the collective
+            sharded_peer = sharded_joint_fit(ctx, rank, world, transport='peer')
+        except Exception as e:
+            sharded_peer = {'error': repr(e)}
 
     if rank == 0:
         value = F * S * world * ITERS_PER_STEP * args.steps / elapsed
@@ -446,17 +545,27 @@ def main():
         if world == 1 and not args.no_extra:
             extra = []
             for fn, kw in ((joint_workload, dict(E=200, n=64, M=2, seed=104, iters=2000, label='C4')),
+                           (joint_workload, dict(E=25, n=64, M=2, seed=104, iters=2000,
+                                                 label="C4 shard (one GPU's eighth of C4's 200 epochs)")),
                            (joint_workload, dict(E=125, n=128, M=4, seed=105, iters=200,
                                                  label="C5 shard (one GPU's eighth of C5's 1000 epochs)")),
-                           (c3_shard_workload, {})):
+                           (c3_shard_workload, {}),
+                           (distortion_workload, {})):
                 try:
                     extra.append(fn(ctx, **kw))
                 except Exception as e:
                     extra.append({'workload': kw.get('label', fn.__name__), 'error': repr(e)})
+            if not args.no_cpu_baseline:   # the CPU path timed beside the joint fit too (north_star): attached to the C4 entry
+                try:
+                    extra[0]['cpu_baseline'] = joint_cpu_oracle(n=64, M=2, seed=104)
+                except Exception as e:
+                    extra[0]['cpu_baseline'] = {'value': None, 'error': repr(e)}
             out['config']['other_workloads'] = extra
         if sharded is not None:
             out['config']['sharded_joint_fit'] = sharded
             out['config']['rccl_ranks'] = sharded.get('rccl_ranks')
+        if sharded_peer is not None:
+            out['config']['sharded_joint_fit_peer'] = sharded_peer
         if not args.no_cpu_baseline and world == 1:
             try:
                 out['cpu_baseline'] = cpu_baseline(ds, weight, b, stars0, ss)

@@ -156,6 +156,9 @@ int lc_psf_distortion_forward(lc_psf_batch *frames, lc_psf_batch *stars);
 int lc_psf_distortion_backward(lc_psf_batch *frames, lc_psf_batch *stars);
 int lc_psf_batch_get_ext_grad(lc_psf_batch *b, float *grad /* [F][N*N] */);
 int lc_psf_batch_step_adabelief(lc_psf_batch *b, const lc_adabelief_cfg *cfg, int use_ext_grad, int export_grad);
+/* the whole pixel-grid stage in one call: n_iter times { forward; step(stars, export_grad); backward; step(frames,
+ * use_ext_grad) } and a final forward, enqueued from C++ */
+int lc_psf_distortion_run(lc_psf_batch *frames, lc_psf_batch *stars, int n_iter, const lc_adabelief_cfg *cfg);
 /* The batched bounded L-BFGS of the analytic stage with a caller-supplied evaluation (the distortion fit adds nine
  * coefficients per frame to the variables): x, lo, hi [nb][D]; eval fills F [nb] and G [nb][D] for the trial points X. */
 int lc_batched_lbfgs(int nb, int D, double *x, const double *lo, const double *hi, int maxiter,

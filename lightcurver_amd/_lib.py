@@ -79,6 +79,7 @@ SIGNATURES = {
     'lc_psf_distortion_backward': (C.c_int, [vp, vp]),
     'lc_psf_batch_get_ext_grad': (C.c_int, [vp, fp]),
     'lc_psf_batch_step_adabelief': (C.c_int, [vp, C.POINTER(AdabeliefCfg), C.c_int, C.c_int]),
+    'lc_psf_distortion_run': (C.c_int, [vp, vp, C.c_int, C.POINTER(AdabeliefCfg)]),
     'lc_batched_lbfgs': (C.c_int, [C.c_int, C.c_int, dp, dp, dp, C.c_int, LBFGS_EVAL, vp, dp, C.POINTER(C.c_int)]),
     'lc_apply_distortion': (C.c_int, [vp, C.c_int, C.c_int, fp, fp, fp, fp]),
     'lc_joint_supported': (C.c_int, [C.c_int, C.c_int]),

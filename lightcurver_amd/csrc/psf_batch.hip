@@ -569,6 +569,21 @@ int lc_psf_batch_step_adabelief(lc_psf_batch *b, const lc_adabelief_cfg *cfg, in
   b->iters_done += 1;
   return LC_OK;
 }
+// The pixel-grid stage of build_psf(field_distortion=True) as ONE call: n_iter times { forward, step of `stars` with its
+// gradient exported, backward, step of `frames` with the external gradient }, then one more forward so that the star batch
+// holds the final resampled grid - the loop the host language used to drive call by call (4 n_iter ABI calls).
+int lc_psf_distortion_run(lc_psf_batch *frames, lc_psf_batch *stars, int n_iter, const lc_adabelief_cfg *cfg) {
+  if (!frames || !stars || n_iter < 0) return LC_ERR_INVALID;
+  int rc = LC_OK;
+  for (int it = 0; it < n_iter && !rc; ++it) {
+    if ((rc = lc_psf_distortion_forward(frames, stars))) break;
+    if ((rc = lc_psf_batch_step_adabelief(stars, cfg, 0, 1))) break;
+    if ((rc = lc_psf_distortion_backward(frames, stars))) break;
+    rc = lc_psf_batch_step_adabelief(frames, cfg, 1, 0);
+  }
+  if (!rc) rc = lc_psf_distortion_forward(frames, stars);
+  return rc;
+}
 int lc_psf_batch_get_moffat(lc_psf_batch *b, float *moffat) {
   if (!b || !moffat) return LC_ERR_INVALID;
   LC_ENTER(b->ctx);

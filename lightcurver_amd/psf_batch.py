@@ -58,6 +58,12 @@ class PsfBatch:
     def distortion_backward(self, stars):
         self._chk(self._l.lc_psf_distortion_backward(self.h, stars.h), 'distortion_backward')
 
+    def distortion_run(self, stars, n_iter, **cfg):
+        """The whole pixel-grid stage of the distortion fit in one call (lc_psf_distortion_run): n_iter times
+        { forward; step of ``stars``; backward; step of this batch } and a final forward, enqueued from C++."""
+        c = _lib.adabelief_cfg(**cfg)
+        self._chk(self._l.lc_psf_distortion_run(self.h, stars.h, int(n_iter), C.byref(c)), 'distortion_run')
+
     def get_ext_grad(self):
         g = np.empty((self.F, self.N, self.N), np.float32)
         self._chk(self._l.lc_psf_batch_get_ext_grad(self.h, ptr(g)), 'get_ext_grad')

@@ -271,12 +271,9 @@ def _fit_with_distortion(images, data, weight, norms, stars, moffat, S_list, coo
         frame_b.set_distortion(S, theta[:, 4:13], xy)
         star_b.set_regularization(None, 0.0, 0.0)
         cfg = dict(init_learning_rate=init_learning_rate, schedule_learning_rate=schedule_learning_rate)
-        for _ in range(n_iter_adabelief):
-            frame_b.distortion_forward(star_b)                       # B seen by every star
-            star_b.step_adabelief(export_grad=True, **cfg)           # chi2, its gradients, step of a, x0, y0
-            frame_b.distortion_backward(star_b)                      # d chi2 / d B summed over the stars
-            frame_b.step_adabelief(use_ext_grad=True, **cfg)         # starlet term + step of B
-        frame_b.distortion_forward(star_b)
+        # per iteration: B resampled for every star -> step of the stars (chi2, its gradients, a, x0, y0) -> d chi2 / d B
+        # summed over the stars by the adjoint resampling -> starlet term + step of B; the loop runs in the library
+        frame_b.distortion_run(star_b, n_iter_adabelief, **cfg)
         hist = frame_b.loss_history() + star_b.loss_history().reshape(F, S, -1).sum(axis=1)
         res_f = frame_b.results()
         res_s = star_b.results()

@@ -20,6 +20,7 @@ j.set_loss(W=W, lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source
 free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'mean'] + (['h'] if with_h else [])
 j.set_free(free)
 j.run_adabelief(5, init_learning_rate=1e-4, schedule_learning_rate=False); ctx.synchronize()
+if os.environ.get('LCMI_PHIST'): print('param history rows of', j.param_history_begin(iters + 8), 'floats, recorded on the device')
 ctx.timer_start(); t0 = time.time()
 j.run_adabelief(iters, init_learning_rate=1e-4, schedule_learning_rate=False)
 ms = ctx.timer_stop(); wall = time.time() - t0
