@@ -127,6 +127,13 @@ JointVariant make_jv() {
   return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, joint_update_kernel<N, PX>, N * N / PX,
                       (int)(StarletLds<N>::FLOATS * sizeof(float)), false, joint_epoch_kernel<C, true>};
 }
+// stamp sizes beside the tuned ones (any multiple of 8 up to 64 at ss = 2): the same epoch kernel at that N, regulariser and
+// update as the run-time-N multi-block kernels (joint_gm.h) instead of a single-workgroup kernel built per size
+template <int N, int SS, int L, int NW, int LPF = 16>
+JointVariant make_jv_plain() {
+  typedef JointCfg<N, SS, L, NW, false, LPF> C;
+  return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, nullptr, 0, 0, false, joint_epoch_kernel<C, true>};
+}
 // large grids: spectrum scratch in HBM, starlet / update as multi-block kernels
 template <int N, int SS, int L, int NW, int LPF = 16>
 JointVariant make_jv_gm() {
@@ -178,6 +185,9 @@ const JointVariant *find_jv(int n, int ss, int E = 0, int n_cu = 0) {
       make_jv<32, 2, 48, 4, 16>(),    // n = 16, ss = 2
       make_jv<48, 2, 96, 4, 8>(),     // n = 24 (default stamp_size_stars)
       make_jv<64, 2, 96, 8, 16>(),    // n = 32 (default stamp_size_ROI)
+      make_jv_plain<80, 2, 128, 8>(),    // n = 40
+      make_jv_plain<96, 2, 192, 8>(),    // n = 48
+      make_jv_plain<112, 2, 192, 8>(),   // n = 56
       // n = 64 (C4); 16 waves with 32-lane transforms (4 waves per SIMD, 128 registers, 34 spilled) measured 2 % slower
       make_jv<128, 2, 192, 16, 8>(),
       // n = 128 (C5): transforms over 32 lanes (12 registers per lane like the n = 64 kernel; at 16 lanes the 24-register
@@ -254,6 +264,9 @@ void find_ps_kernel(int N, int ss, ps_fn *fn, int *lds, bool persist = false) {
   LC_PS(32, 2)
   LC_PS(48, 2)
   LC_PS(64, 2)
+  LC_PS(80, 2)
+  LC_PS(96, 2)
+  LC_PS(112, 2)
   LC_PS(128, 2)
 #undef LC_PS
 }

@@ -40,6 +40,7 @@ def test_no_cpu_fallback_without_gpu():
     # stamp-size queries need no device
     assert lib.lc_psf_supported(32, 2) == 1 and lib.lc_psf_supported(33, 2) == 0
     assert lib.lc_joint_supported(64, 2) == 1 and lib.lc_joint_supported(128, 2) == 1 and lib.lc_joint_supported(100, 2) == 0
+    assert all(lib.lc_joint_supported(n, 2) == 1 for n in (16, 24, 32, 40, 48, 56, 64, 128))
 
 
 def test_missing_library_fails_loudly(monkeypatch):

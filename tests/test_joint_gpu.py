@@ -47,7 +47,10 @@ def _setup(ctx, E, M, n, ss, seed, alpha_sigma=0.0, with_h=True):
 
 @pytest.mark.parametrize('E,M,n,ss,alpha', [(3, 1, 16, 1, 0.0), (4, 2, 16, 2, 0.0), (3, 2, 16, 2, 2.0),
                                             (3, 3, 24, 2, 0.5), (2, 2, 32, 2, 0.3), (2, 2, 64, 2, 0.3),
-                                            (3, 2, 64, 2, 0.0)])
+                                            (3, 2, 64, 2, 0.0),
+                                            # stamp sizes beside the tuned ones (config.yaml:205-206 leaves them free):
+                                            # the same kernels at that N, multi-block regulariser / update
+                                            (2, 2, 40, 2, 0.3), (2, 1, 48, 2, 0.0), (2, 2, 56, 2, 0.0)])
 def test_model_loss_and_gradients(ctx, E, M, n, ss, alpha, monkeypatch):
     # n = 64 is the instantiation BASELINE.json configs[3] (C4) runs: joint_epoch_kernel<JointCfg<128,2,192,...>> +
     # joint_update_kernel<128,16>; alpha = 0.3 exercises the ordered-gather T^T, alpha = 0 the 4-tap translation path
@@ -136,7 +139,7 @@ def test_noise_propagation_and_fisher(ctx, E, n, ss):
     assert H.rel_err(s, so) < 3e-5
 
 
-@pytest.mark.parametrize('n,ss,with_h', [(16, 2, True), (32, 2, True), (16, 1, False), (64, 2, True)])
+@pytest.mark.parametrize('n,ss,with_h', [(16, 2, True), (32, 2, True), (16, 1, False), (64, 2, True), (40, 2, True), (48, 2, False)])
 def test_adabelief_trajectory(ctx, n, ss, with_h):
     E, M, T = 4, 2, 20
     ds, j, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 40 + n, with_h=with_h)
