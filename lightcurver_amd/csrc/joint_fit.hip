@@ -55,6 +55,7 @@ struct lc_joint {
   int psize[LC_P_COUNT] = {};
   float *tabs = nullptr, *HG = nullptr;
   float *part = nullptr;  // [E][kMaxParts][4 + 3 kMaxSources] partial sums of phased launches
+  float *tshift = nullptr;  // [E][2] shifts used by the last gradient evaluation (JointArgs::tshift)
   float *chi2_e = nullptr, *g_a = nullptr, *g_cx_e = nullptr, *g_cy_e = nullptr, *g_dx = nullptr, *g_dy = nullptr,
         *g_mean = nullptr;
   float *model = nullptr, *fisher = nullptr, *shared = nullptr, *W = nullptr, *norms = nullptr,
@@ -85,6 +86,8 @@ struct lc_joint {
   unsigned int reg_seq = 0;
   bool flag_sync = false;            // this iteration's update checks reg_flag itself instead of waiting for evReg
   bool fuse_full = false;  // lc_joint_run_adabelief, background free: reduction over the epochs and update in one launch
+  bool fuse_stencil = false;  // ... and the T_e^T step too: no phase D, no slabs (global-spectrum kernels, translated epochs)
+  bool any_rotation = false;  // some alpha != 0
   bool pts_pending = false;  // the point-source starlet term of this iteration was evaluated by the stream-B launch  // lc_joint_run_adabelief: scalar reduction fused into the update
   // batched star photometry (lc_joint_create_groups): G stars, star g owns the epochs [gstart[g], gstart[g + 1]) and its own
   // shared positions c_x, c_y [g * M ..]; the update runs one block per star (joint_update_groups_kernel)
@@ -307,6 +310,8 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   A.part = j->part;
   A.fisher_out = j->fisher;
   A.group = j->group_dev;
+  A.skip_D = (mode == 0 && j->fuse_stencil) ? 1 : 0;
+  A.tshift = j->tshift;
   // no background in the scene: separable Gaussian filtering of the epoch PSFs instead of the FFT pipeline
   if (!A.h_active && j->M > 0 && j->psf_dev && !std::getenv("LCMI_JOINT_FFT_ONLY")) {
     ps_fn pk = nullptr;
@@ -353,7 +358,7 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   if (const char *tc = std::getenv("LCMI_TILE_COLS")) tile = v->ek_tile && std::atoi(tc) != 0;
   if (phased) {
     for (int ph = 0; ph < 6; ++ph) {
-      if (ph == 5 && !(A.h_active && A.need_hgrad)) continue;
+      if (ph == 5 && (!(A.h_active && A.need_hgrad) || A.skip_D)) continue;
       const bool tl = tile && v->ek_phase_tile[ph];
       const bool col = (ph == 1 || ph == 3), lite = col || ph == 5;
       epoch_fn pk = tl ? v->ek_phase_tile[ph] : v->ek_phase[ph];
@@ -362,7 +367,7 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
       LC_HIP(j->ctx, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
       hipLaunchKernelGGL(pk, dim3(j->E, np), dim3(v->e_thr), plds, j->ctx->stream, A);
     }
-    if (!(A.h_active && A.need_hgrad))  // (phase D's first workgroup of an epoch adds up the partial sums otherwise)
+    if (!(A.h_active && A.need_hgrad) || A.skip_D)  // (phase D's first workgroup of an epoch adds up the partial sums otherwise)
       hipLaunchKernelGGL(joint_epoch_finish_kernel, dim3(j->E), dim3(64), 0, j->ctx->stream, A, j->ss, parts);
     LC_HIP(j->ctx, hipGetLastError());
     return A.need_hgrad;
@@ -605,6 +610,18 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
       A.shared_w = j->shared;
       // (16-pixel tiles per block; 256 x 256 grids: four - 4096 one-tile blocks spend more on block turnover than on the
       //  sums, C5 shard 294 -> 287 us per iteration; LCMI_UPDATE_TILES overrides)
+      if (j->fuse_stencil) {
+        StencilSrc S;
+        const int KS = (j->KH + 15) / 16 * 16;
+        S.gs = (const float *)j->spec;
+        S.epoch_stride = (size_t)j->N * KS * 2;
+        S.row_stride = 2 * KS;
+        S.shifts = j->tshift;
+        S.ss = j->ss;
+        hipLaunchKernelGGL(joint_stencil_update_kernel, dim3(NN / kStPix + 2), dim3(kRedThreads), 0, stream, A, j->N, S);
+        LC_HIP(j->ctx, hipGetLastError());
+        return LC_OK;
+      }
       int tiles = j->flag_sync ? 2 : (NN / kRedPix >= 4096 ? 4 : 1);
       if (const char *tl = std::getenv("LCMI_UPDATE_TILES")) tiles = std::max(1, std::atoi(tl));
       if ((NN / kRedPix) % tiles) tiles = 1;
@@ -757,6 +774,7 @@ static int joint_create_impl(lc_ctx *ctx, int E, int M, int n, int ss, const flo
   TRY(dmalloc(j, &j->regs, 4 + 3 * kMaxSources + 4));
   if (v->gspec && !lean) TRY(dmalloc(j, &j->spec, (size_t)E * N * ((KH + 15) / 16 * 16)));  // rows padded to 128-byte lines (JointCfg::KS)
   if (v->gspec && !lean) TRY(dmalloc(j, &j->part, (size_t)E * kMaxParts * (4 + 3 * kMaxSources)));
+  if (v->gspec && !lean) TRY(dmalloc(j, &j->tshift, (size_t)E * 2));
   if (lean) {
     std::vector<int> grp(E);
     j->gstart.assign(G + 1, 0);
@@ -900,6 +918,11 @@ int lc_joint_set_param(lc_joint *j, int which, const float *values, int count) {
   if (!j || which < 0 || which >= LC_P_COUNT || !values) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
   if (count != j->psize[which]) LC_FAIL(j->ctx, LC_ERR_INVALID, "lc_joint_set_param: wrong element count");
+  if (which == LC_P_ALPHA) {
+    j->any_rotation = false;
+    for (int i = 0; i < count; ++i)
+      if (values[i] != 0.f) j->any_rotation = true;
+  }
   if (which == LC_P_H) {
     j->h_nonzero = false;
     for (int i = 0; i < count; ++i)
@@ -1107,11 +1130,19 @@ int lc_joint_step_local(lc_joint *j) {
     LC_HIP(j->ctx, hipEventRecord(j->evReg, j->streamB));
     j->reg_pending = true;
   }
+  const bool gm_update = !j->v->uk || ((j->cfg.lam_pts_source == 0.f || j->pts_pending) && (j->reg_pending || !reg_h_on(j)));
+  // global-spectrum kernels, every epoch a translation, reduction and update fused: the reduction can apply T_e^T itself
+  // (joint_stencil_update_kernel) - no phase D, no slabs (64 MB less traffic per iteration of the C5 shard).  Built, tested
+  // (tests/test_joint_paths_gpu.py) and NOT the default: measured on MI355X it is no faster - C5 shard 261.7 against 260.6
+  // us per iteration, 200 epochs 389.9 / 381.9, 1000 epochs 1621 / 1603 (blocks of 64 pixels with 4-byte taps: 260.8 /
+  // 385.5 / 1617): the strided gather over the epochs' scratch costs what phase D and the slabs cost.  LCMI_STENCIL_REDUCE=1
+  // selects it.
+  j->fuse_stencil = j->in_device_loop && j->free_mask[LC_P_H] && gm_update && j->v->gspec && j->spec && j->tshift && !j->any_rotation &&
+                    (j->N * j->N) % kStPix == 0 && j->N % 4 == 0 && !std::getenv("LCMI_SPLIT_UPDATE") && std::getenv("LCMI_STENCIL_REDUCE");
   int need = launch_epochs(j, 0, 0, false, nullptr);
   if (need < 0) return need;
   // inside lc_joint_run_adabelief, with the background fixed, only scalars are reduced: the multi-block update
   // kernel does that itself (one launch less per iteration)
-  const bool gm_update = !j->v->uk || ((j->cfg.lam_pts_source == 0.f || j->pts_pending) && (j->reg_pending || !reg_h_on(j)));
   j->fuse_pending = j->in_device_loop && need == 0 && !j->free_mask[LC_P_H] && gm_update;
   // with the background free the same holds for the image part: reduction and update share one launch
   j->fuse_full = j->in_device_loop && need == 1 && j->free_mask[LC_P_H] && gm_update && !std::getenv("LCMI_SPLIT_UPDATE");
@@ -1156,6 +1187,7 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   j->reg_pending = false;
   j->fuse_pending = false;
   j->fuse_full = false;
+  j->fuse_stencil = false;
   j->pts_pending = false;
   j->iters_done += 1;
   return LC_OK;

@@ -431,4 +431,143 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointU
   gm_small_blocks(A, N, lr, bc1, bc2, scl, 1, &pre);
 }
 
+// The same launch with the T_e^T step folded into the reduction (global-spectrum kernels, every epoch a pure translation):
+// phase D of the epoch kernel wrote one N x N slab per epoch (4-tap adjoint stencil of the scene gradient) that the reduction
+// read back - 32 MB out and 32 MB in per iteration at 125 epochs of 256 x 256, a launch of its own in the phased form.  Here
+// the reduction applies the stencil itself, reading the scene-gradient rows phase C' left in the spectrum scratch: a block
+// owns 64 consecutive pixels of one row of h, wave w adds the epochs w, w + 4, ... (each lane the four taps of its pixel:
+// coalesced 256-byte row segments, all loads of a wave independent), the four waves are combined in order, and the 64
+// pixels take their AdaBelief step in the same block.  Same taps and weights as phase D (joint_kernels.h); the border ring
+// of h (edge replication) takes phase D's exact ordered gather.
+struct StencilSrc {
+  const float *gs;      // scene-gradient rows of epoch e: gs + e * epoch_stride + u * row_stride + v
+  size_t epoch_stride;  // floats
+  int row_stride;       // floats
+  const float *shifts;  // [E][2] (dx, dy) as the epoch kernel of this iteration used them (the blocks of this launch that
+                        // update dx, dy run concurrently: the parameter arrays themselves are being rewritten)
+  int ss;
+};
+constexpr int kStPix = 256, kStEpochs = 512;
+__global__ __launch_bounds__(kRedThreads) void joint_stencil_update_kernel(JointUpdArgs A, int N, StencilSrc S) {
+  __shared__ float part[kRedThreads / 64][kStPix];
+  __shared__ double lanes[kRedThreads];
+  const int E = A.E, M = A.M, NN = N * N;
+  const int nimg = NN / kStPix;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float lr = A.lr, bc1 = A.bc1, bc2 = A.bc2;
+  if ((int)blockIdx.x < nimg) {
+    // a block owns 256 consecutive pixels of h; a lane four consecutive pixels of one row (N is a multiple of 4 ... 256):
+    // per epoch two rows of five scene-gradient samples, as phase D takes them (16-byte + 4-byte loads)
+    const int px0 = blockIdx.x * kStPix, pxl = px0 + 4 * lane, ky = pxl / N, kx0 = pxl % N;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // Per-epoch constants of the stencil (integer offsets, fractions) go through LDS in chunks of kStEpochs epochs: read per
+    // epoch from global memory they put a load -> address -> load chain into every turn of the epoch loop; from LDS the taps
+    // of several epochs are in flight at once.
+    __shared__ int cI[kStEpochs][2];
+    __shared__ float cF[kStEpochs][2];
+    const bool row_border = (ky == 0 || ky == N - 1);
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    for (int e0 = 0; e0 < E; e0 += kStEpochs) {
+      const int cnt = min(kStEpochs, E - e0);
+      __syncthreads();
+      for (int i = tid; i < cnt; i += kRedThreads) {
+        const float t_nsx = -((float)S.ss * S.shifts[2 * (e0 + i)]), t_nsy = -((float)S.ss * S.shifts[2 * (e0 + i) + 1]);
+        const float t_ixf = floorf(t_nsx), t_iyf = floorf(t_nsy);
+        cI[i][0] = (int)t_ixf;
+        cI[i][1] = (int)t_iyf;
+        cF[i][0] = t_nsx - t_ixf;
+        cF[i][1] = t_nsy - t_iyf;
+      }
+      __syncthreads();
+#pragma unroll 2
+      for (int k = wid; k < cnt; k += kRedThreads / 64) {
+        const int ixc = cI[k][0], iyc = cI[k][1];
+        const float fxc = cF[k][0], fyc = cF[k][1];
+        const float *GS = S.gs + (size_t)(e0 + k) * S.epoch_stride;
+        const float w00 = (1.f - fyc) * (1.f - fxc), w01 = (1.f - fyc) * fxc, w10 = fyc * (1.f - fxc), w11 = fyc * fxc;
+        const int r0 = ky - iyc, q0 = kx0 - ixc;
+        const bool ra = (r0 >= 0 && r0 < N), rb = (r0 >= 1 && r0 <= N);
+        const int rca = min(max(r0, 0), N - 1), rcb = min(max(r0 - 1, 0), N - 1);
+        float ga[5], gb[5];  // rows r0 and r0 - 1 at columns q0 - 1 .. q0 + 3
+        if (q0 >= 1 && q0 + 3 < N) {  // the whole window inside the row: one 16-byte and one 4-byte load per row
+          const float *pa = GS + (size_t)rca * S.row_stride + q0 - 1, *pb = GS + (size_t)rcb * S.row_stride + q0 - 1;
+          const f4u va = *(const f4u *)pa, vb = *(const f4u *)pb;
+          const float ea = pa[4], eb = pb[4];
+          ga[0] = va.x; ga[1] = va.y; ga[2] = va.z; ga[3] = va.w; ga[4] = ea;
+          gb[0] = vb.x; gb[1] = vb.y; gb[2] = vb.z; gb[3] = vb.w; gb[4] = eb;
+#pragma unroll
+          for (int t = 0; t < 5; ++t) {
+            ga[t] = ra ? ga[t] : 0.f;
+            gb[t] = rb ? gb[t] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 5; ++t) {
+            const int qq = q0 - 1 + t;
+            const bool qin = (qq >= 0 && qq < N);
+            const int qc = min(max(qq, 0), N - 1);
+            const float a = GS[(size_t)rca * S.row_stride + qc], b = GS[(size_t)rcb * S.row_stride + qc];
+            ga[t] = (ra && qin) ? a : 0.f;
+            gb[t] = (rb && qin) ? b : 0.f;
+          }
+        }
+        float o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = fmaf(w00, ga[t + 1], fmaf(w01, ga[t], fmaf(w10, gb[t + 1], w11 * gb[t])));
+        // the border ring of h collects clamped (edge-replicated) samples: phase D's exact ordered gather
+        if (row_border || kx0 == 0 || kx0 + 4 == N) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int kx = kx0 + t;
+            if (!(row_border || kx == 0 || kx == N - 1)) continue;
+            const int ulo = max((ky == 0) ? 0 : ky - iyc - 1, 0), uhi = min((ky == N - 1) ? N - 1 : ky - iyc, N - 1);
+            const int vlo = max((kx == 0) ? 0 : kx - ixc - 1, 0), vhi = min((kx == N - 1) ? N - 1 : kx - ixc, N - 1);
+            float ob = 0.f;
+            for (int u = ulo; u <= uhi; ++u)
+              for (int v = vlo; v <= vhi; ++v) {
+                const int x0 = v + ixc, y0 = u + iyc;
+                const int xa = min(max(x0, 0), N - 1), xb = min(max(x0 + 1, 0), N - 1);
+                const int ya = min(max(y0, 0), N - 1), yb = min(max(y0 + 1, 0), N - 1);
+                const float wx = ((xa == kx) ? (1.f - fxc) : 0.f) + ((xb == kx) ? fxc : 0.f);
+                const float wy = ((ya == ky) ? (1.f - fyc) : 0.f) + ((yb == ky) ? fyc : 0.f);
+                ob = fmaf(wx * wy, GS[(size_t)u * S.row_stride + v], ob);
+              }
+            o[t] = ob;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] += o[t];
+      }
+    }
+    *(float4 *)&part[wid][4 * lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    // state of this thread's pixel (one pixel per thread from here on): requested before the wait, used after it
+    const int px = px0 + tid;
+    float hv = A.h[px], m = A.mh[px], sv = A.sh[px];
+    __syncthreads();
+    wait_for_flag(A.wait_flag, A.wait_seq, A.wait_err);  // the regulariser of this iteration (second stream)
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < kRedThreads / 64; ++w) t += part[w][tid];
+    const float gr = (A.reg_mode == 2) ? ld_coherent(A.greg + px, A.wait_flag != nullptr) : 0.f;
+    A.shared_w[px] = t;
+    adabelief_step(hv, m, sv, t + gr, lr, bc1, bc2, A.ab);
+    A.h[px] = hv;
+    A.mh[px] = m;
+    A.sh[px] = sv;
+    phist_put(A, LC_P_H, px, hv);
+    return;
+  }
+  if ((int)blockIdx.x == nimg + 1) {  // shifts and sky levels: nothing to wait for
+    gm_small_blocks(A, N, lr, bc1, bc2, nullptr, 2);
+    return;
+  }
+  __shared__ float scl[4 * kMaxSources + 2];
+  FluxPre pre;
+  gm_flux_preload(A, pre);
+  reduce_scalars(E, M, NN, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.a_ref, A.shared_w, lanes, tid, scl);
+  __syncthreads();
+  wait_for_flag(A.wait_flag, A.wait_seq, A.wait_err);
+  gm_small_blocks(A, N, lr, bc1, bc2, scl, 1, &pre);
+}
+
 }  // namespace lc

@@ -48,6 +48,10 @@ struct JointArgs {
   float *conv_out;            // [E][N][N]
   // batched star photometry (point-source-only kernel): epoch -> star; the shared positions are cx[group[e] * M + i]
   const int *group;           // [E] or null
+  // the T_e^T step is applied by the reduction itself (joint_stencil_update_kernel): phase D leaves the scene-gradient rows
+  // in the spectrum scratch and writes no slab
+  int skip_D;
+  float *tshift;              // [E][2] the shifts (dx, dy) this evaluation used: the reduction runs beside the update of dx, dy
 };
 
 __device__ __forceinline__ void sample_coords(int u, int v, float c0, float ca, float sa, float sdx, float sdy,
@@ -197,6 +201,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   constexpr float inv_s2 = 1.0f / (kSigmaG * kSigmaG);
 
   LC_JSTAMP(0);
+  if constexpr (PHASE <= 1) {
+    if (A.skip_D && tid == 0 && part == 0) {
+      A.tshift[2 * e] = dxe;
+      A.tshift[2 * e + 1] = dye;
+    }
+  }
   for (int k = tid; k < L; k += C::NTHR) TW[k] = A.twid[k];
   if constexpr (C::FOLD && !LITE) {
     float2 *TWH = lds2 + C::OFF_TWH, *PHI = TWH + L / 2;
@@ -1168,7 +1178,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   }
   LC_JSTAMP(7);
   // ---- phase D: T_e^T of the scene gradient by an exact, ordered gather -----------------------------
-  if ((PHASE == 0 || PHASE == 6) && use_h && A.need_hgrad) {
+  if ((PHASE == 0 || PHASE == 6) && use_h && A.need_hgrad && !A.skip_D) {
     if constexpr (PHASE == 6) {  // (launched with the workgroup count of the row phases, whose partial sums these are)
       if (part == 0) joint_epoch_totals(A, e, tid, SS, nparts, RED);
     }

@@ -143,6 +143,20 @@ def test_tiled_column_passes_equal_the_direct_ones(ctx):
     _compare(a, b, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 12, 1e-4)
 
 
+@pytest.mark.parametrize('E,parts', [(3, None), (3, '1'), (5, '2')])
+def test_stencil_in_the_reduction_equals_the_slab_form(ctx, E, parts):
+    """128 x 128 ROIs, translated epochs, device loop: the reduction over the epochs applies the adjoint interpolation
+    stencil T_e^T itself, reading the scene-gradient rows from the spectrum scratch (no phase D, no per-epoch
+    slabs: LCMI_STENCIL_REDUCE=1 - measured no faster, so not the default), or phase D writes one slab per epoch that the
+    reduction adds up.  Same taps and weights; the epochs are added in another order."""
+    ds = make_roi_dataset(E=E, M=4, n=128, ss=2, seed=106)
+    env = {} if parts is None else {'LCMI_EPOCH_PARTS': parts}
+    a = _fit(ctx, ds, 4, 12, env=env)
+    b = _fit(ctx, ds, 4, 12, env=dict(env, LCMI_STENCIL_REDUCE='1'))
+    assert np.max(np.abs(a[0] - b[0]) / np.abs(b[0])) < 1e-6
+    _compare(a, b, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 12, 1e-4)
+
+
 @pytest.mark.parametrize('parts', ['2', '4'])
 def test_epoch_spread_over_workgroups_equals_the_one_workgroup_kernel(ctx, parts):
     """128 x 128 ROIs with fewer epochs than CUs: the six phases of an epoch become six launches on a grid

@@ -16,7 +16,8 @@ p = dict(ds['truth']); p['a'] = p['a'] * 0.9
 if not with_h: p['h'] = np.zeros_like(p['h'])
 j.set_params(**p)
 t0 = time.time(); W = j.propagate_noise(); print('propagate_noise', time.time() - t0)
-j.set_loss(W=W, lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=float(os.environ.get('LCMI_PTS', '0')), lam_flux_uniformity=float(os.environ.get('LCMI_FU', '0')))
+lam = 0.0 if os.environ.get('LCMI_LAM0') else 1.0   # LCMI_LAM0=1: no regulariser at all (the epoch path alone)
+j.set_loss(W=W, lam_scales=lam, lam_hf=lam, lam_positivity=100.0 * lam, lam_pts_source=float(os.environ.get('LCMI_PTS', '0')), lam_flux_uniformity=float(os.environ.get('LCMI_FU', '0')))
 free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'mean'] + (['h'] if with_h else [])
 j.set_free(free)
 j.run_adabelief(5, init_learning_rate=1e-4, schedule_learning_rate=False); ctx.synchronize()
