@@ -5,6 +5,7 @@
 #include <limits>
 #include <complex>
 #include <thread>
+#include <cstdio>
 #include <cstring>
 
 #include "joint_kernels.h"
@@ -39,10 +40,12 @@ struct JointVariant {
 };
 
 typedef void (*mreg_fn)(MregArgs);
+typedef void (*mreg_mm_fn)(MmBatch);
 struct MregKernels {
   int N;
   mreg_fn fwd, adj;
   int lds_fwd, lds_adj, nthr;
+  mreg_mm_fn mm;  // batched tiled products of the second form of the chain (joint_reg_mfma.h)
 };
 
 struct lc_joint {
@@ -78,9 +81,11 @@ struct lc_joint {
   const struct MregKernels *mreg = nullptr;
   float *mr_A = nullptr, *mr_AT = nullptr, *mr_C = nullptr, *mr_Z = nullptr, *mr_l1 = nullptr, *mr_pos = nullptr,
         *mr_part = nullptr, *mr_pbar = nullptr;
+  float *mr_l1b = nullptr, *mr_posb = nullptr, *mr_S = nullptr, *mr_T = nullptr;  // second form of the chain: per-block values, S planes, product scratch
   hipStream_t streamB = nullptr;      // the h regulariser runs here, concurrently with the epoch kernel
   hipEvent_t evReg = nullptr, evUpd = nullptr;
   bool reg_pending = false;
+  hipEvent_t *tl_events = nullptr;  // LCMI_TIMELINE diagnostic (lc_joint_run_adabelief)
   bool in_device_loop = false, fuse_pending = false;
   unsigned int *reg_flag = nullptr;  // [0] sequence number of the last finished regulariser chain, [1] a flag wait ran out
   unsigned int reg_seq = 0;
@@ -443,7 +448,8 @@ int launch_reg_gm(lc_joint *j, hipStream_t stream, bool with_pts, bool abar_from
 
 template <int N>
 MregKernels make_mreg() {
-  return MregKernels{N, mreg_forward_kernel<N>, mreg_adjoint_kernel<N>, MregCfg<N>::LDS_FWD, MregCfg<N>::LDS_ADJ, MregCfg<N>::NTHR};
+  return MregKernels{N, mreg_forward_kernel<N>, mreg_adjoint_kernel<N>, MregCfg<N>::LDS_FWD, MregCfg<N>::LDS_ADJ, MregCfg<N>::NTHR,
+                     mreg_mm_kernel<N>};
 }
 const MregKernels *find_mreg(int N) {
   static const MregKernels table[] = {make_mreg<128>(), make_mreg<256>()};
@@ -508,6 +514,54 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
   if (with_pts)
     hipLaunchKernelGGL(mreg_pbar_kernel, dim3(nb), dim3(kGmThreads), 0, stream, N, j->ss, j->E, j->M, j->par[LC_P_A],
                        j->par[LC_P_CX], j->par[LC_P_CY], j->mr_pbar);
+  if (!std::getenv("LCMI_REG_MFMA_V1")) {
+    // second form (default): batched tiled products over the scales, telescoped adjoint
+    const size_t NNs = (size_t)NN;
+    auto At = [&](int s) { return j->mr_AT + (size_t)s * NNs; };
+    auto Ap = [&](int s) { return j->mr_A + (size_t)s * NNs; };
+    MmBatch f1, f2, a1, a2;
+    std::memset(&f1, 0, sizeof(f1));
+    f2 = a1 = a2 = f1;
+    int nbch = 0;
+    auto add = [&](int s, const float *in, float *cplane, const float *splane, float *zplane) {
+      float *T = j->mr_T + (size_t)nbch * NNs;
+      f1.A[nbch] = in;      f1.B[nbch] = At(s); f1.C[nbch] = T;        // T = X AT_s
+      f2.A[nbch] = Ap(s);   f2.B[nbch] = T;     f2.C[nbch] = cplane;   // c_s = A_s T
+      a1.A[nbch] = splane;  a1.B[nbch] = Ap(s); a1.C[nbch] = T;        // T' = S_s A_s
+      a2.A[nbch] = At(s);   a2.B[nbch] = T;     a2.C[nbch] = zplane;   // Z_s = AT_s T'
+      ++nbch;
+    };
+    if (l1_on)
+      for (int s = 1; s <= J; ++s) add(s, j->par[LC_P_H], j->mr_C + (size_t)s * NNs, j->mr_S + (size_t)s * NNs, j->mr_Z + (size_t)s * NNs);
+    if (with_pts) add(1, j->mr_pbar, j->mr_C + (size_t)(J + 1) * NNs, j->mr_S + (size_t)(J + 1) * NNs, j->mr_Z + (size_t)(J + 1) * NNs);
+    f1.nb = f2.nb = a1.nb = a2.nb = nbch;
+    const dim3 mgrid(N / 64, N / 64, nbch), mblock(kMmThreads);
+    if (nbch > 0) {
+      hipLaunchKernelGGL(k->mm, mgrid, mblock, 0, stream, f1);
+      hipLaunchKernelGGL(k->mm, mgrid, mblock, 0, stream, f2);
+    }
+    MregSArgs G;
+    std::memset(&G, 0, sizeof(G));
+    G.B = A;
+    G.lam_pos = j->cfg.lam_positivity;
+    G.has_l1 = l1_on ? 1 : 0;
+    G.S = j->mr_S;
+    G.l1b = j->mr_l1b;
+    G.posb = j->mr_posb;
+    const int sslots = (l1_on ? J + 1 : 1) + (with_pts ? 1 : 0);  // slot 0 always: it carries the positivity term
+    hipLaunchKernelGGL(mreg_splanes_kernel, dim3(nb, sslots), dim3(kGmThreads), 0, stream, G, NN);
+    if (nbch > 0) {
+      hipLaunchKernelGGL(k->mm, mgrid, mblock, 0, stream, a1);
+      hipLaunchKernelGGL(k->mm, mgrid, mblock, 0, stream, a2);
+    }
+    hipLaunchKernelGGL(mreg_finish2_kernel, dim3(nb), dim3(kGmThreads), 0, stream, N, J, l1_on ? 1 : 0, with_pts ? 1 : 0, j->ss, j->M,
+                       j->mr_S, j->mr_Z, j->par[LC_P_CX], j->par[LC_P_CY], j->greg, j->mr_part);
+    j->reg_seq += 1;
+    hipLaunchKernelGGL(mreg_regs2_kernel, dim3(1), dim3(64), 0, stream, J, l1_on ? 1 : 0, with_pts ? 1 : 0, nb, j->M, j->mr_l1b,
+                       j->mr_posb, j->mr_part, j->regs, j->reg_flag, j->reg_seq);
+    LC_HIP(j->ctx, hipGetLastError());
+    return LC_OK;
+  }
   const int slots = (l1_on ? J : 0) + (with_pts ? 1 : 0);
   if (slots > 0) {
     hipLaunchKernelGGL(k->fwd, dim3(N / 32, slots), dim3(k->nthr), k->lds_fwd, stream, A);
@@ -810,14 +864,19 @@ static int joint_create_impl(lc_ctx *ctx, int E, int M, int n, int ss, const flo
     TRY(h2d(j, j->mr_A, A.data(), A.size() * sizeof(float)));
     TRY(h2d(j, j->mr_AT, AT.data(), AT.size() * sizeof(float)));
     TRY(dmalloc(j, &j->mr_C, (size_t)(j->J + 2) * NN));
-    TRY(dmalloc(j, &j->mr_Z, (size_t)(j->J + 1) * NN));
+    TRY(dmalloc(j, &j->mr_Z, (size_t)(j->J + 2) * NN));
+    TRY(dmalloc(j, &j->mr_l1b, (size_t)(j->J + 2) * nb));
+    TRY(dmalloc(j, &j->mr_posb, nb));
+    TRY(dmalloc(j, &j->mr_S, (size_t)(j->J + 2) * NN));
+    TRY(dmalloc(j, &j->mr_T, (size_t)(j->J + 1) * NN));
     TRY(dmalloc(j, &j->mr_l1, j->J + 1));
     TRY(dmalloc(j, &j->mr_pos, nb));
     TRY(dmalloc(j, &j->mr_part, nb * 3 * kMaxSources));
     TRY(dmalloc(j, &j->mr_pbar, NN));
-    TRY(dmalloc(j, &j->reg_flag, 2));
+    TRY(dmalloc(j, &j->reg_flag, 4));  // [0] completion flag, [1] a wait ran out, [2] ticket of the finishing launch
     LC_HIP(ctx, hipFuncSetAttribute((const void *)j->mreg->fwd, hipFuncAttributeMaxDynamicSharedMemorySize, j->mreg->lds_fwd));
     LC_HIP(ctx, hipFuncSetAttribute((const void *)j->mreg->adj, hipFuncAttributeMaxDynamicSharedMemorySize, j->mreg->lds_adj));
+
   }
   LC_HIP(ctx, hipStreamCreate(&j->streamB));
   LC_HIP(ctx, hipEventCreateWithFlags(&j->evReg, hipEventDisableTiming));
@@ -1125,8 +1184,10 @@ int lc_joint_step_local(lc_joint *j) {
     // starlet l1 + positivity of h depend on h alone: evaluate them on a second stream while the epoch
     // kernel (which leaves CUs idle whenever E < 256) runs; the update kernel joins the two
     LC_HIP(j->ctx, hipStreamWaitEvent(j->streamB, j->evUpd, 0));
+    if (j->tl_events) (void)hipEventRecord(j->tl_events[1], j->streamB);
     int rc = launch_update(j, 0, 0, nullptr, false, false, 1, j->streamB);
     if (rc) return rc;
+    if (j->tl_events) (void)hipEventRecord(j->tl_events[2], j->streamB);
     LC_HIP(j->ctx, hipEventRecord(j->evReg, j->streamB));
     j->reg_pending = true;
   }
@@ -1442,10 +1503,36 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
   if ((rc = run_adabelief_persistent(j, n_iter, cfg, &done)) || done) return rc;
   j->in_device_loop = true;
   bool flags_used = false;
+  // LCMI_TIMELINE=1 (diagnostic): HIP events around the parts of ONE iteration in the middle of the run - where the epoch
+  // kernels, the regulariser chain on the second stream and the update start and end relative to each other
+  hipEvent_t tl[5] = {};
+  const int tl_it = std::getenv("LCMI_TIMELINE") ? n_iter / 2 : -1;
   for (int it = 0; it < n_iter && !rc; ++it) {
+    if (it == tl_it) {
+      for (auto &e : tl) (void)hipEventCreate(&e);
+      j->tl_events = tl;
+      (void)hipEventRecord(tl[0], j->ctx->stream);
+    }
     if ((rc = lc_joint_step_local(j))) break;
+    if (it == tl_it) (void)hipEventRecord(tl[3], j->ctx->stream);
     rc = lc_joint_step_update(j, cfg);
+    if (it == tl_it) {
+      (void)hipEventRecord(tl[4], j->ctx->stream);
+      j->tl_events = nullptr;
+    }
     flags_used = flags_used || j->flag_sync;
+  }
+  if (tl_it >= 0 && !rc) {
+    (void)hipStreamSynchronize(j->ctx->stream);
+    (void)hipStreamSynchronize(j->streamB);
+    float b0 = 0, b1 = 0, e1 = 0, e2 = 0;
+    const bool chain = hipEventElapsedTime(&b0, tl[0], tl[1]) == hipSuccess && hipEventElapsedTime(&b1, tl[0], tl[2]) == hipSuccess;
+    (void)hipEventElapsedTime(&e1, tl[0], tl[3]);
+    (void)hipEventElapsedTime(&e2, tl[0], tl[4]);
+    std::fprintf(stderr, "timeline (us, from the end of the previous update): epoch kernels end %.1f, update ends %.1f", e1 * 1e3f, e2 * 1e3f);
+    if (chain) std::fprintf(stderr, ", regulariser chain %.1f .. %.1f", b0 * 1e3f, b1 * 1e3f);
+    std::fprintf(stderr, "\n");
+    for (auto &e : tl) (void)hipEventDestroy(e);
   }
   j->in_device_loop = false;
   j->flag_sync = false;

@@ -295,6 +295,224 @@ __global__ void mreg_regs_kernel(int J, int l1_on, int has_pts, int nblocks, int
   }
 }
 
+// ---- second form of the chain (default): batched tiled products, telescoped adjoint, one finishing launch -------------------
+// The block-column kernels above keep 72 long-lived workgroups on the machine for ~130 us per iteration of a 256 x 256 grid,
+// beside the epoch kernel's phases: every phase that shares CUs with them runs 40 - 60 % longer (rocprofv3 timelines,
+// profiles/r03_c5_timeline_*.txt: C5 shard 264 us per iteration with the chain, 212 without).  The same numbers as plain
+// batched products C = A B over the scales (row-major N x N operands, 64 x 64 output tiles, four waves of 32 x 32 MFMA
+// accumulators, operands staged through LDS in K slices of 32 with 16-byte loads):
+//     forward   T_j = X AT_j ,  c_j = A_j T_j                                (j = 1 .. J; the point-source channel with j = 1)
+//     values    S_0 = q_0 - positivity ,  S_j = q_j - q_{j-1} ,  q_J = 0     (one element-wise launch, with the l1 / positivity
+//                                                                             values per block)
+//     adjoint   T'_j = S_j A_j ,  Z_j = AT_j T'_j                             (telescoped: d l1 / d X = S_0 + sum_{j >= 1} Z_j)
+// Each launch is short and covers the machine (16 tiles x up to 9 scales), so the chain overlaps one or two phases instead
+// of all of them.
+struct MmBatch {
+  int nb;                        // products of this launch
+  const float *A[12], *B[12];    // row-major N x N
+  float *C[12];
+};
+constexpr int kMmThreads = 256, kMmKT = 32;
+// C[b] = A[b] B[b]; grid (N / 64, N / 64, nb)
+template <int N>
+__global__ __launch_bounds__(kMmThreads) void mreg_mm_kernel(MmBatch G) {
+  __shared__ float As[2][64][kMmKT + 1];   // A tile: 64 rows x 32 k (padded: a lane reads one k of 32 consecutive rows)
+  __shared__ float Bs[2][kMmKT][64 + 4];   // B tile: 32 k x 64 columns
+  const int bz = blockIdx.z, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const float *A = G.A[bz], *B = G.B[bz];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, h = lane >> 5;
+  const int wr = (wid >> 1) * 32, wc = (wid & 1) * 32;  // the wave's 32 x 32 accumulator inside the tile
+  // staging: A tile 64 x 32 = 512 float4 (two per thread), B tile 32 x 64 = 512 float4 (two per thread)
+  float4 pa[2], pb[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + q * kMmThreads;
+      const int ar = e >> 3, ak = (e & 7) * 4;      // 8 float4 per A row
+      pa[q] = *(const float4 *)(A + (size_t)(r0 + ar) * N + k0 + ak);
+      const int bk = e >> 4, bc = (e & 15) * 4;     // 16 float4 per B row
+      pb[q] = *(const float4 *)(B + (size_t)(k0 + bk) * N + c0 + bc);
+    }
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + q * kMmThreads;
+      const int ar = e >> 3, ak = (e & 7) * 4;
+      As[buf][ar][ak] = pa[q].x; As[buf][ar][ak + 1] = pa[q].y; As[buf][ar][ak + 2] = pa[q].z; As[buf][ar][ak + 3] = pa[q].w;
+      const int bk = e >> 4, bc = (e & 15) * 4;
+      *(float4 *)&Bs[buf][bk][bc] = pb[q];
+    }
+  };
+  mr_acc acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  fetch(0);
+  put(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < N; k0 += kMmKT, buf ^= 1) {
+    if (k0 + kMmKT < N) fetch(k0 + kMmKT);   // next slice in flight while this one is multiplied
+    // lane half h feeds k = 2 s + h of every step: a = A[row][k], b = B[k][column]
+#pragma unroll
+    for (int s2 = 0; s2 < kMmKT / 2; ++s2) {
+      const int k = 2 * s2 + h;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][wr + i][k], Bs[buf][k][wc + i], acc, 0, 0, 0);
+    }
+    if (k0 + kMmKT < N) put(buf ^ 1);
+    __syncthreads();
+  }
+  float *C = G.C[bz];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) C[(size_t)(r0 + wr + mr_row(r, h)) * N + c0 + wc + i] = acc[r];
+}
+
+// S planes and values.  grid (NN / 256, slots): slot map as the adjoint: has_l1 ? 0 .. J : 0 only; then the point-source slot.
+//   slot 0       S[0] = q_0 - positivity sub-gradient      (final: needs no product)
+//   slot 1 .. J  S[j] = q_j - q_{j-1},  q_J = 0
+//   pts          S[J + 1] = q^p = lam_pts W_0 sign(Pbar - c_1(Pbar))
+// values per block: l1b[j][blk] (scale j < J, from slot j), posb[blk] (slot 0), l1b[J + 1][blk] (point-source slot)
+struct MregSArgs {
+  MregArgs B;
+  float lam_pos;
+  int has_l1;
+  float *S;      // [J + 2][NN]
+  float *l1b;    // [J + 2][nblk]
+  float *posb;   // [nblk]
+};
+__global__ __launch_bounds__(kGmThreads) void mreg_splanes_kernel(MregSArgs G, int NN) {
+  __shared__ float red[kGmThreads / 64][2];
+  const MregArgs &A = G.B;
+  const int J = A.J, nblk = gridDim.x, blk = blockIdx.x;
+  const int k = blk * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nh = G.has_l1 ? J + 1 : 1;
+  const bool pts = ((int)blockIdx.y >= nh);
+  const int j = pts ? 0 : (int)blockIdx.y;
+  auto plane = [&](int s) { return s == 0 ? A.X : A.C + (size_t)s * NN; };
+  auto lw_of = [&](int s, float lam) { return A.W ? lam * A.W[(size_t)s * NN + k] : lam * A.norms[s]; };
+  auto sgn = [](float d, float lw) { return (d > 0.f) ? lw : ((d < 0.f) ? -lw : 0.f); };
+  float l1 = 0.f, pos = 0.f;
+  if (k < NN) {
+    if (pts) {
+      const float d = A.P[k] - A.C[(size_t)(J + 1) * NN + k], lw = lw_of(0, A.lam_pts);
+      G.S[(size_t)(J + 1) * NN + k] = sgn(d, lw);
+      l1 = lw * fabsf(d);
+    } else if (j == 0) {
+      const float hv = A.X[k];
+      float z = 0.f;
+      if (G.has_l1) {
+        const float d = hv - A.C[(size_t)NN + k], lw = lw_of(0, A.lam_hf);
+        z = sgn(d, lw);
+        l1 = lw * fabsf(d);
+      }
+      if (G.lam_pos != 0.f && hv < 0.f) {
+        pos = -G.lam_pos * hv;
+        z -= G.lam_pos;
+      }
+      G.S[k] = z;
+    } else {
+      const float cm = plane(j - 1)[k], cj = plane(j)[k];
+      const float qm = sgn(cm - cj, lw_of(j - 1, j - 1 == 0 ? A.lam_hf : A.lam_sc));
+      float qj = 0.f;
+      if (j < J) {
+        const float d = cj - plane(j + 1)[k], lw = lw_of(j, A.lam_sc);
+        qj = sgn(d, lw);
+        l1 = lw * fabsf(d);
+      }
+      G.S[(size_t)j * NN + k] = qj - qm;
+    }
+  }
+  l1 = wave_sum_shfl(l1);
+  pos = wave_sum_shfl(pos);
+  if (lane == 0) {
+    red[wid][0] = l1;
+    red[wid][1] = pos;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int w = 0; w < kGmThreads / 64; ++w) {
+      t0 += red[w][0];
+      t1 += red[w][1];
+    }
+    if (pts) G.l1b[(size_t)(J + 1) * nblk + blk] = t0;
+    else if (j < J) G.l1b[(size_t)j * nblk + blk] = t0;
+    if (!pts && j == 0) G.posb[blk] = t1;
+  }
+}
+
+// greg = S[0] + sum_{j = 1 .. J} Z[j]; the point-source slot: z = S[J + 1] - Z[J + 1] and its inner products with the
+// Gaussians of the sources (per-block partials, gm_pts_inner_kernel's contract); a second, one-wave launch adds the per-block
+// values and inner products into regs (regs[0] = l1, regs[1] = positivity, regs[2] = point-source term, regs[4 ..] the inner
+// products; fixed order) and raises the completion flag (mreg_regs2_kernel).
+__global__ __launch_bounds__(kGmThreads) void mreg_finish2_kernel(int N, int J, int has_l1, int has_pts, int ss, int M, const float *S,
+                                                                  const float *Z, const float *cx, const float *cy, float *greg,
+                                                                  float *pts_part) {
+  __shared__ float red[kGmThreads / 64][kMaxSources * 3];
+  const int NN = N * N;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool in = k < NN;
+  if (in) {
+    float g = S[k];
+    if (has_l1)
+      for (int s = 1; s <= J; ++s) g += Z[(size_t)s * NN + k];
+    greg[k] = g;
+  }
+  if (has_pts) {
+    const float c0 = (N - 1) * 0.5f, inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm2 = 0.15915494309189535f * inv_s2;
+    const float z = in ? S[(size_t)(J + 1) * NN + k] - Z[(size_t)(J + 1) * NN + k] : 0.f;
+    const int u = in ? k / N : 0, v = in ? k % N : 0;
+    for (int i = 0; i < M; ++i) {
+      const float tx = (float)v - (c0 + ss * cx[i]), ty = (float)u - (c0 + ss * cy[i]);
+      const float gq = z * nrm2 * expf(-0.5f * (tx * tx + ty * ty) * inv_s2);
+      const float sa = wave_sum_shfl(gq), sx = wave_sum_shfl(gq * tx * inv_s2), sy = wave_sum_shfl(gq * ty * inv_s2);
+      if (lane == 0) {
+        red[wid][i * 3] = sa;
+        red[wid][i * 3 + 1] = sx;
+        red[wid][i * 3 + 2] = sy;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 3 * M) {
+      float acc = 0.f;
+      for (int w = 0; w < kGmThreads / 64; ++w) acc += red[w][threadIdx.x];
+      pts_part[(size_t)blockIdx.x * 3 * kMaxSources + threadIdx.x] = acc;
+    }
+  }
+}
+// inner products of the point-source term (lanes stride over the blocks, fixed combine order), then the completion flag
+__global__ void mreg_regs2_kernel(int J, int has_l1, int has_pts, int nblocks, int M, const float *l1b, const float *posb,
+                                  const float *pts_part, float *regs, unsigned int *done_flag, unsigned int done_seq) {
+  const int lane = threadIdx.x;
+  {  // values: l1 over the scales, positivity, point-source term (per-block partials; lanes stride, fixed combine order)
+    float a = 0.f, b = 0.f, c = 0.f;
+    if (has_l1)
+      for (int i = lane; i < J * nblocks; i += 64) a += l1b[i];
+    for (int i = lane; i < nblocks; i += 64) b += posb[i];
+    if (has_pts)
+      for (int i = lane; i < nblocks; i += 64) c += l1b[(size_t)(J + 1) * nblocks + i];
+    a = wave_sum_shfl(a);
+    b = wave_sum_shfl(b);
+    c = wave_sum_shfl(c);
+    if (lane == 0) {
+      regs[0] = a;
+      regs[1] = b;
+      if (has_pts) regs[2] = c;
+    }
+  }
+  if (has_pts)
+    for (int t = 0; t < 3 * M; ++t) {
+      float acc = 0.f;
+      for (int blk = lane; blk < nblocks; blk += 64) acc += pts_part[(size_t)blk * 3 * kMaxSources + t];
+      acc = wave_sum_shfl(acc);
+      if (lane == 0) regs[4 + t] = acc;
+    }
+  if (done_flag) {  // (one wave; every write of this chain before the flag)
+    __threadfence();
+    if (lane == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // test hook (LCMI_REG_DELAY_US): holds the second stream back in front of the chain, so that the update kernel of the
 // iteration really has to wait for the chain's completion flag
 __global__ void mreg_delay_kernel(long long ticks) {  // ticks of the constant 100 MHz counter
