@@ -160,7 +160,7 @@ def psf_step(b, stars0, ab):
 
 
 def cpu_baseline(ds, weight, b, stars0, ss, seconds_target=12.0):
-    """oracle/psf_cpu.c (fp32 C + OpenMP over frames, the same algorithm as the HIP path; kind 'port') timed on the
+    """oracle/psf_cpu.c (fp32 C + OpenMP over (frame, star) work units, the same algorithm as the HIP path; kind 'port') timed on the
     host cores on a bounded sample of the same C2 workload: all hardware threads, then one thread."""
     from oracle import model as om, psf_cpu
     try:  # compile for the CPU this runs on; the portable build shipped with the repo is the fall-back
@@ -190,7 +190,7 @@ def cpu_baseline(ds, weight, b, stars0, ss, seconds_target=12.0):
                           finite=bool(np.all(np.isfinite(hist))))
     return dict(value=out['all']['rate'], unit='cutouts/sec', cores=threads, kind='port',
                 sample=f"{out['all']['frames']} frames x {S} stamps x {out['all']['iters']} AdaBelief iterations of the same "
-                       f"C2 data ({out['all']['seconds']:.1f} s), oracle/psf_cpu.c fp32 + OpenMP over frames",
+                       f"C2 data ({out['all']['seconds']:.1f} s), oracle/psf_cpu.c fp32 + OpenMP over (frame, star)",
                 value_one_thread=out['one']['rate'],
                 sample_one_thread=f"{out['one']['frames']} frames x {S} stamps x {out['one']['iters']} iterations "
                                   f"({out['one']['seconds']:.1f} s)",

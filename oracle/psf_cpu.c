@@ -1,4 +1,4 @@
-/* CPU restatement (plain C, fp32, OpenMP over frames) of the pixel-grid stage of the PSF fit.
+/* CPU restatement (plain C, fp32, OpenMP over (frame, star)) of the pixel-grid stage of the PSF fit.
  *
  * TEST / MEASUREMENT INFRASTRUCTURE ONLY (see oracle/__init__.py): this file is the "port" CPU baseline of
  * bench.py (cpu_baseline.kind = "port") and a second, independent checker of the HIP path in tests/.  The product
@@ -120,17 +120,15 @@ static void work_free(Work *w) {
   free(w->q); free(w->z); free(w->y); free(w->y2);
 }
 
-/* loss and gradients of one frame at the current parameters.  gs[S][3] = dL/da, dL/dx0, dL/dy0; gB += chi2 part,
- * z = l1 sub-gradient.  model_out (nullable) [S][n][n]. */
-static real frame_eval(int S, int n, int ss, const real *data, const real *wgt, const real *Tm, const real *W,
-                        const real *B, const real *stars, real lam_sc, real lam_hf, Work *w, real *gs,
-                        real *model_out, real *chi2_out) {
-  const int N = n * ss, J = ilog2i(N);
-  const size_t NN = (size_t)N * N;
+/* One star of a frame: forward model, chi2 and the star's gradients gs[3] = dL/da, dL/dx0, dL/dy0; its share of
+ * dchi2/dB is ADDED to gB.  T = Moffat + B of the frame (read only); tmp, tmpx, V, res of `w` are scratch.
+ * model_out (nullable) [n][n].  Returns the star's chi2. */
+static double star_eval(int s, int n, int ss, const real *data, const real *wgt, const real *T, const real *stars, Work *w,
+                        real *gB, real *gs, real *model_out) {
+  const int N = n * ss;
   const real c_off = (N % 2 == 0) ? R(0.5) : R(0.0);
-  for (size_t i = 0; i < NN; ++i) { w->T[i] = Tm[i] + B[i]; w->gB[i] = R(0.); }
   double chi2 = 0.0;
-  for (int s = 0; s < S; ++s) {
+  {
     const real a = stars[s * 4 + 0], x0 = stars[s * 4 + 1], y0 = stars[s * 4 + 2], sky = stars[s * 4 + 3];
     real gx[MAXT], dgx[MAXT], gy[MAXT], dgy[MAXT];
     int ox, oy;
@@ -143,7 +141,7 @@ static real frame_eval(int S, int n, int ss, const real *data, const real *wgt, 
         for (int dv = 0; dv < ss; ++dv) {
           const int base = ss * jd + dv - ox + KRG;  /* v = base - k must lie in [0, N) */
           const int k0 = base - (N - 1) > 0 ? base - (N - 1) : 0, k1 = base < MAXT - 1 ? base : MAXT - 1;
-          const real *Tr = w->T + u * N + base;
+          const real *Tr = T + u * N + base;
           for (int k = k0; k <= k1; ++k) { acc += gx[k] * Tr[-k]; accx += dgx[k] * Tr[-k]; }
         }
         w->tmp[u * n + jd] = acc;
@@ -151,7 +149,7 @@ static real frame_eval(int S, int n, int ss, const real *data, const real *wgt, 
       }
     /* column pass + row down-sampling, residuals, chi2, star gradients */
     double ga = 0.0, ggx = 0.0, ggy = 0.0;
-    const real *d = data + (size_t)s * n * n, *wg = wgt + (size_t)s * n * n;
+    const real *d = data, *wg = wgt;  /* (the caller passes this star's stamp) */
     for (int id = 0; id < n; ++id)
       for (int jd = 0; jd < n; ++jd) {
         real fv = R(0.), fx = R(0.), fy = R(0.);
@@ -172,11 +170,11 @@ static real frame_eval(int S, int n, int ss, const real *data, const real *wgt, 
         ggx += (double)rw * fx;
         ggy += (double)rw * fy;
         w->res[id * n + jd] = rw;
-        if (model_out) model_out[(size_t)s * n * n + id * n + jd] = model;
+        if (model_out) model_out[id * n + jd] = model;
       }
-    gs[s * 3 + 0] = (real)ga;
-    gs[s * 3 + 1] = (real)(ggx * a * ss);
-    gs[s * 3 + 2] = (real)(ggy * a * ss);
+    gs[0] = (real)ga;
+    gs[1] = (real)(ggx * a * ss);
+    gs[2] = (real)(ggy * a * ss);
     /* transposed column pass: V[u][jd] = sum_id gy(ss id + du - u) rw[id][jd] */
     memset(w->V, 0, sizeof(real) * (size_t)N * n);
     for (int id = 0; id < n; ++id)
@@ -194,12 +192,18 @@ static real frame_eval(int S, int n, int ss, const real *data, const real *wgt, 
         for (int dv = 0; dv < ss; ++dv) {
           const int base = ss * jd + dv - ox + KRG;
           const int k0 = base - (N - 1) > 0 ? base - (N - 1) : 0, k1 = base < MAXT - 1 ? base : MAXT - 1;
-          real *gr = w->gB + u * N + base;
+          real *gr = gB + u * N + base;
           for (int k = k0; k <= k1; ++k) gr[-k] += gx[k] * vv;
         }
       }
   }
-  /* starlet l1 of B: value, sub-gradient z through the exact adjoint */
+  return chi2;
+}
+
+/* starlet l1 of B: value (returned), sub-gradient w->z through the exact adjoint */
+static double starlet_eval(int N, const real *W, const real *B, real lam_sc, real lam_hf, Work *w) {
+  const int J = ilog2i(N);
+  const size_t NN = (size_t)N * N;
   double l1 = 0.0;
   memset(w->z, 0, sizeof(real) * NN);
   if (lam_sc != R(0.) || lam_hf != R(0.)) {
@@ -228,6 +232,25 @@ static real frame_eval(int S, int n, int ss, const real *data, const real *wgt, 
       for (size_t i = 0; i < NN; ++i) w->z[i] = q[i] + w->y[i];
     }
   }
+  return l1;
+}
+
+/* loss and gradients of one frame at the current parameters.  gs[S][3] = dL/da, dL/dx0, dL/dy0; w->gB = chi2 part,
+ * w->z = l1 sub-gradient.  model_out (nullable) [S][n][n]. */
+static real frame_eval(int S, int n, int ss, const real *data, const real *wgt, const real *Tm, const real *W,
+                        const real *B, const real *stars, real lam_sc, real lam_hf, Work *w, real *gs,
+                        real *model_out, real *chi2_out) {
+  const int N = n * ss;
+  const size_t NN = (size_t)N * N, nn = (size_t)n * n;
+  for (size_t i = 0; i < NN; ++i) { w->T[i] = Tm[i] + B[i]; w->gB[i] = R(0.); }
+  double chi2 = 0.0;
+  for (int s = 0; s < S; ++s) {  /* every star's share on its own, then added: the order psf_cpu_run uses (stars in parallel) */
+    memset(w->y, 0, sizeof(real) * NN);
+    chi2 += star_eval(s, n, ss, data + (size_t)s * nn, wgt + (size_t)s * nn, w->T, stars, w, w->y, gs + s * 3,
+                      model_out ? model_out + (size_t)s * nn : NULL);
+    for (size_t i = 0; i < NN; ++i) w->gB[i] += w->y[i];
+  }
+  const double l1 = starlet_eval(N, W, B, lam_sc, lam_hf, w);
   if (chi2_out) *chi2_out = (real)chi2;
   return (real)(0.5 * chi2 + l1);
 }
@@ -243,7 +266,10 @@ static void adabelief_step(real *p, real *m, real *s, real g, real lr, real bc1,
 }
 
 /* n_iter AdaBelief iterations on B, a, x0, y0 of every frame (state in / out).  loss_hist[F][n_iter + 1]:
- * loss before each update, then the loss of the final parameters.  Returns 0, or -1 on allocation failure. */
+ * loss before each update, then the loss of the final parameters.  Returns 0, or -1 on allocation failure.
+ * Parallel over (frame, star) for the convolution part and over frames for the starlet term and the update: an iteration
+ * is F * (S + 1) independent work units, so a host with more hardware threads than frames (256 threads, 100 frames of C2)
+ * is kept busy; three barriers per iteration. */
 int psf_cpu_run(int F, int S, int n, int ss, const real *data, const real *wgt, const real *Tm, const real *W,
                 real *B, real *mB, real *sB, real *stars, real *stars_m, real *stars_s, real lam_sc,
                 real lam_hf, real lr0, int schedule, int t0, int n_iter, real *loss_hist, int n_threads) {
@@ -253,37 +279,64 @@ int psf_cpu_run(int F, int S, int n, int ss, const real *data, const real *wgt, 
 #ifdef _OPENMP
   if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
+  real *T_all = malloc(sizeof(real) * F * NN), *gBs = malloc(sizeof(real) * (size_t)F * S * NN), *z_all = malloc(sizeof(real) * F * NN);
+  real *gs_all = malloc(sizeof(real) * (size_t)F * S * 3);
+  double *chi_all = malloc(sizeof(double) * (size_t)F * S), *l1_all = malloc(sizeof(double) * F);
+  if (!T_all || !gBs || !z_all || !gs_all || !chi_all || !l1_all) fail = 1;
 #pragma omp parallel
   {
     Work w;
-    real *gs = malloc(sizeof(real) * (size_t)S * 3);
-    if (!work_alloc(&w, N, n, J) || !gs) {
+    int ok = work_alloc(&w, N, n, J);
+    if (!ok) {
 #pragma omp atomic write
       fail = 1;
-    } else {
+    }
+#pragma omp barrier
+    if (!fail) {
+      for (int it = 0; it <= n_iter; ++it) {
+#pragma omp for schedule(static)
+        for (int f = 0; f < F; ++f)
+          for (size_t i = 0; i < NN; ++i) T_all[(size_t)f * NN + i] = Tm[(size_t)f * NN + i] + B[(size_t)f * NN + i];
 #pragma omp for schedule(dynamic, 1)
-      for (int f = 0; f < F; ++f) {
-        const real *df = data + (size_t)f * S * nn, *wf = wgt + (size_t)f * S * nn, *Tf = Tm + (size_t)f * NN;
-        const real *Wf = W + (size_t)f * J * NN;
-        real *Bf = B + (size_t)f * NN, *mf = mB + (size_t)f * NN, *sf = sB + (size_t)f * NN;
-        real *st = stars + (size_t)f * S * 4, *stm = stars_m + (size_t)f * S * 4, *sts = stars_s + (size_t)f * S * 4;
-        for (int it = 0; it <= n_iter; ++it) {
-          const real loss = frame_eval(S, n, ss, df, wf, Tf, Wf, Bf, st, lam_sc, lam_hf, &w, gs, NULL, NULL);
-          loss_hist[(size_t)f * (n_iter + 1) + it] = loss;
-          if (it == n_iter) break;
-          const int t = t0 + it;
-          const double lr = schedule ? (double)lr0 * pow(0.99, (double)t / 10.0) : (double)lr0;
-          const real bc1 = (real)(1.0 / (1.0 - pow(0.9, t + 1))), bc2 = (real)(1.0 / (1.0 - pow(0.999, t + 1)));
-          for (size_t i = 0; i < NN; ++i) adabelief_step(&Bf[i], &mf[i], &sf[i], w.gB[i] + w.z[i], (real)lr, bc1, bc2);
+        for (int unit = 0; unit < F * (S + 1); ++unit) {
+          const int f = unit / (S + 1), u = unit % (S + 1);
+          if (u < S) {
+            real *g = gBs + ((size_t)f * S + u) * NN;
+            memset(g, 0, sizeof(real) * NN);
+            chi_all[(size_t)f * S + u] = star_eval(u, n, ss, data + ((size_t)f * S + u) * nn, wgt + ((size_t)f * S + u) * nn,
+                                                  T_all + (size_t)f * NN, stars + (size_t)f * S * 4, &w, g,
+                                                  gs_all + ((size_t)f * S + u) * 3, NULL);
+          } else {
+            l1_all[f] = starlet_eval(N, W + (size_t)f * J * NN, B + (size_t)f * NN, lam_sc, lam_hf, &w);
+            memcpy(z_all + (size_t)f * NN, w.z, sizeof(real) * NN);
+          }
+        }
+        const int t = t0 + it;
+        const double lr = schedule ? (double)lr0 * pow(0.99, (double)t / 10.0) : (double)lr0;
+        const real bc1 = (real)(1.0 / (1.0 - pow(0.9, t + 1))), bc2 = (real)(1.0 / (1.0 - pow(0.999, t + 1)));
+#pragma omp for schedule(static)
+        for (int f = 0; f < F; ++f) {
+          double chi2 = 0.0;
+          for (int s = 0; s < S; ++s) chi2 += chi_all[(size_t)f * S + s];
+          loss_hist[(size_t)f * (n_iter + 1) + it] = (real)(0.5 * chi2 + l1_all[f]);
+          if (it == n_iter) continue;
+          real *Bf = B + (size_t)f * NN, *mf = mB + (size_t)f * NN, *sf = sB + (size_t)f * NN;
+          real *st = stars + (size_t)f * S * 4, *stm = stars_m + (size_t)f * S * 4, *sts = stars_s + (size_t)f * S * 4;
+          const real *zf = z_all + (size_t)f * NN;
+          for (size_t i = 0; i < NN; ++i) {
+            real g = R(0.);
+            for (int s = 0; s < S; ++s) g += gBs[((size_t)f * S + s) * NN + i];  /* the stars' shares in order */
+            adabelief_step(&Bf[i], &mf[i], &sf[i], g + zf[i], (real)lr, bc1, bc2);
+          }
           for (int s = 0; s < S; ++s)
             for (int q = 0; q < 3; ++q)
-              adabelief_step(&st[s * 4 + q], &stm[s * 4 + q], &sts[s * 4 + q], gs[s * 3 + q], (real)lr, bc1, bc2);
+              adabelief_step(&st[s * 4 + q], &stm[s * 4 + q], &sts[s * 4 + q], gs_all[((size_t)f * S + s) * 3 + q], (real)lr, bc1, bc2);
         }
       }
     }
-    work_free(&w);
-    free(gs);
+    if (ok) work_free(&w);
   }
+  free(T_all); free(gBs); free(z_all); free(gs_all); free(chi_all); free(l1_all);
   return fail ? -1 : 0;
 }
 
