@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs A) {
   if (tid == 0) {
     const unsigned int want = A.seq + 1u;
     __hip_atomic_store(peer_flags(A.xch[A.rank], A.cpad) + par * A.nchunks + c, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    int good = 1;
+    // once a wait has run out, every later call of this rank gives up at once: a broken exchange costs one time-out, not one per call
+    int good = (__hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) ? 1 : 0;
     for (int r = 0; r < A.world && good; ++r) {
       if (r == A.rank) continue;
       const unsigned int *fl = peer_flags(A.xch[r], A.cpad) + par * A.nchunks + c;
