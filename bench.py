@@ -123,6 +123,70 @@ def measure_traffic(timeout_s=150):
                      f'WRITE_SIZE {out["WRITE_SIZE"]:.0f} KiB per {ITERS_PER_STEP}-iteration launch')
 
 
+JOINT_PMC_ITERS = 30   # iterations of a --pmc-child-joint run (10 untimed + 20)
+
+
+def measure_joint_traffic(E, n, M, timeout_s=150):
+    """HBM traffic of ONE joint-fit iteration (every kernel of it: epoch kernel or phases, reduction + update, regulariser
+    chain) from the same two rocprofv3 --pmc passes as measure_traffic, on a child that runs JOINT_PMC_ITERS iterations.
+    LCMI_EVENT_SYNC=1: counter collection serialises the two streams, the update must wait for the chain by an event."""
+    exe = shutil.which('rocprofv3')
+    if not exe:
+        return None, 'rocprofv3 not found'
+    tot = {}
+    tmp = tempfile.mkdtemp(prefix='lcmi_pmcj_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp', LCMI_EVENT_SYNC='1')
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable,
+                   os.path.abspath(__file__), '--pmc-child-joint', f'{E},{n},{M}']
+            try:
+                subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=timeout_s, check=True)
+            except Exception as e:
+                return None, f'{counter} pass failed: {e!r}'
+            per_kernel = {}
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get('Counter_Name') != counter:
+                        continue
+                    k = r.get('Kernel_Name', '')
+                    c = per_kernel.setdefault(k, [0, 0.0])
+                    c[0] += 1
+                    c[1] += float(r['Counter_Value'])
+            # the kernels of the iterations (launched at least once per iteration), not those of the set-up
+            vals = [v for k, (c, v) in per_kernel.items() if c >= JOINT_PMC_ITERS and c % JOINT_PMC_ITERS == 0]
+            if not vals:
+                return None, f'no {counter} rows for the iteration kernels'
+            tot[counter] = sum(vals) / JOINT_PMC_ITERS
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    traffic = (2.0 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0
+    return traffic, (f'rocprofv3 --pmc passes inside this run, all kernels of one iteration: FETCH_SIZE {tot["FETCH_SIZE"]:.0f} KiB '
+                     f'(x2 on gfx950) + WRITE_SIZE {tot["WRITE_SIZE"]:.0f} KiB')
+
+
+def joint_pmc_child(spec):
+    """under rocprofv3 --pmc: JOINT_PMC_ITERS iterations of the joint workload, nothing timed"""
+    from lightcurver_amd import _lib
+    from lightcurver_amd.joint import JointFit
+    from lightcurver_amd.synthetic import make_roi_dataset
+    E, n, M = [int(v) for v in spec.split(',')]
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=104 if n == 64 else 105)
+    ctx = _lib.Context(0)
+    j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], 2, M, ctx)
+    p = dict(ds['truth'])
+    p['a'] = p['a'] * 0.9
+    j.set_params(**p)
+    W = j.propagate_noise()
+    j.set_loss(W=W, lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
+    j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
+    j.run_adabelief(JOINT_PMC_ITERS, init_learning_rate=1e-4, schedule_learning_rate=False)
+    ctx.synchronize()
+    j.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------------
@@ -159,6 +223,28 @@ def psf_step(b, stars0, ab):
     b.run_adabelief(ITERS_PER_STEP, **ab)
 
 
+def effective_cpus():
+    """Hardware threads this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands a
+    job a share of its host: os.cpu_count() says 256 there, the quota 16 - 256 OpenMP threads on 16 cores is what a barrier
+    or a dynamic schedule pays for dearly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path, parse in (('/sys/fs/cgroup/cpu.max', lambda t: t.split()),):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != 'max':
+                n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+        except Exception:
+            pass
+    try:   # cgroup v1
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0:
+            n = min(n, max(1, int(q / p + 0.5)))
+    except Exception:
+        pass
+    return max(n, 1)
+
+
 def cpu_baseline(ds, weight, b, stars0, ss, seconds_target=12.0):
     """oracle/psf_cpu.c (fp32 C + OpenMP over (frame, star) work units, the same algorithm as the HIP path; kind 'port') timed on the
     host cores on a bounded sample of the same C2 workload: all hardware threads, then one thread."""
@@ -173,7 +259,7 @@ def cpu_baseline(ds, weight, b, stars0, ss, seconds_target=12.0):
     mof = b.get_moffat()
     Tm = np.stack([om.moffat(N, ss, *[om.T(float(v)) for v in mof[f]]).numpy() for f in range(F)])
     W = b.get_weights()
-    threads = os.cpu_count() or 1
+    threads = effective_cpus()
     out = {}
     for label, thr, frames, iters in (('all', threads, F, 60), ('one', 1, min(F, 8), 20)):
         st = psf_cpu.PsfCpuState(ds['data'][:frames], weight[:frames], ss, Tm[:frames], W[:frames],
@@ -188,9 +274,9 @@ def cpu_baseline(ds, weight, b, stars0, ss, seconds_target=12.0):
         dt = time.perf_counter() - t0
         out[label] = dict(rate=frames * S * iters / dt, frames=frames, iters=iters, seconds=dt,
                           finite=bool(np.all(np.isfinite(hist))))
-    return dict(value=out['all']['rate'], unit='cutouts/sec', cores=threads, kind='port',
+    return dict(value=out['all']['rate'], unit='cutouts/sec', cores=threads, host_logical_cpus=os.cpu_count(), kind='port',
                 sample=f"{out['all']['frames']} frames x {S} stamps x {out['all']['iters']} AdaBelief iterations of the same "
-                       f"C2 data ({out['all']['seconds']:.1f} s), oracle/psf_cpu.c fp32 + OpenMP over (frame, star)",
+                       f"C2 data ({out['all']['seconds']:.1f} s), oracle/psf_cpu.c fp32 + OpenMP (whole frames per thread; (frame, star) units when there are more threads than frames)",
                 value_one_thread=out['one']['rate'],
                 sample_one_thread=f"{out['one']['frames']} frames x {S} stamps x {out['one']['iters']} iterations "
                                   f"({out['one']['seconds']:.1f} s)",
@@ -432,7 +518,11 @@ def main():
     ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc passes (roofline.traffic = null)')
     ap.add_argument('--no-sharded-joint', action='store_true', help='N > 1: skip the epoch-sharded C4 fit with RCCL')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--pmc-child-joint', default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child_joint:
+        joint_pmc_child(args.pmc_child_joint)
+        return
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
@@ -445,8 +535,12 @@ def main():
         sys.exit(2)
 
     traffic, traffic_source = None, 'not measured (--no-traffic, N > 1 or a profiler child)'
+    joint_traffic = {}
     if world == 1 and not args.no_traffic and not args.pmc_child and args.config == 'C2':
         traffic, traffic_source = measure_traffic()   # before this process touches the GPU
+        if not args.no_extra:
+            for key, spec in (('C4', (200, 64, 2)), ('C5 shard', (125, 128, 4))):
+                joint_traffic[key] = measure_joint_traffic(*spec)
 
     dist = None
     if world > 1:
@@ -555,6 +649,12 @@ def main():
                     extra.append(fn(ctx, **kw))
                 except Exception as e:
                     extra.append({'workload': kw.get('label', fn.__name__), 'error': repr(e)})
+            for w in extra:   # counter traffic of one iteration, measured before this process touched the GPU
+                for key, (tr, src) in joint_traffic.items():
+                    if w.get('workload', '').startswith(key + ':') or w.get('workload', '').startswith(key + ' ('):
+                        if 'roofline' in w and not (key == 'C4' and 'shard' in w['workload'][:10]):
+                            w['roofline']['traffic'] = tr
+                            w['roofline']['traffic_source'] = src
             if not args.no_cpu_baseline:   # the CPU path timed beside the joint fit too (north_star): attached to the C4 entry
                 try:
                     extra[0]['cpu_baseline'] = joint_cpu_oracle(n=64, M=2, seed=104)

@@ -1,4 +1,4 @@
-/* CPU restatement (plain C, fp32, OpenMP over (frame, star)) of the pixel-grid stage of the PSF fit.
+/* CPU restatement (plain C, fp32, OpenMP over frames or (frame, star) units) of the pixel-grid stage of the PSF fit.
  *
  * TEST / MEASUREMENT INFRASTRUCTURE ONLY (see oracle/__init__.py): this file is the "port" CPU baseline of
  * bench.py (cpu_baseline.kind = "port") and a second, independent checker of the HIP path in tests/.  The product
@@ -267,18 +267,57 @@ static void adabelief_step(real *p, real *m, real *s, real g, real lr, real bc1,
 
 /* n_iter AdaBelief iterations on B, a, x0, y0 of every frame (state in / out).  loss_hist[F][n_iter + 1]:
  * loss before each update, then the loss of the final parameters.  Returns 0, or -1 on allocation failure.
- * Parallel over (frame, star) for the convolution part and over frames for the starlet term and the update: an iteration
- * is F * (S + 1) independent work units, so a host with more hardware threads than frames (256 threads, 100 frames of C2)
- * is kept busy; three barriers per iteration. */
+ * With no more threads than frames every thread takes whole frames (no barrier).  With more threads than frames the work is
+ * split further: (frame, star) units for the convolution part, frames for the starlet term and the update - an iteration is
+ * F * (S + 1) independent units, three barriers per iteration.  Both forms add the stars' shares in the same order: same bits. */
 int psf_cpu_run(int F, int S, int n, int ss, const real *data, const real *wgt, const real *Tm, const real *W,
                 real *B, real *mB, real *sB, real *stars, real *stars_m, real *stars_s, real lam_sc,
                 real lam_hf, real lr0, int schedule, int t0, int n_iter, real *loss_hist, int n_threads) {
   const int N = n * ss, J = ilog2i(N);
   const size_t NN = (size_t)N * N, nn = (size_t)n * n;
   int fail = 0;
+  int threads = 1;
 #ifdef _OPENMP
   if (n_threads > 0) omp_set_num_threads(n_threads);
+  threads = omp_get_max_threads();
 #endif
+  if (threads <= F) {
+    /* no more threads than frames: every thread takes whole frames through all their iterations, no barrier at all */
+#pragma omp parallel
+    {
+      Work w;
+      real *gs = malloc(sizeof(real) * (size_t)S * 3);
+      const int ok = work_alloc(&w, N, n, J) && gs;
+      if (!ok) {
+#pragma omp atomic write
+        fail = 1;
+      } else {
+#pragma omp for schedule(dynamic, 1)
+        for (int f = 0; f < F; ++f) {
+          const real *df = data + (size_t)f * S * nn, *wf = wgt + (size_t)f * S * nn, *Tf = Tm + (size_t)f * NN;
+          const real *Wf = W + (size_t)f * J * NN;
+          real *Bf = B + (size_t)f * NN, *mf = mB + (size_t)f * NN, *sf = sB + (size_t)f * NN;
+          real *st = stars + (size_t)f * S * 4, *stm = stars_m + (size_t)f * S * 4, *sts = stars_s + (size_t)f * S * 4;
+          for (int it = 0; it <= n_iter; ++it) {
+            const real loss = frame_eval(S, n, ss, df, wf, Tf, Wf, Bf, st, lam_sc, lam_hf, &w, gs, NULL, NULL);
+            loss_hist[(size_t)f * (n_iter + 1) + it] = loss;
+            if (it == n_iter) break;
+            const int t = t0 + it;
+            const double lr = schedule ? (double)lr0 * pow(0.99, (double)t / 10.0) : (double)lr0;
+            const real bc1 = (real)(1.0 / (1.0 - pow(0.9, t + 1))), bc2 = (real)(1.0 / (1.0 - pow(0.999, t + 1)));
+            for (size_t i = 0; i < NN; ++i) adabelief_step(&Bf[i], &mf[i], &sf[i], w.gB[i] + w.z[i], (real)lr, bc1, bc2);
+            for (int s = 0; s < S; ++s)
+              for (int q = 0; q < 3; ++q)
+                adabelief_step(&st[s * 4 + q], &stm[s * 4 + q], &sts[s * 4 + q], gs[s * 3 + q], (real)lr, bc1, bc2);
+          }
+        }
+      }
+      if (ok) work_free(&w);
+      free(gs);
+    }
+    return fail ? -1 : 0;
+  }
+  /* more threads than frames: (frame, star) work units */
   real *T_all = malloc(sizeof(real) * F * NN), *gBs = malloc(sizeof(real) * (size_t)F * S * NN), *z_all = malloc(sizeof(real) * F * NN);
   real *gs_all = malloc(sizeof(real) * (size_t)F * S * 3);
   double *chi_all = malloc(sizeof(double) * (size_t)F * S), *l1_all = malloc(sizeof(double) * F);

@@ -92,3 +92,17 @@ def test_two_float64_implementations_agree_but_fp32_trajectories_drift():
         assert 1e-7 < d32 < 5e-3, d32                                     # drifts, but stays a small number
         assert H.rel_err(st32.stars[f][:, 0], pf['a'].numpy()) < 1e-4    # fluxes: north-star level
         assert np.abs(st32.stars[f][:, 1] - pf['x0'].numpy()).max() < 1e-4
+
+
+def test_frame_and_star_parallel_forms_of_the_c_port_give_the_same_bits():
+    """psf_cpu_run takes whole frames per thread while there are no more threads than frames and (frame, star) work
+    units beyond that (bench.py's cpu_baseline on a host with more cores than frames); both add the stars' shares in
+    the same order."""
+    n, ss, S, F, T = 16, 2, 4, 2, 12
+    out = []
+    for threads in (1, 2, 5):
+        ds, plist, Ws, st = _problem(n, ss, S, F, 77, jitter=0.1)
+        hist = st.run_adabelief(T, lr0=1e-4, schedule=True, threads=threads)
+        out.append((hist.copy(), st.B.copy(), st.stars.copy()))
+    for h, B, stars in out[1:]:
+        assert np.array_equal(h, out[0][0]) and np.array_equal(B, out[0][1]) and np.array_equal(stars, out[0][2])

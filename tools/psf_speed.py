@@ -3,6 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from lightcurver_amd import _lib
+if os.environ.get('LCMI_DBG_LIB'): _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ['LCMI_DBG_LIB'])
 from lightcurver_amd.psf_batch import PsfBatch
 from lightcurver_amd.synthetic import make_psf_dataset
 F, S, n, iters = [int(x) for x in sys.argv[1:5]]
