@@ -529,6 +529,12 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
       f2.A[nbch] = Ap(s);   f2.B[nbch] = T;     f2.C[nbch] = cplane;   // c_s = A_s T
       a1.A[nbch] = splane;  a1.B[nbch] = Ap(s); a1.C[nbch] = T;        // T' = S_s A_s
       a2.A[nbch] = At(s);   a2.B[nbch] = T;     a2.C[nbch] = zplane;   // Z_s = AT_s T'
+      // A_s and its transpose are banded with half-width 2 (2^s - 1): as the second operand the band follows the tile's
+      // columns, as the first its rows (LCMI_REG_DENSE=1: all K slices, the cross-check)
+      const int hw = 2 * ((1 << s) - 1), on = std::getenv("LCMI_REG_DENSE") ? 0 : 1;
+      f1.band[nbch] = a1.band[nbch] = on * 1;
+      f2.band[nbch] = a2.band[nbch] = on * 2;
+      f1.hw[nbch] = f2.hw[nbch] = a1.hw[nbch] = a2.hw[nbch] = hw;
       ++nbch;
     };
     if (l1_on)
@@ -1256,6 +1262,8 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
 
 int lc_joint_run_sharded(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg, lc_allreduce_fn allreduce, void *user) {
   if (!j || n_iter < 0 || !allreduce) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
+  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_run_sharded: not available on a batched star-photometry object");
   int rc = ensure_hist(j, j->iters_done + n_iter + 2);
   for (int it = 0; it < n_iter && !rc; ++it) {
     if ((rc = lc_joint_step_local(j))) break;

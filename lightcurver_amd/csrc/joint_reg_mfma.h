@@ -311,6 +311,10 @@ struct MmBatch {
   int nb;                        // products of this launch
   const float *A[12], *B[12];    // row-major N x N
   float *C[12];
+  // one operand is a cumulative smoothing operator, banded with half-width hw: band = 1: B[k][c] = 0 beyond |k - c| > hw (the
+  // k range follows the tile's columns); band = 2: A[r][k] = 0 beyond |k - r| > hw (it follows the tile's rows); 0: dense.
+  // The K loop then covers [lo - hw, lo + 64 + hw) only: 3 of 8 slices of 32 at the first scales of a 256 x 256 grid.
+  int band[12], hw[12];
 };
 constexpr int kMmThreads = 256, kMmKT = 32;
 // C[b] = A[b] B[b]; grid (N / 64, N / 64, nb)
@@ -347,19 +351,25 @@ __global__ __launch_bounds__(kMmThreads) void mreg_mm_kernel(MmBatch G) {
   mr_acc acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  fetch(0);
+  int kbeg = 0, kend = N;
+  if (G.band[bz]) {
+    const int lo = (G.band[bz] == 1) ? c0 : r0;
+    kbeg = max(lo - G.hw[bz], 0) / kMmKT * kMmKT;
+    kend = min((lo + 64 + G.hw[bz] + kMmKT - 1) / kMmKT * kMmKT, N);
+  }
+  fetch(kbeg);
   put(0);
   __syncthreads();
   int buf = 0;
-  for (int k0 = 0; k0 < N; k0 += kMmKT, buf ^= 1) {
-    if (k0 + kMmKT < N) fetch(k0 + kMmKT);   // next slice in flight while this one is multiplied
+  for (int k0 = kbeg; k0 < kend; k0 += kMmKT, buf ^= 1) {
+    if (k0 + kMmKT < kend) fetch(k0 + kMmKT);   // next slice in flight while this one is multiplied
     // lane half h feeds k = 2 s + h of every step: a = A[row][k], b = B[k][column]
 #pragma unroll
     for (int s2 = 0; s2 < kMmKT / 2; ++s2) {
       const int k = 2 * s2 + h;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][wr + i][k], Bs[buf][k][wc + i], acc, 0, 0, 0);
     }
-    if (k0 + kMmKT < N) put(buf ^ 1);
+    if (k0 + kMmKT < kend) put(buf ^ 1);
     __syncthreads();
   }
   float *C = G.C[bz];
@@ -486,8 +496,19 @@ __global__ void mreg_regs2_kernel(int J, int has_l1, int has_pts, int nblocks, i
   const int lane = threadIdx.x;
   {  // values: l1 over the scales, positivity, point-source term (per-block partials; lanes stride, fixed combine order)
     float a = 0.f, b = 0.f, c = 0.f;
-    if (has_l1)
-      for (int i = lane; i < J * nblocks; i += 64) a += l1b[i];
+    if (has_l1) {  // (four running sums per lane: the loads of a lane do not wait for each other's additions)
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      const int n = J * nblocks;
+      int i = lane;
+      for (; i + 192 < n; i += 256) {
+        a0 += l1b[i];
+        a1 += l1b[i + 64];
+        a2 += l1b[i + 128];
+        a3 += l1b[i + 192];
+      }
+      for (; i < n; i += 64) a0 += l1b[i];
+      a = (a0 + a1) + (a2 + a3);
+    }
     for (int i = lane; i < nblocks; i += 64) b += posb[i];
     if (has_pts)
       for (int i = lane; i < nblocks; i += 64) c += l1b[(size_t)(J + 1) * nblocks + i];

@@ -104,3 +104,37 @@ def test_two_hip_ranks_equal_the_unsharded_fit(ctx, tmp_path):
         assert np.abs(g['p_' + k] - pf[k]).max() <= 2e-5, k
     assert np.abs(g['p_h'] - pf['h']).max() <= 0.02 * T * 1e-3 + 1e-7   # a sign flip of a ~0 gradient moves a pixel by <= 2 lr
     assert np.median(np.abs(g['p_h'] - pf['h'])) <= 1e-6
+
+
+def test_sharded_loop_in_the_library_reports_a_failing_collective(ctx):
+    """lc_joint_run_sharded drives step_local / all-reduce callback / step_update from C++; with an identity callback it is
+    the unsharded fit bit for bit, and a callback that fails stops the loop with an error instead of continuing on a block
+    that was not reduced."""
+    from lightcurver_amd import _lib
+    from lightcurver_amd.joint import JointFit
+    E, M, n, ss, T = 5, 2, 32, 2, 8
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=4243)
+    p = dict(ds['truth'])
+    p['a'] = np.asarray(p['a']) * 0.9
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h']
+    fits = []
+    for _ in range(3):
+        j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
+        j.set_params(**p)
+        j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_flux_uniformity=0.5)
+        j.set_free(free)
+        fits.append(j)
+    for _ in range(T):
+        fits[0].step_local()
+        fits[0].step_update(init_learning_rate=1e-3)
+    calls = []
+    ident = _lib.ALLREDUCE_FN(lambda user, buf, count, stream: calls.append(count) or 0)
+    fits[1].run_sharded(T, ident, None, init_learning_rate=1e-3)
+    assert len(calls) == T and calls[0] == n * ss * n * ss + 4 * M + 2
+    np.testing.assert_array_equal(fits[1].loss_history(), fits[0].loss_history())
+    np.testing.assert_array_equal(fits[1].get_params()['h'], fits[0].get_params()['h'])
+    bad = _lib.ALLREDUCE_FN(lambda user, buf, count, stream: 1)
+    with pytest.raises(_lib.LcError):
+        fits[2].run_sharded(T, bad, None, init_learning_rate=1e-3)
+    for j in fits:
+        j.close()

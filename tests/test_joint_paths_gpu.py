@@ -76,6 +76,21 @@ def test_matrix_core_regulariser_equals_the_cascade(ctx, E, n, M):
     assert a[0][-1] < a[0][0]
 
 
+@pytest.mark.parametrize('E,n,M', [(8, 64, 2), (3, 128, 4)])
+def test_regulariser_chain_forms_agree(ctx, E, n, M):
+    """The matrix-core regulariser of the large grids exists as batched tiled products over the scales (default; the K loop of
+    a tile only covers the band of the cumulative smoothing operator), the same with all K slices (LCMI_REG_DENSE=1: the
+    skipped slices multiply by zeros, so the bits are the same) and as the block-column kernels of round 2
+    (LCMI_REG_MFMA_V1=1: another summation order)."""
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=104)
+    a = _fit(ctx, ds, M, 20)
+    b = _fit(ctx, ds, M, 20, env={'LCMI_REG_DENSE': '1'})
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1]['h'], b[1]['h'])
+    c = _fit(ctx, ds, M, 20, env={'LCMI_REG_MFMA_V1': '1'})
+    _compare(a, c, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 20, 1e-4)
+
+
 @pytest.mark.parametrize('E,n,M', [(8, 64, 2), (5, 32, 2), (3, 128, 4)])
 def test_fused_reduction_and_update_equals_the_two_kernels(ctx, E, n, M):
     ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=104)
@@ -212,3 +227,45 @@ def test_c5_at_its_full_epoch_count(ctx):
     hf, pf = _fit(ctx, ds, M, 1)
     for k in ('dx', 'dy', 'mean'):
         assert np.max(np.abs(ps[k] - pf[k][:125])) < 1e-6 * (np.max(np.abs(pf[k])) + 1e-3), k
+
+
+@pytest.mark.parametrize('n,E,free', [(32, 5, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h')), (64, 4, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h')),
+                                      (16, 6, ('a', 'dx', 'dy'))])
+def test_device_resident_parameter_history(ctx, n, E, free):
+    """return_param_history (star_photometry.py:119, roi_modelling.py:331): the update kernels - single-workgroup, multi-block,
+    fused reduction + update, and the persistent point-source loop - store the free blocks after every update in a
+    device-resident history; its rows equal what get_params() returns after each iteration of a one-iteration-per-call
+    drive of the same fit."""
+    from lightcurver_amd.joint import JointFit
+    M, T = 2, 9
+    with_h = 'h' in free
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=104, with_background=with_h)
+    rows = []
+    for history in (True, False):
+        j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], 2, M, ctx)
+        p = {k: np.asarray(v, dtype=np.float64) for k, v in ds['truth'].items()}
+        p['a'] = 0.9 * p['a']
+        j.set_params(**p)
+        if with_h:
+            j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
+        else:
+            j.set_loss(lam_positivity_ps=2.0)
+        j.set_free(list(free))
+        cfg = dict(init_learning_rate=1e-4, schedule_learning_rate=False)
+        if history:
+            P = j.param_history_begin(T)
+            assert P == sum(j.sizes[k] for k in free)
+            j.run_adabelief(T - 4, **cfg)
+            j.run_adabelief(4, **cfg)          # a second call appends
+            rows.append(j.param_history())
+            j.param_history_end()
+        else:
+            ref = []
+            for _ in range(T):
+                j.run_adabelief(1, **cfg)
+                got = j.get_params()
+                ref.append(np.concatenate([got[k] for k in ('a', 'c_x', 'c_y', 'dx', 'dy', 'alpha', 'h', 'mean') if k in free]))
+            rows.append(np.asarray(ref))
+        j.close()
+    assert rows[0].shape == rows[1].shape and rows[0].shape[0] == T
+    np.testing.assert_array_equal(rows[0], rows[1])

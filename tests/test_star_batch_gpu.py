@@ -13,10 +13,10 @@ from lightcurver_amd.synthetic import make_roi_dataset
 pytestmark = pytest.mark.gpu
 
 
-def _stars(G, E_list, n, seed):
+def _stars(G, E_list, n, seed, M=1):
     out = []
     for g in range(G):
-        ds = make_roi_dataset(E=E_list[g], M=1, n=n, ss=2, seed=seed + g, with_background=False)
+        ds = make_roi_dataset(E=E_list[g], M=M, n=n, ss=2, seed=seed + g, with_background=False)
         out.append(ds)
     return out
 
@@ -24,32 +24,34 @@ def _stars(G, E_list, n, seed):
 def _start(ds, rng):
     E = ds['data'].shape[0]
     p = {k: np.array(v, dtype=np.float64) for k, v in ds['truth'].items()}
-    p['a'] = p['a'] * rng.uniform(0.8, 1.2, E)
-    p['c_x'] = p['c_x'] + rng.normal(0, 0.2, 1)
-    p['c_y'] = p['c_y'] + rng.normal(0, 0.2, 1)
+    M = p['c_x'].size
+    p['a'] = p['a'] * rng.uniform(0.8, 1.2, E * M)
+    p['c_x'] = p['c_x'] + rng.normal(0, 0.2, M)
+    p['c_y'] = p['c_y'] + rng.normal(0, 0.2, M)
     p['h'] = np.zeros_like(p['h'])
     return p
 
 
-@pytest.mark.parametrize('n,E_list,free', [(16, [5, 3, 7, 1], ('a', 'c_x', 'c_y', 'dx', 'dy')),
-                                           (32, [6, 4, 9], ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean'))])
-def test_every_star_of_a_batch_equals_its_own_fit(ctx, n, E_list, free):
+@pytest.mark.parametrize('n,E_list,free,M', [(16, [5, 3, 7, 1], ('a', 'c_x', 'c_y', 'dx', 'dy'), 1),
+                                             (32, [6, 4, 9], ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean'), 1),
+                                             (16, [4, 6], ('a', 'c_x', 'c_y', 'dx', 'dy'), 2)])
+def test_every_star_of_a_batch_equals_its_own_fit(ctx, n, E_list, free, M):
     from lightcurver_amd.joint import JointFit, StarPhotometryBatch
     G, T = len(E_list), 60
-    stars = _stars(G, E_list, n, 400 + n)
+    stars = _stars(G, E_list, n, 400 + n, M)
     rng = np.random.default_rng(3)
     starts = [_start(ds, rng) for ds in stars]
     cfg = dict(init_learning_rate=1e-3, schedule_learning_rate=True)
     single = []
     for ds, p in zip(stars, starts):
-        j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], 2, 1, ctx)
+        j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], 2, M, ctx)
         j.set_params(**p)
         j.set_loss(lam_positivity_ps=2.0, lam_flux_uniformity=0.5)
         j.set_free(list(free))
         j.run_adabelief(T, **cfg)
         single.append((j.get_params(), j.loss_history(), j.model(), j.fisher_flux_sigma()))
         j.close()
-    b = StarPhotometryBatch([(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf']) for ds in stars], 2, 1, ctx)
+    b = StarPhotometryBatch([(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf']) for ds in stars], 2, M, ctx)
     cat = {k: np.concatenate([p[k] for p in starts]) for k in ('a', 'c_x', 'c_y', 'dx', 'dy', 'alpha', 'mean')}
     b.set_params(h=starts[0]['h'], **cat)
     b.set_loss(lam_positivity_ps=2.0, lam_flux_uniformity=0.5)
@@ -65,7 +67,7 @@ def test_every_star_of_a_batch_equals_its_own_fit(ctx, n, E_list, free):
         assert np.array_equal(hist[g], hs), g
         e0, e1 = b.starts[g], b.starts[g + 1]
         assert np.array_equal(model[e0:e1], ms) and np.array_equal(chi2_e[e0:e1], cs)
-        assert np.array_equal(sig[e0:e1], ss_)
+        assert np.array_equal(sig[e0 * M:e1 * M], ss_)
         assert hs[-1] < hs[0]
     b.close()
 
