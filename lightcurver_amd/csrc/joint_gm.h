@@ -374,9 +374,14 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_groups_kernel(const J
   A.bc1 = bc1;
   A.bc2 = bc2;
   __shared__ float scl[4 * kMaxSources + 2];  // (the sums also go to LDS: the rules below read them without a trip through L2)
+  // (same rules in another order of issue: the fluxes with their moments are requested first, the shifts and sky levels - which
+  //  need nothing from the reduction - step while those loads and the reduction's are in flight)
+  FluxPre pre;
+  gm_flux_preload(A, pre);
+  gm_small_blocks(A, 0, lr, bc1, bc2, nullptr, 2);
   reduce_scalars(A.E, A.M, 0, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.a_ref, A.shared_w, lanes, threadIdx.x, scl);
   __syncthreads();
-  gm_small_blocks(A, 0, lr, bc1, bc2, scl, 3);
+  gm_small_blocks(A, 0, lr, bc1, bc2, scl, 1, &pre);
 }
 
 // The reduction over the epochs and the update in ONE launch (the device loop of a single GPU, where nothing has to

@@ -303,6 +303,43 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     }
   }
 
+  // ---- tap tables of every star of the frame: once before the first iteration, then right behind the star update of every
+  //      iteration - in the two-workgroup form between the hand-off stores and their drain, whose latency they hide ----------
+  auto compute_taps = [&](int tid) {
+    for (int e = tid; e < S * 2 * NTP; e += NTHR) {
+      const int s = e / (2 * NTP), ax = (e / NTP) & 1, k = e % NTP - 1;  // k = -1, NT, NT + 1: the zero padding
+      float tap = 0.f, dtap = 0.f;
+      int bq = 0;
+      const float c_off = (N % 2 == 0) ? 0.5f : 0.0f;  // (N-1)/2 - (N-1)//2
+      // a star further than N/4 high-res pixels from the stamp centre is a broken fit: pin the kernel there
+      const float delta = fminf(fmaxf(SS * SP[s * 4 + 1 + ax], -(float)(N / 4)), (float)(N / 4)) + c_off;
+      if (k >= 0 && k < NT) tap_entry<SS, NT>(delta, k, tap, dtap, bq);
+      TAPS[(s * 4 + 2 * ax) * NTP + k] = tap;
+      TAPS[(s * 4 + 2 * ax + 1) * NTP + k] = dtap;
+      if (k >= 0 && k < NT) TAPP[(s * 2 + ax) * NT + k] = (lc_v2f){tap, dtap};
+      if (k == 0) BQ[s * 2 + ax] = bq;
+    }
+  };
+  // AdaBelief step of a, x0, y0 of every star (threads tid < 3 S) and the tap tables of the next iteration.  Needs the
+  // complete star gradients (SGR) and this iteration's schedule (SCAL); every thread of the workgroup calls (barrier inside).
+  auto update_stars_and_taps = [&](int tid) {
+#pragma clang fp contract(off)
+    if (tid < S * 3) {
+      const float lr = SCAL[0], bc1 = SCAL[1], bc2 = SCAL[2];
+      const float b1 = A.ab.b1, b2 = A.ab.b2, eps = A.ab.eps, eps_root = A.ab.eps_root;
+      const int s = tid / 3, q = tid % 3;  // a, x0, y0
+      const float g = SGR[s * 5 + 1 + q];
+      const float mn = b1 * SM[s * 4 + q] + (1.f - b1) * g;
+      const float dg = g - mn;
+      const float sn = b2 * SV[s * 4 + q] + (1.f - b2) * dg * dg + eps_root;
+      SM[s * 4 + q] = mn;
+      SV[s * 4 + q] = sn;
+      SP[s * 4 + q] -= lr * (mn * bc1) / (sqrtf(sn * bc2) + eps);
+    }
+    __syncthreads();
+    compute_taps(tid);
+  };
+  if (conv_role) compute_taps(tid0);  // (visible behind the barrier that opens the first group of stars)
   // (measured and left out: s_setprio 1 for the second-dispatched half of the workgroup - MI355X_MICROARCH.md, two waves per
   //  SIMD - C2 16.2 us per iteration with and without, C3 shard 86.8 / 86.9)
   for (int it = 0; it < A.n_iter; ++it) {
@@ -349,21 +386,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       }
     }
     if (tid < S * 5) SGR[tid] = 0.f;
-
-    // ---- tap tables of every star of the frame (once per iteration) ----------------------------
-    for (int e = tid; e < S * 2 * NTP; e += NTHR) {
-      const int s = e / (2 * NTP), ax = (e / NTP) & 1, k = e % NTP - 1;  // k = -1, NT, NT + 1: the zero padding
-      float tap = 0.f, dtap = 0.f;
-      int bq = 0;
-      const float c_off = (N % 2 == 0) ? 0.5f : 0.0f;  // (N-1)/2 - (N-1)//2
-      // a star further than N/4 high-res pixels from the stamp centre is a broken fit: pin the kernel there
-      const float delta = fminf(fmaxf(SS * SP[s * 4 + 1 + ax], -(float)(N / 4)), (float)(N / 4)) + c_off;
-      if (k >= 0 && k < NT) tap_entry<SS, NT>(delta, k, tap, dtap, bq);
-      TAPS[(s * 4 + 2 * ax) * NTP + k] = tap;
-      TAPS[(s * 4 + 2 * ax + 1) * NTP + k] = dtap;
-      if (k >= 0 && k < NT) TAPP[(s * 2 + ax) * NT + k] = (lc_v2f){tap, dtap};
-      if (k == 0) BQ[s * 2 + ax] = bq;
-    }
+    // (the tap tables of this iteration were made at the end of the previous one, behind the star update: compute_taps)
 
     for (int g0 = 0; g0 < S; g0 += SG) {
       __syncthreads();  // T and taps visible; previous group's P5 (reads V) done before P2 rewrites R
@@ -927,6 +950,8 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         store_sc1_x4(mine + poff + 4 * q, v);
       }
       if (tid == 0 && role == 1) store_sc1_f(mine + N * N, tl1);
+      // role 0: the stars' step and the next tap tables need nothing from the partner: done while the stores drain
+      if (role == 0 && A.mode == 1) update_stars_and_taps(tid);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       LC_STAMP(45);
@@ -1032,16 +1057,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         mp[q] = m;
         sp[q] = s;
       }
-      if (tid < S * 3 && conv_role) {
-        const int s = tid / 3, q = tid % 3;  // a, x0, y0
-        const float g = SGR[s * 5 + 1 + q];
-        const float mn = b1 * SM[s * 4 + q] + (1.f - b1) * g;
-        const float dg = g - mn;
-        const float sn = b2 * SV[s * 4 + q] + (1.f - b2) * dg * dg + eps_root;
-        SM[s * 4 + q] = mn;
-        SV[s * 4 + q] = sn;
-        SP[s * 4 + q] -= lr * (mn * bc1) / (sqrtf(sn * bc2) + eps);
-      }
+      if constexpr (!SPLIT) update_stars_and_taps(tid);  // (the two-workgroup form did this beside its hand-off)
     }
     __syncthreads();
     LC_STAMP(43);
