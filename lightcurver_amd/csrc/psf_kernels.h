@@ -405,6 +405,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           const int bqx = BQ[s * 2 + 0], bqy = BQ[s * 2 + 1];
           const float amp = SP[s * 4 + 0], sky = SP[s * 4 + 3];
           // data / weights of the task's pixels: requested now, used after the row pass
+          // (measured and left out: requesting them one task ahead - 8 more registers in flight, 5 spilled: 16.6 against 15.8 us)
           constexpr int NI3 = (JB * (n / LC) + 63) / 64;
           float dpre[NI3][LC], wpre[NI3][LC];
 #pragma unroll
