@@ -527,6 +527,12 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
+    # stdout carries ONE line, the JSON of rank 0: libraries that chat on file descriptor 1 (gloo's "[Gloo] Rank 0 is connected
+    # to ..." from C++) are sent to stderr for the rest of the run; the line itself is written to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -671,7 +677,7 @@ def main():
                 out['cpu_baseline'] = cpu_baseline(ds, weight, b, stars0, ss)
             except Exception as e:  # the bench line must still be printed
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()
