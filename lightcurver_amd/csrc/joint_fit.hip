@@ -996,8 +996,10 @@ int lc_joint_set_param(lc_joint *j, int which, const float *values, int count) {
         break;
       }
   }
-  if (j->G > 0 && which == LC_P_H && j->h_nonzero)
+  if (j->G > 0 && which == LC_P_H && j->h_nonzero) {
+    j->h_nonzero = false;  // (nothing was stored)
     LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "batched star photometry has no background: h must stay zero");
+  }
   if (j->G > 0 && which == LC_P_A) {  // one reference per star and source: the mean over that star's epochs
     std::vector<float> ref((size_t)j->G * kMaxSources, 0.f);
     for (int g = 0; g < j->G; ++g)
@@ -1025,6 +1027,7 @@ int lc_joint_set_param(lc_joint *j, int which, const float *values, int count) {
 int lc_joint_set_flux_reference(lc_joint *j, const float *ref, int count) {
   if (!j || !ref) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
+  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_set_flux_reference: a batched object keeps one reference per star (set with the fluxes)");
   if (count != j->M) LC_FAIL(j->ctx, LC_ERR_INVALID, "lc_joint_set_flux_reference: one reference flux per point source");
   float r[kMaxSources] = {};
   for (int i = 0; i < count; ++i) r[i] = ref[i];
@@ -1033,6 +1036,7 @@ int lc_joint_set_flux_reference(lc_joint *j, const float *ref, int count) {
 int lc_joint_get_flux_reference(lc_joint *j, float *ref, int count) {
   if (!j || !ref) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
+  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_get_flux_reference: a batched object keeps one reference per star");
   if (count != j->M) LC_FAIL(j->ctx, LC_ERR_INVALID, "lc_joint_get_flux_reference: one reference flux per point source");
   return d2h(j, ref, j->a_ref, (size_t)count * sizeof(float));
 }
