@@ -457,18 +457,38 @@ def sharded_joint_fit(ctx, rank, world, iters=500, transport='collective'):
     E, n, M, ss = 200, 64, 2, 2
     ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=104)  # same seed on every rank: identical full problem
     lo, hi = shard_epochs(E, world, rank)
-    j = JointFit(ds['data'][lo:hi], ds['noisemap'][lo:hi].astype(np.float64) ** 2, ds['psf'][lo:hi], ss, M, ctx)
-    p = dict(ds['truth'])
-    p['a'] = (np.asarray(p['a']).reshape(E, M) * 0.9)[lo:hi].reshape(-1)
-    for k in ('dx', 'dy', 'alpha', 'mean'):
-        p[k] = np.asarray(p[k])[lo:hi]
-    j.set_params(**p)
-    j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
-    j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
+
+    def all_ranks(step, fn):
+        """Runs fn on this rank, then lets the ranks agree (host-side group): a failure anywhere raises everywhere, so
+        that no rank walks into a collective or a barrier the failed one never reaches."""
+        err, out = None, None
+        try:
+            out = fn()
+        except Exception as e:
+            err = repr(e)
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        bad = [f'rank {r}: {e}' for r, e in enumerate(errs) if e]
+        if bad:
+            raise RuntimeError(f'{step}: ' + '; '.join(bad))
+        return out
+
+    def make_fit():
+        j = JointFit(ds['data'][lo:hi], ds['noisemap'][lo:hi].astype(np.float64) ** 2, ds['psf'][lo:hi], ss, M, ctx)
+        p = dict(ds['truth'])
+        p['a'] = (np.asarray(p['a']).reshape(E, M) * 0.9)[lo:hi].reshape(-1)
+        for k in ('dx', 'dy', 'alpha', 'mean'):
+            p[k] = np.asarray(p[k])[lo:hi]
+        j.set_params(**p)
+        j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
+        j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
+        return j
+
+    j = all_ranks('set-up of the local fit', make_fit)
     peer = None
     if transport == 'peer':
         group = None
-        peer = PeerGroup(j)                 # IPC handles travel over the default (gloo) group
+        peer = PeerGroup(j)                 # IPC handles travel over the default (gloo) group; fails on every rank or on none
     elif os.environ.get('LCMI_BENCH_DEVICE') is not None:
         # one-GPU rehearsal (every rank on the same device): RCCL refuses two ranks on one GPU, so the shared block
         # is staged through the host over the gloo group
@@ -478,13 +498,14 @@ def sharded_joint_fit(ctx, rank, world, iters=500, transport='collective'):
         group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=180))
     opt = ShardedJointOptimizer(j, group, peer=peer)
     ab = dict(init_learning_rate=1e-4, schedule_learning_rate=False)
-    opt.run(10, **ab)
-    ctx.synchronize()
-    dist.barrier()
+
+    def run_synced(n):
+        opt.run(n, **ab)
+        ctx.synchronize()
+
+    all_ranks('first iterations', lambda: run_synced(10))
     t0 = time.perf_counter()
-    opt.run(iters, **ab)
-    ctx.synchronize()
-    dist.barrier()
+    all_ranks('timed iterations', lambda: run_synced(iters))   # the agreement doubles as the closing barrier
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -553,7 +574,9 @@ def main():
         import torch.distributed as dist
         # frames shard with no data-path collective: this host-side (gloo) group only carries the barriers and the
         # max-over-ranks of the timing; the sharded joint fit makes its own nccl (= RCCL) group
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        import datetime
+        # bounded: a rank that died makes the others raise after five minutes instead of waiting for half an hour
+        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
 
     from lightcurver_amd import _lib
     # rehearsal of the multi-rank path on a one-GPU box: LCMI_BENCH_DEVICE=0 puts every rank on that device

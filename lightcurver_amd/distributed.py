@@ -55,16 +55,36 @@ class PeerGroup:
         self.fit = local_fit
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         _, count = local_fit.shared_buffer()
-        h = C.c_void_p()
-        local_fit.ctx.check(self._l.lc_peer_group_create(local_fit.ctx.h, count, self.rank, self.world, C.byref(h)), 'lc_peer_group_create')
-        self.h = h
-        mine = C.create_string_buffer(_lib.IPC_HANDLE_BYTES)
-        local_fit.ctx.check(self._l.lc_peer_group_export(self.h, mine, _lib.IPC_HANDLE_BYTES), 'lc_peer_group_export')
+        # a rank whose step fails still takes part in the exchanges that follow, so that every rank raises instead of one
+        # raising and the others waiting for it in a collective
+        self.h, err, raw = None, None, b''
+        try:
+            h = C.c_void_p()
+            local_fit.ctx.check(self._l.lc_peer_group_create(local_fit.ctx.h, count, self.rank, self.world, C.byref(h)), 'lc_peer_group_create')
+            self.h = h
+            mine = C.create_string_buffer(_lib.IPC_HANDLE_BYTES)
+            local_fit.ctx.check(self._l.lc_peer_group_export(self.h, mine, _lib.IPC_HANDLE_BYTES), 'lc_peer_group_export')
+            raw = bytes(mine.raw)
+        except Exception as e:
+            err = repr(e)
         parts = [None] * self.world
-        dist.all_gather_object(parts, bytes(mine.raw), group=group)
-        allh = C.create_string_buffer(b''.join(parts), _lib.IPC_HANDLE_BYTES * self.world)
-        local_fit.ctx.check(self._l.lc_peer_group_connect(self.h, allh, _lib.IPC_HANDLE_BYTES), 'lc_peer_group_connect')
-        dist.barrier(group=group)   # every rank has mapped every peer before anyone publishes
+        dist.all_gather_object(parts, (err, raw), group=group)
+        self._raise_if_any([p[0] for p in parts], 'exchange buffer')
+        err = None
+        try:
+            allh = C.create_string_buffer(b''.join(p[1] for p in parts), _lib.IPC_HANDLE_BYTES * self.world)
+            local_fit.ctx.check(self._l.lc_peer_group_connect(self.h, allh, _lib.IPC_HANDLE_BYTES), 'lc_peer_group_connect')
+        except Exception as e:
+            err = repr(e)
+        parts = [None] * self.world
+        dist.all_gather_object(parts, err, group=group)   # also the barrier: every rank has mapped every peer before anyone publishes
+        self._raise_if_any(parts, 'mapping the peers')
+
+    def _raise_if_any(self, errors, what):
+        bad = [(r, e) for r, e in enumerate(errors) if e]
+        if bad:
+            self.close()
+            raise RuntimeError(f'peer group ({what}): ' + '; '.join(f'rank {r}: {e}' for r, e in bad))
 
     def callback(self):
         """(function pointer, user pointer) for lc_joint_run_sharded: the library's own lc_peer_allreduce - no Python in the loop."""

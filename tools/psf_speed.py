@@ -18,4 +18,4 @@ b.set_grid(None); b.propagate_noise(); b.set_regularization(None, 1.0, 1.0)
 b.run_adabelief(10, init_learning_rate=1e-4); ctx.synchronize()
 ctx.timer_start(); b.run_adabelief(iters, init_learning_rate=1e-4); ms = ctx.timer_stop()
 h = b.loss_history()
-print(f'F={F} S={S} n={n}: {ms / iters * 1e3:.1f} us/iter, {F * S * iters / (ms * 1e-3):.3e} cutouts/s, loss finite {np.isfinite(h).all()}, single_wg={os.environ.get("LCMI_PSF_SINGLE_WG")}')
+print(f'F={F} S={S} n={n}: {ms / iters * 1e3:.1f} us/iter, {F * S * iters / (ms * 1e-3):.3e} cutouts/s, loss finite {np.isfinite(h).all()} last {float(np.asarray(h)[..., -1].sum())!r}, single_wg={os.environ.get("LCMI_PSF_SINGLE_WG")}')
