@@ -36,6 +36,19 @@ def _initial_positions(data, masks, method):
     return np.clip(x0, -lim, lim), np.clip(y0, -lim, lim)
 
 
+def _fit_size(n, ss):
+    """The stamp size the device fits an n x n stamp at: n itself when a kernel is instantiated for it, otherwise the next
+    instantiated size of the same parity (the stamp is embedded centrally, psf_routines.build_psf_batch)."""
+    l = _lib.lib()
+    if l.lc_psf_supported(int(n), int(ss)):
+        return int(n)
+    for m in range(int(n) + 2, 129, 2):
+        if l.lc_psf_supported(m, int(ss)):
+            return m
+    raise _lib.LcError(f'no PSF kernel for {n}x{n} stamps at subsampling {ss} (instantiated: 16 at ss = 1; 16, 24, 32, 64 at '
+                       f'ss = 2; smaller even sizes are fitted embedded in the next of these)')
+
+
 def build_psf_batch(images, noisemaps, subsampling_factor, masks=None, n_iter_analytic=40,
                     n_iter_adabelief=2000, guess_method_star_position='barycenter', guess_fwhm_pixels=3.,
                     field_distortion=False, stamp_coordinates=None, regularization_strength_scales=1.,
@@ -87,6 +100,22 @@ def build_psf_batch(images, noisemaps, subsampling_factor, masks=None, n_iter_an
         moffat[f] = (f0, f0, 0.0, 2.5)
 
     ctx = ctx or _lib.default_context(device)
+    # Stamp sizes without a kernel of their own (config.yaml:205 ``stamp_size_stars`` is a free integer) are fitted
+    # EMBEDDED in the next instantiated size: the stamps sit in the centre of a larger frame whose extra ring carries zero
+    # weight ("absent" to the fit), the pixel grid is fitted on the larger frame and every output is cut back to the
+    # caller's size (PSFs renormalised to unit sum).  Same centre, so positions and widths mean the same.
+    n_fit = _fit_size(n, ss)
+    pad = (n_fit - n) // 2
+    if pad:
+        if field_distortion:
+            raise _lib.LcError(f'build_psf(field_distortion=True): no kernel for {n}x{n} stamps at subsampling {ss} '
+                               f'(the embedded form covers the plain fit only)')
+        big = np.zeros((F, S, n_fit, n_fit), np.float64)
+        big[..., pad:pad + n, pad:pad + n] = data
+        data = big
+        big = np.zeros((F, S, n_fit, n_fit), np.float64)
+        big[..., pad:pad + n, pad:pad + n] = weight
+        weight = big
     if field_distortion:
         if stamp_coordinates is None:
             raise ValueError('field_distortion=True needs stamp_coordinates (rescaled frame positions of the stamps)')
@@ -114,6 +143,14 @@ def build_psf_batch(images, noisemaps, subsampling_factor, masks=None, n_iter_an
         grid = b.get_grid()
     finally:
         b.close()
+    if pad:
+        P = pad * ss
+        res = dict(res)
+        res['residuals'] = res['residuals'][..., pad:pad + n, pad:pad + n]
+        for key in ('narrow_psf', 'full_psf'):
+            cut = res[key][:, P:P + N, P:P + N]
+            res[key] = cut / cut.sum(axis=(-1, -2), keepdims=True)
+        grid = np.ascontiguousarray(grid[:, P:P + N, P:P + N])
 
     out = []
     for f in range(F):
