@@ -443,6 +443,60 @@ def c3_shard_workload(ctx, iters=200):
             'loss_finite': bool(np.all(np.isfinite(hist)))}
 
 
+def star_photometry_workload(ctx, iters=2000, with_cpu=True):
+    """The reference's star photometry (star_photometry.py:257-326: 30 reference stars, each a 2000-iteration joint fit of
+    one point source over its epochs, background fixed at zero) as one batched device fit: 30 stars x 100 epochs x 32x32,
+    fluxes, star position and per-epoch shifts free.  CPU beside it: oracle/joint_ps_cpu.c (fp32 C + OpenMP over epochs, the
+    same separable algorithm) on one star's 100 epochs."""
+    from lightcurver_amd.joint import StarPhotometryBatch
+    from lightcurver_amd.synthetic import make_roi_dataset
+    G, E, n, ss = 30, 100, 32, 2
+    base = make_roi_dataset(E=E, M=1, n=n, ss=ss, seed=106, with_background=False)
+    sig2 = base['noisemap'].astype(np.float64) ** 2
+    b = StarPhotometryBatch([(base['data'], sig2, base['psf'])] * G, ss, 1, ctx)
+    a0 = np.asarray(base['truth']['a'], np.float64) * 0.9
+    b.set_params(a=np.tile(a0, G), c_x=np.zeros(G), c_y=np.zeros(G), dx=np.zeros(G * E), dy=np.zeros(G * E),
+                 alpha=np.zeros(G * E), mean=np.zeros(G * E))
+    b.set_loss()
+    b.set_free(['a', 'c_x', 'c_y', 'dx', 'dy'])
+    ab = dict(init_learning_rate=1e-3, schedule_learning_rate=True)
+    b.run_adabelief(5, **ab)
+    ctx.synchronize()
+    ctx.timer_start()
+    b.run_adabelief(iters, **ab)
+    ms = ctx.timer_stop()
+    hist = b.loss_history()
+    b.close()
+    N = n * ss
+    bytes_per = 8 * n * n + 4 * N * N     # data + 1/sigma^2 + the epoch's narrow PSF (SURVEY 8(d), no background term)
+    out = {'workload': f'star photometry: {G} stars x {E} epochs x {n}x{n} in one batched fit (lc_joint_create_groups), '
+                       f'{iters} AdaBelief iterations',
+           'value': G * E * iters / (ms * 1e-3), 'unit': 'cutouts/sec', 'us_per_iteration': ms * 1e3 / iters,
+           'roofline': hbm_roofline(G * E * iters * bytes_per, ms * 1e-3, 'joint_ps_kernel + joint_update_groups_kernel',
+                                    {'algorithmic_bytes_per_cutout_iteration': bytes_per}),
+           'loss_finite': bool(np.all(np.isfinite(hist)))}
+    if with_cpu:
+        try:
+            from oracle.joint_ps_cpu import JointPsCpu
+            cores = effective_cpus()
+            c = JointPsCpu(base['data'], sig2, base['psf'], ss, 1, double=False)
+            c.set_params(a=a0)
+            c.run(5, threads=cores)
+            k, t0 = 0, time.perf_counter()
+            while True:
+                c.run(50, threads=cores)
+                k += 50
+                dt = time.perf_counter() - t0
+                if dt > 5.0 or k >= 4000:
+                    break
+            out['cpu_baseline'] = dict(value=E * k / dt, unit='cutouts/sec', cores=cores, kind='port',
+                                       sample=f'{k} AdaBelief iterations of one star ({E} epochs x {n}x{n}, the same synthetic '
+                                              f'stack) in {dt:.1f} s: oracle/joint_ps_cpu.c, fp32 C + OpenMP over the epochs')
+        except Exception as e:
+            out['cpu_baseline'] = {'value': None, 'error': repr(e)}
+    return out
+
+
 def sharded_joint_fit(ctx, rank, world, iters=500, transport='collective'):
     """C4's 200 epochs sharded over the ranks; the shared block is all-reduced every iteration - in place by RCCL
     (transport 'collective'; gloo staged through the host in the one-GPU rehearsal) or by the library's one-shot
@@ -673,7 +727,8 @@ def main():
                            (joint_workload, dict(E=125, n=128, M=4, seed=105, iters=200,
                                                  label="C5 shard (one GPU's eighth of C5's 1000 epochs)")),
                            (c3_shard_workload, {}),
-                           (distortion_workload, {})):
+                           (distortion_workload, {}),
+                           (star_photometry_workload, dict(with_cpu=not args.no_cpu_baseline))):
                 try:
                     extra.append(fn(ctx, **kw))
                 except Exception as e:

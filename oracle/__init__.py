@@ -14,4 +14,9 @@ STARRED algorithm (Michalewicz et al. 2023; Millon et al. 2024) as frozen in
 ``DESIGN.md`` section "SPEC", anchored on the reference's call sites, and
 pinned only by library known-answer checks (scipy ``fftconvolve``/
 ``map_coordinates``, starlet exact reconstruction, finite differences).
+
+Contents: ``model.py`` / ``optim.py`` (torch float64 + autograd: the oracle), ``prep.py`` (stamp pre-processing),
+``psf_cpu.c`` and ``joint_ps_cpu.c`` (plain-C restatements of the PSF pixel-grid stage and of the point-source-only joint
+fit in the direct separable form; their float64 builds are second, algorithmically independent checkers, their float32
+builds the ``cpu_baseline`` "port" figures of ``bench.py``).
 """

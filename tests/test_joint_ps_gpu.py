@@ -82,3 +82,29 @@ def test_point_sources_only_trajectory(ctx):
     assert H.rel_err(got['a'], pf['a'].numpy()) < 2e-4
     assert np.abs(got['c_x'] - pf['c_x'].numpy()).max() < 5e-4
     assert np.abs(got['dy'] - pf['dy'].numpy()).max() < 5e-4
+
+
+def test_star_photometry_loop_against_the_c_port(ctx):
+    """The second, independent CPU implementation of this path (oracle/joint_ps_cpu.c: direct separable sums, derivative taps;
+    the one bench.py times as CPU baseline): loss / gradient in float64 and 300 AdaBelief iterations of the reference's default
+    star photometry (fluxes, position, shifts free) against the device loop."""
+    from oracle.joint_ps_cpu import JointPsCpu
+    E, M, n, ss, T = 12, 1, 32, 2, 300
+    ds, j, p, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 77)
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy']
+    j.set_loss()
+    j.set_free(free)
+    c = JointPsCpu(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, double=True)
+    c.set_params(**{k: p[k] for k in ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean')})
+    Lc, gc = c.eval(threads=4)
+    loss, grads = j.loss_grad(free)
+    assert abs(loss - Lc) / Lc < 3e-5
+    for k in free:
+        assert H.rel_err(grads[k], gc[k]) < 1e-4, k
+    hist_c = c.run(T, lr0=1e-3, schedule=True, threads=4)
+    j.run_adabelief(T, init_learning_rate=1e-3, schedule_learning_rate=True)
+    hist = np.asarray(j.loss_history(), np.float64)
+    assert hist.shape[0] == T + 1 and np.abs(hist - hist_c).max() / hist_c[0] < 1e-4
+    final = j.get_params()
+    assert H.rel_err(final['a'], c.p['a']) < 1e-4
+    assert np.abs(final['dx'] - c.p['dx']).max() < 1e-4 and np.abs(final['c_x'] - c.p['c_x']).max() < 1e-4
