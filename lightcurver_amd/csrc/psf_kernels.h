@@ -397,6 +397,10 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         float *wsc = lds + C::OFF_WSC + wid * C::WSZ;
         constexpr int TSA = C::TSA, AP = C::AP, APR = C::APR;
         float *R2w = wsc + AP, *RESw = wsc + JB * TSA + APR * C::JBP;
+        // (Two waves share a SIMD and the arbiter favours the older one: waves 0-3 are done after ~14 k cycles, waves 4-7
+        // after ~17.5 k, running alone - at 1 / 1.75 of the pair's rate - for the rest; tools/psf_stamps.py prints the times.
+        // Measured and left out: handing the tasks out from an LDS counter.  With four tasks of 3.5 k cycles per wave the
+        // older waves simply take a fifth one each and the phase ends at the same time: 16.2 against 15.9 us per iteration.)
         for (int task = wid; task < SG * NBLK; task += C::NW) {
           const int sl = task / NBLK, blk = task % NBLK, s = g0 + sl;
           if (s >= S) continue;  // wave-uniform
@@ -617,6 +621,9 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           LC_STAMP(13);
         }
         LC_STAMP(14);
+#ifdef LC_STAMPS
+        if (blockIdx.x == 0 && lane == 0 && it == A.n_iter - 1) g_stamps[20 + wid] = clock64();  // when each wave is done with its tasks
+#endif
         __syncthreads();
         LC_STAMP(15);
         if (tid < SG * 5) {

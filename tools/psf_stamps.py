@@ -41,4 +41,6 @@ for blk, label in ((0, 'block 0 (role 0 / single form)'), (64, 'block 8 (role 1)
         print('   last group, wave 0, last task:')
         for a in range(11, 18):
             print(f'     {fine[a]:34s} {s[a]-s[a-1]:8d} ticks')
+    if blk == 0 and s[20]:
+        print('   waves done with their tasks, ticks after the first barrier:', [int(s[20 + w] - s[1]) for w in range(16) if s[20 + w]])
     print('  total ticks', tot, '(s_memtime ticks @100MHz => us:', tot / 100.0, ')')
