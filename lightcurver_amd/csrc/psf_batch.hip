@@ -302,7 +302,9 @@ int launch_psf(lc_psf_batch *b, int mode, int n_iter, const lc_adabelief_cfg *cf
   // still hold CUs; a partner that does not show up makes the launch give up and the fall-back launch behind it redo
   // the work in the one-workgroup form (abort word protocol, psf_kernels.h), so the result never depends on it.
   const int split_grid = ((b->F + 7) / 8) * 16;
-  bool split = mode == 1 && v->fn_split && (A.lam_sc != 0.f || A.lam_hf != 0.f) && !std::getenv("LCMI_PSF_SINGLE_WG");
+  // (not for launches of a few iterations - the step-by-step drive of the distortion fit: the copies of the pre-launch state
+  // the fall-back needs cost ~35 us per launch, the two-workgroup form gains ~9 us per iteration)
+  bool split = mode == 1 && n_iter >= 4 && v->fn_split && (A.lam_sc != 0.f || A.lam_hf != 0.f) && !std::getenv("LCMI_PSF_SINGLE_WG");
   if (split) {
     LC_HIP(b->ctx, hipFuncSetAttribute((const void *)v->fn_split, hipFuncAttributeMaxDynamicSharedMemorySize, v->lds_bytes));
     if (b->split_blocks_per_cu < 0) {
@@ -543,7 +545,7 @@ int lc_psf_distortion_backward(lc_psf_batch *frames, lc_psf_batch *stars) {
   LC_ENTER(frames->ctx);
   if (frames->ctx != stars->ctx || frames->dist_S <= 0 || stars->F != frames->F * frames->dist_S || stars->N != frames->N)
     LC_FAIL(frames->ctx, LC_ERR_INVALID, "lc_psf_distortion_backward: the star batch must hold F * S single-star frames of the same grid");
-  hipLaunchKernelGGL(psf_warp_adjoint_kernel, dim3(frames->F), dim3(256), 0, frames->ctx->stream, frames->N, frames->dist_S,
+  hipLaunchKernelGGL(psf_warp_adjoint_kernel, dim3(frames->F, (frames->N * frames->N + 255) / 256), dim3(256), 0, frames->ctx->stream, frames->N, frames->dist_S,
                      frames->dist_coef, frames->dist_xy, stars->o_ggrid, frames->ext_grad);
   LC_HIP(frames->ctx, hipGetLastError());
   frames->use_ext_grad = true;

@@ -114,9 +114,11 @@ __global__ __launch_bounds__(256) void psf_warp_kernel(int N, int S, const float
 // lie within +-2 of the forward image of k.
 __global__ __launch_bounds__(256) void psf_warp_adjoint_kernel(int N, int S, const float *coef, const float *xy, const float *g,
                                                                float *gsrc) {
+  // grid (frames, ceil(N^2 / 256)): one source pixel per thread (one block per frame left 60 % of the CUs idle and took
+  // 400 us of the 500 us iteration at 100 frames x 8 stars x 64^2; the sums per pixel are unchanged)
   const int f = blockIdx.x;
   const float c = (float)((N - 1) / 2);
-  for (int i = threadIdx.x; i < N * N; i += 256) {
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < N * N; i += 256 * gridDim.y) {
     const int ky = i / N, kx = i % N;
     float acc = 0.f;
     for (int s = 0; s < S; ++s) {
