@@ -513,7 +513,7 @@ int lc_psf_batch_set_moffat_q(lc_psf_batch *b, const float *q) {
   return LC_OK;
 }
 int lc_psf_batch_set_distortion(lc_psf_batch *b, int S_stars, const float *coeffs, const float *xy) {
-  if (!b || !coeffs || !xy || S_stars <= 0) return LC_ERR_INVALID;
+  if (!b || !coeffs || !xy || S_stars <= 0 || S_stars > 16) return LC_ERR_INVALID;  // (16 stars per frame: the library's limit)
   LC_ENTER(b->ctx);
   for (size_t i = 0; i < (size_t)b->F * 9; ++i)
     if (!std::isfinite(coeffs[i]) || std::fabs(coeffs[i]) > 0.25f)

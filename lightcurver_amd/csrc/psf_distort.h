@@ -115,25 +115,40 @@ __global__ __launch_bounds__(256) void psf_warp_kernel(int N, int S, const float
 __global__ __launch_bounds__(256) void psf_warp_adjoint_kernel(int N, int S, const float *coef, const float *xy, const float *g,
                                                                float *gsrc) {
   // grid (frames, ceil(N^2 / 256)): one source pixel per thread (one block per frame left 60 % of the CUs idle and took
-  // 400 us of the 500 us iteration at 100 frames x 8 stars x 64^2; the sums per pixel are unchanged)
+  // 400 us of the 500 us iteration at 100 frames x 8 stars x 64^2; the sums per pixel are unchanged).  The matrices of
+  // the frame's stars are made once per block; the candidate window of a star is as wide as its matrix asks for
+  // (|d - A k| < |a00| + |a01| + 1/2 along x, |a01| + |a11| + 1/2 along y: 3 x 3 for distortions of a few per cent) -
+  // the candidates left out have weight zero.
+  __shared__ float sm[16][8];
   const int f = blockIdx.x;
   const float c = (float)((N - 1) / 2);
+  if ((int)threadIdx.x < S) {
+    const int img = f * S + threadIdx.x;
+    float a00, a01, a11;
+    distort_matrix(coef + f * 9, xy[2 * img], xy[2 * img + 1], a00, a01, a11);
+    const float det = a00 * a11 - a01 * a01, idet = 1.f / det;
+    float *m = sm[threadIdx.x];
+    m[0] = a00; m[1] = a01; m[2] = a11;
+    m[3] = a11 * idet; m[4] = -a01 * idet; m[5] = a00 * idet; m[6] = idet;
+    const int hv = min((int)floorf(fabsf(a00) + fabsf(a01) + 0.501f), 2), hu = min((int)floorf(fabsf(a01) + fabsf(a11) + 0.501f), 2);
+    m[7] = __int_as_float(hv | (hu << 8));
+  }
+  __syncthreads();
   for (int i = blockIdx.y * 256 + threadIdx.x; i < N * N; i += 256 * gridDim.y) {
     const int ky = i / N, kx = i % N;
     float acc = 0.f;
     for (int s = 0; s < S; ++s) {
       const int img = f * S + s;
-      float a00, a01, a11;
-      distort_matrix(coef + f * 9, xy[2 * img], xy[2 * img + 1], a00, a01, a11);
-      const float det = a00 * a11 - a01 * a01, idet = 1.f / det;
-      const float i00 = a11 * idet, i01 = -a01 * idet, i11 = a00 * idet;
+      const float *m = sm[s];
+      const float a00 = m[0], a01 = m[1], a11 = m[2], i00 = m[3], i01 = m[4], i11 = m[5], idet = m[6];
+      const int hw = __float_as_int(m[7]), hv = hw & 255, hu = hw >> 8;
       // forward image of the source pixel: u = c + A (k - c)
       const float rx = (float)kx - c, ry = (float)ky - c;
       const int vc = (int)nearbyintf(c + a00 * rx + a01 * ry), uc = (int)nearbyintf(c + a01 * rx + a11 * ry);
       const float *gi = g + (size_t)img * N * N;
       float part = 0.f;
-      for (int u = max(uc - 2, 0); u <= min(uc + 2, N - 1); ++u)
-        for (int v = max(vc - 2, 0); v <= min(vc + 2, N - 1); ++v) {
+      for (int u = max(uc - hu, 0); u <= min(uc + hu, N - 1); ++u)
+        for (int v = max(vc - hv, 0); v <= min(vc + hv, N - 1); ++v) {
           float X, Y;
           warp_sample(u, v, c, i00, i01, i11, X, Y);
           const float x0f = floorf(X), y0f = floorf(Y);
