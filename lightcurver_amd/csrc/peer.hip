@@ -135,7 +135,21 @@ int lc_peer_group_export(lc_peer_group *g, void *handle_out, int handle_bytes) {
   if (!g || !handle_out || handle_bytes < (int)sizeof(hipIpcMemHandle_t)) return LC_ERR_INVALID;
   LC_ENTER(g->ctx);
   hipIpcMemHandle_t h;
-  LC_HIP(g->ctx, hipIpcGetMemHandle(&h, g->own));
+  hipError_t e = hipIpcGetMemHandle(&h, g->own);
+  if (e != hipSuccess && g->seq == 0) {
+    // a runtime that does not export the fine-grained allocation: the same region as plain device memory (the kernel's
+    // accesses are system-scope either way)
+    (void)hipGetLastError();
+    float *plain = nullptr;
+    if (hipMalloc((void **)&plain, g->bytes) == hipSuccess && hipMemset(plain, 0, g->bytes) == hipSuccess) {
+      (void)hipFree(g->own);
+      g->own = g->peer[g->rank] = plain;
+      e = hipIpcGetMemHandle(&h, g->own);
+    } else if (plain) {
+      (void)hipFree(plain);
+    }
+  }
+  LC_HIP(g->ctx, e);
   std::memset(handle_out, 0, (size_t)handle_bytes);
   std::memcpy(handle_out, &h, sizeof(h));
   return LC_OK;
