@@ -273,6 +273,10 @@ int launch_psf(lc_psf_batch *b, int mode, int n_iter, const lc_adabelief_cfg *cf
     A.out_model = b->o_model;
   }
   A.ext_grad = b->use_ext_grad ? b->ext_grad : nullptr;
+  {
+    const char *xf = std::getenv("LCMI_PSF_XCD_FAST");
+    A.xcd_fast = !(xf && xf[0] == '0');
+  }
   A.lam_sc = reg ? b->lam_sc : 0.f;
   A.lam_hf = reg ? b->lam_hf : 0.f;
   if (cfg) A.ab = *cfg; else lc_adabelief_defaults(&A.ab);

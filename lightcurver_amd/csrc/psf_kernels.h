@@ -57,6 +57,7 @@ struct PsfArgs {
                           // stars of the adjoint resampling of their gradients, csrc/psf_distort.h)
   const float *sched;     // [>= t0 + n_iter][3]: learning rate and bias corrections by absolute iteration (host-made)
   float *B1, *mB1, *sB1;  // [F][N*N]: role 1's own copy of the pixel state when it does not fit in registers
+  int xcd_fast;           // two-workgroup form: partners that find themselves on one XCD hand over through its L2 (below)
 };
 
 // Write-through (sc1) stores and L1-bypassing (sc1) loads for data handed from one workgroup to another
@@ -68,6 +69,9 @@ __device__ __forceinline__ void store_sc1_x4(float *p, lc_v4f v) {
   // the compiler's hazard recogniser cannot see inside the asm, so they are spelled out here
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
 }
+__device__ __forceinline__ void store_plain_x4(float *p, lc_v4f v) {
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void store_sc1_f(float *p, float v) {
   asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
@@ -75,6 +79,13 @@ __device__ __forceinline__ void load_sc1_2x4(const float *p, lc_v4f &a, lc_v4f &
   asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
                : "=&v"(a), "=&v"(b)
                : "v"(p)
+               : "memory");
+}
+// the same with one more dword (the partner's scalar) in flight beside the two quads: one round trip instead of two
+__device__ __forceinline__ void load_sc1_2x4_1(const float *p, lc_v4f &a, lc_v4f &b, const float *ps, float &s) {
+  asm volatile("global_load_dword %2, %4, off sc1\n\tglobal_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(a), "=&v"(b), "=&v"(s)
+               : "v"(p), "v"(ps)
                : "memory");
 }
 __device__ __forceinline__ void load_sc1_x4(const float *p, lc_v4f &a) {
@@ -230,6 +241,9 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     if (f >= A.F) return;
   }
   const bool conv_role = !SPLIT || role == 0, starlet_role = !SPLIT || role == 1;
+  // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this workgroup runs on (s_getreg immediate: id | offset << 6 | (width - 1) << 11)
+  const int my_xcc = SPLIT ? (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u) : 0;
+  int same_xcd = 0;
   const int tid0 = threadIdx.x;
   const int S = A.S;
 
@@ -948,6 +962,10 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       float *mine = A.xch + (((size_t)f * 2 + (it & 1)) * 2 + role) * XS;
       const float *theirs = A.xch + (((size_t)f * 2 + (it & 1)) * 2 + (1 - role)) * XS;
       const int poff = pu * N + pv;
+      // Partners on ONE XCD (each reads HW_REG_XCC_ID and tells the other in the first hand-off of the launch; a workgroup
+      // never moves) share an L2: plain stores keep their lines there and the partner's L1-bypassing loads are served from
+      // it, where an sc1 store drops the line and the partner reads at the memory-side rate (MI355X_MICROARCH.md, "stores
+      // of each flavour").  Anything else - another XCD, the first iteration, xcd_fast off - takes the sc1 stores.
 #pragma unroll
       for (int q = 0; q < PX / 4; ++q) {
         lc_v4f v;
@@ -955,9 +973,14 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         v.y = role ? z[4 * q + 1] : gB[4 * q + 1];
         v.z = role ? z[4 * q + 2] : gB[4 * q + 2];
         v.w = role ? z[4 * q + 3] : gB[4 * q + 3];
-        store_sc1_x4(mine + poff + 4 * q, v);
+        if (same_xcd) store_plain_x4(mine + poff + 4 * q, v);
+        else store_sc1_x4(mine + poff + 4 * q, v);
       }
-      if (tid == 0 && role == 1) store_sc1_f(mine + N * N, tl1);
+      if (tid == 0 && role == 1) {
+        if (same_xcd) asm volatile("global_store_dword %0, %1, off" ::"v"(mine + N * N), "v"(tl1) : "memory");
+        else store_sc1_f(mine + N * N, tl1);
+      }
+      if (tid == 0 && it == 0) store_sc1_f(mine + N * N + 1, __int_as_float(my_xcc + 1));
       // role 0: the stars' step and the next tap tables need nothing from the partner: done while the stores drain
       if (role == 0 && A.mode == 1) update_stars_and_taps(tid);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -965,7 +988,9 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       LC_STAMP(45);
       int *OK = (int *)(SCAL + 5);
       if (tid == 0) {
-        __hip_atomic_store(A.xflags + f * 2 + role, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (same XCD: the flag too stays in the shared L2, where the partner's L1-bypassing poll finds it)
+        if (same_xcd) asm volatile("global_store_dword %0, %1, off" ::"v"(A.xflags + f * 2 + role), "v"(it + 1) : "memory");
+        else __hip_atomic_store(A.xflags + f * 2 + role, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 1, spins = 0;
         while (__hip_atomic_load(A.xflags + f * 2 + (1 - role), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it + 1) {
           __builtin_amdgcn_s_sleep(2);
@@ -978,6 +1003,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
             break;
           }
         }
+        if (it == 0 && ok) OK[1] = (A.xcd_fast && __float_as_int(load_sc1_f(theirs + N * N + 1)) == my_xcc + 1) ? 1 : 0;
         *OK = ok;
 #ifdef LC_XCH_ACQUIRE
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -987,10 +1013,12 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       __syncthreads();
       LC_STAMP(46);
       if (*OK == 0) break;
+      if (it == 0) same_xcd = OK[1];
       float other[PX];
+      float tl1_other = 0.f;  // (every thread reads the partner's scalar along with its pixels: one line, no second round trip)
       if constexpr (PX == 8) {
         lc_v4f a, b;
-        load_sc1_2x4(theirs + poff, a, b);
+        load_sc1_2x4_1(theirs + poff, a, b, theirs + N * N, tl1_other);
         other[0] = a.x; other[1] = a.y; other[2] = a.z; other[3] = a.w;
         other[4] = b.x; other[5] = b.y; other[6] = b.z; other[7] = b.w;
       } else {
@@ -1005,7 +1033,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       for (int p = 0; p < PX; ++p) {
         if (role) gB[p] = other[p]; else z[p] = other[p];
       }
-      if (tid == 0 && role == 0) tl1 = load_sc1_f(theirs + N * N);
+      if (tid == 0 && role == 0) tl1 = (PX == 8) ? tl1_other : load_sc1_f(theirs + N * N);
       LC_STAMP(47);
     }
     if (tid == 0 && conv_role) {

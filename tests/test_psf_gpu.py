@@ -210,9 +210,10 @@ def test_two_workgroup_form_is_bit_identical(ctx, n, S, F):
     import os
     ss, T = 2, (60 if n < 64 else 20)   # n = 64 (one GPU's share of C3): pixel state in HBM, role 1 on its own copy
     out = []
-    for single in (False, True):
-        if single:
-            os.environ['LCMI_PSF_SINGLE_WG'] = '1'
+    # the two-workgroup form with its same-XCD hand-off (partners that share an L2: plain stores), with the write-through
+    # hand-off everywhere (LCMI_PSF_XCD_FAST=0), and the one-workgroup form
+    for env in ({}, {'LCMI_PSF_XCD_FAST': '0'}, {'LCMI_PSF_SINGLE_WG': '1'}):
+        os.environ.update(env)
         try:
             ds, plist, b = _setup(n, ss, F, S, 900 + n, ctx, jitter=0.1)
             b.propagate_noise()
@@ -221,9 +222,11 @@ def test_two_workgroup_form_is_bit_identical(ctx, n, S, F):
             b.run_adabelief(T // 2, init_learning_rate=1e-4, schedule_learning_rate=True)
             out.append((b.loss_history(), b.get_grid(), b.get_stars()))
         finally:
-            os.environ.pop('LCMI_PSF_SINGLE_WG', None)
-    for a, c in zip(out[0], out[1]):
-        np.testing.assert_array_equal(a, c)
+            for k in env:
+                os.environ.pop(k, None)
+    for other in out[1:]:
+        for a, c in zip(out[0], other):
+            np.testing.assert_array_equal(a, c)
     assert np.all(np.isfinite(out[0][0]))
 
 
