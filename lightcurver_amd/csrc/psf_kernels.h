@@ -205,6 +205,18 @@ __device__ inline void tap_entry(float delta, int k, float &tap, float &dtap, in
   dtap = d;
 }
 
+// Issue priority by progress (k = units of work this wave has finished, wave-uniform): of the two waves of a SIMD the one that
+// is behind wins the arbitration, so both reach the barrier together instead of the older one early and the younger one
+// alone at 1 / 1.75 of the pair's rate (MI355X_MICROARCH.md, two waves per SIMD: priority, then age).
+__device__ __forceinline__ void progress_prio(int k) {
+#ifndef LC_NO_PROGRESS_PRIO
+  if (k <= 0) __builtin_amdgcn_s_setprio(3);
+  else if (k == 1) __builtin_amdgcn_s_setprio(2);
+  else if (k == 2) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // SPLIT: two workgroups per frame.  Role 0 evaluates the forward model and the chi2 gradient, role 1 the starlet
 // l1 term of the same B; they swap their halves of dL/dB through L2 once per iteration and both apply the
 // identical AdaBelief update to their own register copy of B (same operands, same order => same bits).
@@ -415,7 +427,9 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         // after ~17.5 k, running alone - at 1 / 1.75 of the pair's rate - for the rest; tools/psf_stamps.py prints the times.
         // Measured and left out: handing the tasks out from an LDS counter.  With four tasks of 3.5 k cycles per wave the
         // older waves simply take a fifth one each and the phase ends at the same time: 16.2 against 15.9 us per iteration.)
-        for (int task = wid; task < SG * NBLK; task += C::NW) {
+        int kdone = 0;  // tasks this wave has finished: the wave that is behind gets the issue priority (progress_prio)
+        for (int task = wid; task < SG * NBLK; task += C::NW, ++kdone) {
+          progress_prio(kdone);
           const int sl = task / NBLK, blk = task % NBLK, s = g0 + sl;
           if (s >= S) continue;  // wave-uniform
           const int jd0 = blk * JB;
@@ -634,6 +648,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           wave_lds_sync();  // the scratch is rewritten by the wave's next task
           LC_STAMP(13);
         }
+        __builtin_amdgcn_s_setprio(0);
         LC_STAMP(14);
 #ifdef LC_STAMPS
         if (blockIdx.x == 0 && lane == 0 && it == A.n_iter - 1) g_stamps[20 + wid] = clock64();  // when each wave is done with its tasks
@@ -831,6 +846,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         for (int sl = 0; sl < SG; ++sl) {
           const int s = g0 + sl;
           if (s >= S) break;
+          progress_prio((4 * sl) / SG);  // (SG stars in four steps)
           const float *tx = TAPS + (s * 4 + 0) * NTP, *dtx = tx + NTP;
           const int bq = BQ[s * 2 + 0];
           const float amp = SP[s * 4 + 0];
@@ -863,6 +879,7 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           gxs = wave_sum(gxs);
           if (lane == 0) REDX[s * C::NW + wid] = gxs;
         }
+        __builtin_amdgcn_s_setprio(0);
       } else {
         constexpr int WJ = (PX - 1 + NT - 1) / SS + 1;
         for (int sl = 0; sl < SG; ++sl) {
