@@ -590,7 +590,9 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   if constexpr (!AUX && C::ROWPIPE) {
     if (use_h && translated) fetch_rows(2 * (pw * GPW + qid), pw * GPW + qid < N / 2, hpre);
   }
-  for (int rp0 = pw * GPW; rp0 < N / 2; rp0 += PWS * GPW) {
+  for (int rp0 = pw * GPW, sw = 0; rp0 < N / 2; rp0 += PWS * GPW, ++sw) {
+    // (of the two waves of a SIMD the one that is a sweep behind wins the issue arbitration: starlet_device.h)
+    progress_prio_end(sw, (N / 2 + PWS * GPW - 1) / (PWS * GPW));
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
     float2 x[N2];
@@ -699,13 +701,15 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       return;
     }
   }
+  __builtin_amdgcn_s_setprio(0);
   // ---- phase B: columns: FFT, multiply by the PSF spectrum, inverse FFT, keep the 'same' window ----
   if constexpr (PIPED && (PHASE == 0 || PHASE == 2)) {
     column_sweeps(Ste, false, 0, CREF);
   } else if constexpr (PHASE == 0 || PHASE == 2) {
-  for (int kt = part * C::NW * GPW; kt < NCOL; kt += PWS * GPW) {  // one sweep: NW * GPW consecutive columns
+  for (int kt = part * C::NW * GPW, sw = 0; kt < NCOL; kt += PWS * GPW, ++sw) {  // one sweep: NW * GPW consecutive columns
     const int kc0 = kt + wid * GPW;
     if (kc0 >= NCOL) break;
+    progress_prio_end(sw, (NCOL + PWS * GPW - 1) / (PWS * GPW));
     const int kc = kc0 + qid;
     const bool active = kc < NCOL;
     const int kcs = active ? kc : 1;
@@ -734,6 +738,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     LC_JSTAMP(14);
   }
   }  // phase B
+  __builtin_amdgcn_s_setprio(0);
   __syncthreads();
   LC_JSTAMP(3);
   if constexpr (AUX) {  // mode 3: inverse rows, 'same' window of the convolution at full resolution
@@ -774,7 +779,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       const float2 gb = cmul(make_float2(b0.x + b1.x, b0.y + b1.y), PHI[LH - m]);
       return make_float2(ga.x + gb.x, ga.y - gb.y);
     };
-    for (int t0 = pw * GPW; t0 < n / 2; t0 += PWS * GPW) {
+    for (int t0 = pw * GPW, sw = 0; t0 < n / 2; t0 += PWS * GPW, ++sw) {
+      progress_prio_end(sw, (n / 2 + PWS * GPW - 1) / (PWS * GPW));
       const int t = t0 + qid, I0 = 2 * t, I1 = I0 + 1;
       const bool active = t < n / 2;
       float2 x[N2H];
@@ -982,13 +988,15 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   }
   __syncthreads();
   LC_JSTAMP(4);
+  __builtin_amdgcn_s_setprio(0);
   // ---- phase B': adjoint columns (rows sit at offset CREF), multiply by conj(spectrum) ------------
   if constexpr (PIPED && (PHASE == 0 || PHASE == 4)) {
     column_sweeps(Ste, true, CREF, 0);
   } else if constexpr (PHASE == 0 || PHASE == 4) {
-  for (int kt = part * C::NW * GPW; kt < NCOL; kt += PWS * GPW) {
+  for (int kt = part * C::NW * GPW, sw = 0; kt < NCOL; kt += PWS * GPW, ++sw) {
     const int kc0 = kt + wid * GPW;
     if (kc0 >= NCOL) break;
+    progress_prio_end(sw, (NCOL + PWS * GPW - 1) / (PWS * GPW));
     const int kc = kc0 + qid;
     const bool active = kc < NCOL;
     const int kcs = active ? kc : 1;
@@ -1011,11 +1019,13 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     }
   }
   }  // phase B'
+  __builtin_amdgcn_s_setprio(0);
   __syncthreads();
   LC_JSTAMP(5);
   // ---- phase C': adjoint inverse rows -> scene gradient rows; parameter gradients ------------------
   if constexpr (PHASE == 0 || PHASE == 5) {
-  for (int rp0 = pw * GPW; rp0 < N / 2; rp0 += PWS * GPW) {
+  for (int rp0 = pw * GPW, sw = 0; rp0 < N / 2; rp0 += PWS * GPW, ++sw) {
+    progress_prio_end(sw, (N / 2 + PWS * GPW - 1) / (PWS * GPW));
     const int rp = rp0 + qid, u0 = 2 * rp;
     const bool active = rp < N / 2;
     float2 x[N2];
@@ -1121,6 +1131,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     }
   }
   }  // phase C'
+  __builtin_amdgcn_s_setprio(0);
   LC_JSTAMP(6);
   acc_dx = fmaf(-(float)SS, acc_hx, acc_dx);
   acc_dy = fmaf(-(float)SS, acc_hy, acc_dy);

@@ -205,18 +205,6 @@ __device__ inline void tap_entry(float delta, int k, float &tap, float &dtap, in
   dtap = d;
 }
 
-// Issue priority by progress (k = units of work this wave has finished, wave-uniform): of the two waves of a SIMD the one that
-// is behind wins the arbitration, so both reach the barrier together instead of the older one early and the younger one
-// alone at 1 / 1.75 of the pair's rate (MI355X_MICROARCH.md, two waves per SIMD: priority, then age).
-__device__ __forceinline__ void progress_prio(int k) {
-#ifndef LC_NO_PROGRESS_PRIO
-  if (k <= 0) __builtin_amdgcn_s_setprio(3);
-  else if (k == 1) __builtin_amdgcn_s_setprio(2);
-  else if (k == 2) __builtin_amdgcn_s_setprio(1);
-  else __builtin_amdgcn_s_setprio(0);
-#endif
-}
-
 // SPLIT: two workgroups per frame.  Role 0 evaluates the forward model and the chi2 gradient, role 1 the starlet
 // l1 term of the same B; they swap their halves of dL/dB through L2 once per iteration and both apply the
 // identical AdaBelief update to their own register copy of B (same operands, same order => same bits).
