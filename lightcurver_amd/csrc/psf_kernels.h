@@ -1019,6 +1019,9 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       LC_STAMP(46);
       if (*OK == 0) break;
       if (it == 0) same_xcd = OK[1];
+      // (measured and left out: role 0, the longer of the two, asking for the partner's half BEFORE publishing its own - the
+      //  partner has published long before - with loads the compiler tracks (agent-scope relaxed atomics, one dword each):
+      //  17.0 against 14.8 us per iteration; the 16-byte form would need registers that are in flight across compiled code)
       float other[PX];
       float tl1_other = 0.f;  // (every thread reads the partner's scalar along with its pixels: one line, no second round trip)
       if constexpr (PX == 8) {
