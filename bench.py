@@ -693,7 +693,9 @@ def main():
                              'fp32_valu_tflops': F * S * ITERS_PER_STEP * flops_per / launch_s / 1e12,
                              'fp32_valu_frac_of_157': F * S * ITERS_PER_STEP * flops_per / launch_s / 1e12 / FP32_PEAK_TFLOPS,
                              'note': 'the pixel state stays on chip across the iterations of a launch, so HBM moves far '
-                                     'fewer bytes than the algorithmic figure; the kernel is bound by fp32 VALU issue'})
+                                     'fewer bytes than the algorithmic figure; at 2 waves / SIMD the kernel is bound by '
+                                     'instruction issue and the latencies it cannot hide (SQ counters, profiles/: waves '
+                                     'parked 40 %, issuing 42 %, of which VALU 31 %)'})
         roof['traffic'] = traffic
         roof['traffic_source'] = traffic_source
         out = {
