@@ -58,3 +58,22 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(('.py', '.h', '.hip')):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+
+
+def test_embedded_fit_sizes_are_chosen_from_the_kernel_table():
+    """build_psf fits a stamp size without a kernel of its own inside the next instantiated one (psf_routines._fit_size);
+    lc_psf_supported is a host-side table look-up, so the choice can be checked without a GPU."""
+    import pytest
+    from lightcurver_amd import _lib
+    from lightcurver_amd.starred.procedures.psf_routines import _fit_size
+    l = _lib.lib()
+    native = [n for n in range(2, 130, 2) if l.lc_psf_supported(n, 2)]
+    assert native == [16, 24, 32, 64]
+    for n in range(8, 66, 2):
+        m = _fit_size(n, 2)
+        assert m in native and m >= n and (m - n) % 2 == 0 and (m == n) == (n in native)
+        assert all(k < n for k in native if k < m)          # the smallest one that holds the stamp
+    with pytest.raises(_lib.LcError):
+        _fit_size(66, 2)
+    with pytest.raises(_lib.LcError):
+        _fit_size(20, 3)
