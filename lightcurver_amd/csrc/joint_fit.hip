@@ -1474,7 +1474,7 @@ int group_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg) {
   if (cfg) ab = *cfg; else lc_adabelief_defaults(&ab);
   float lr, bc1, bc2;
   adabelief_schedule(ab, t, lr, bc1, bc2);
-  hipLaunchKernelGGL(joint_update_groups_kernel, dim3(j->G), dim3(kGmThreads), 0, j->ctx->stream, j->views_dev, mode, t, lr, bc1, bc2);
+  hipLaunchKernelGGL(joint_update_groups_kernel, dim3(2 * j->G), dim3(kGmThreads), 0, j->ctx->stream, j->views_dev, mode, t, lr, bc1, bc2);
   LC_HIP(j->ctx, hipGetLastError());
   return LC_OK;
 }

@@ -367,18 +367,22 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
 __global__ __launch_bounds__(kGmThreads) void joint_update_groups_kernel(const JointUpdArgs *views, int mode, int t, float lr,
                                                                          float bc1, float bc2) {
   __shared__ double lanes[kGmThreads];
-  JointUpdArgs A = views[blockIdx.x];  // (block-uniform: scalar loads)
+  // two blocks per star, as in the one-fit launch (joint_reduce_update_kernel): the shifts and sky levels need nothing from
+  // the reduction over the epochs and step in a block of their own beside it
+  JointUpdArgs A = views[blockIdx.x >> 1];  // (block-uniform: scalar loads)
   A.mode = mode;
   A.t = t;
   A.lr = lr;
   A.bc1 = bc1;
   A.bc2 = bc2;
   __shared__ float scl[4 * kMaxSources + 2];  // (the sums also go to LDS: the rules below read them without a trip through L2)
-  // (same rules in another order of issue: the fluxes with their moments are requested first, the shifts and sky levels - which
-  //  need nothing from the reduction - step while those loads and the reduction's are in flight)
+  // (the fluxes with their moments are requested first and arrive while the reduction's loads are in flight)
+  if (blockIdx.x & 1) {
+    gm_small_blocks(A, 0, lr, bc1, bc2, nullptr, 2);
+    return;
+  }
   FluxPre pre;
   gm_flux_preload(A, pre);
-  gm_small_blocks(A, 0, lr, bc1, bc2, nullptr, 2);
   reduce_scalars(A.E, A.M, 0, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.a_ref, A.shared_w, lanes, threadIdx.x, scl);
   __syncthreads();
   gm_small_blocks(A, 0, lr, bc1, bc2, scl, 1, &pre);

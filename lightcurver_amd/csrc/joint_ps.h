@@ -65,7 +65,7 @@ struct JointPsArgs {
 // LDS / registers, and the loss history leaves as one value per epoch and iteration (summed over the epochs afterwards).
 // Same arithmetic per iteration as the launch-per-iteration form (same filters, same reductions, same update).
 template <int N, int SS, bool PERSIST = false>
-__global__ __launch_bounds__(kPsThreads) void joint_ps_kernel(JointPsArgs P) {
+__global__ __launch_bounds__(kPsThreads) __attribute__((amdgpu_waves_per_eu((N <= 64 && !PERSIST) ? 4 : 1, (N <= 64 && !PERSIST) ? 4 : 8))) void joint_ps_kernel(JointPsArgs P) {
   constexpr int n = N / SS, NT = ntaps(SS), TS = N + 1, RS = n + 1, nn = n * n, NWV = kPsThreads / 64;
   constexpr int NQ = 4 + 3 * kMaxSources;
   const JointArgs &A = P.J;
@@ -137,13 +137,13 @@ __global__ __launch_bounds__(kPsThreads) void joint_ps_kernel(JointPsArgs P) {
     const int bqx = BQ[0], bqy = BQ[1];
     // (the taps of the source in registers for both passes: read from LDS per multiply-add they were three of every five
     //  LDS reads of this kernel, which is what a batch of thousands of epochs waits for; same values, same order of the sums)
-    float tx[NT], tdx[NT], ty[NT], tdy[NT];
+    // value and derivative tap of an axis as one packed operand: a window sample enters both filters with one v_pk_fma_f32
+    // (the same two fused multiply-adds, one instruction instead of two)
+    lc_v2f txd[NT], tyd[NT];
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-      tx[k] = TAP[k];
-      tdx[k] = TAP[NT + k];
-      ty[k] = TAP[2 * NT + k];
-      tdy[k] = TAP[3 * NT + k];
+      txd[k] = (lc_v2f){TAP[k], TAP[NT + k]};
+      tyd[k] = (lc_v2f){TAP[2 * NT + k], TAP[3 * NT + k]};
     }
     // row pass fused with the column down-sampling: R[r][a] = sum_k tx[k] s[r][SS (a - bqx) - k].  A thread takes a strip
     // of LS consecutive outputs of a row and reads their common window of the PSF row once (19 LDS reads for 4 outputs
@@ -161,15 +161,11 @@ __global__ __launch_bounds__(kPsThreads) void joint_ps_kernel(JointPsArgs P) {
       }
 #pragma unroll
       for (int j = 0; j < LS; ++j) {
-        float acc = 0.f, accd = 0.f;
+        lc_v2f acc = {0.f, 0.f};  // (value, x-derivative)
 #pragma unroll
-        for (int k = 0; k < NT; ++k) {
-          const float sv = win[SS * j + NT - 1 - k];
-          acc = fmaf(tx[k], sv, acc);
-          accd = fmaf(tdx[k], sv, accd);
-        }
-        R[r * RS + a0 + j] = acc;
-        Rx[r * RS + a0 + j] = accd;
+        for (int k = 0; k < NT; ++k) acc = pk_fma(txd[k], pk_bcast(win[SS * j + NT - 1 - k]), acc);
+        R[r * RS + a0 + j] = acc.x;
+        Rx[r * RS + a0 + j] = acc.y;
       }
     }
     __syncthreads();
@@ -192,14 +188,15 @@ __global__ __launch_bounds__(kPsThreads) void joint_ps_kernel(JointPsArgs P) {
       }
 #pragma unroll
       for (int j = 0; j < LS; ++j) {
-        float fv = 0.f, fx = 0.f, fy = 0.f;
+        lc_v2f fvy = {0.f, 0.f};  // (value, y-derivative)
+        float fx = 0.f;
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
           const float rv = wr[SS * j + NT - 1 - k], rx = wx[SS * j + NT - 1 - k];
-          fv = fmaf(ty[k], rv, fv);
-          fy = fmaf(tdy[k], rv, fy);
-          fx = fmaf(ty[k], rx, fx);
+          fvy = pk_fma(tyd[k], pk_bcast(rv), fvy);
+          fx = fmaf(tyd[k].x, rx, fx);
         }
+        const float fv = fvy.x, fy = fvy.y;
         const int px = (I0 + j) * n + a;
         if (single) {
           fvr[t][j] = fv;
