@@ -82,7 +82,12 @@ __global__ __launch_bounds__(kPsThreads) __attribute__((amdgpu_waves_per_eu((N <
   const float ca = cosf(al), sa = sinf(al);
   float dxe = A.dx[e], dye = A.dy[e], meane = A.mean[e];
   const float *se = P.psf + (size_t)e * N * N;
-  for (int k = tid; k < N * N; k += kPsThreads) Sx[(k / N) * TS + (k % N)] = se[k];
+  // (16-byte loads: a quarter of the requests; the padded LDS rows take the four values one by one)
+  for (int k4 = tid; k4 < N * N / 4; k4 += kPsThreads) {
+    const float4 v = ((const float4 *)se)[k4];
+    float *d = Sx + ((4 * k4) / N) * TS + (4 * k4) % N;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
   float *Fe = P.F + (size_t)e * M * 3 * nn;
   // persistent form: parameters [a_0 .. a_{M-1}, dx, dy, mean] and their moments, one thread each
   __shared__ float PP[kMaxSources + 3];
