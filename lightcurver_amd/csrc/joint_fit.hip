@@ -395,12 +395,16 @@ int launch_reduce(lc_joint *j, int need_h) {
 }
 
 // starlet l1 + positivity of h as multi-block kernels: -> greg, regs (same contract as reg_mode 1 of joint_update_kernel)
-int launch_reg_gm(lc_joint *j, hipStream_t stream, bool with_pts, bool abar_from_shared) {
+// pts_only: the background part (greg, regs[0..1]) was evaluated by the chain on the second stream; only the point-source
+// starlet term, which in a sharded fit needs the all-reduced mean fluxes, is evaluated here (12 short launches instead of
+// the whole cascade once more: 125 epochs of 128 x 128 in the sharded loop 541 -> see DESIGN.md section 6)
+int launch_reg_gm(lc_joint *j, hipStream_t stream, bool with_pts, bool abar_from_shared, bool pts_only = false) {
   const int N = j->N, NN = N * N, J = j->J, nb = (NN + kGmThreads - 1) / kGmThreads;
   const dim3 grid(nb), block(kGmThreads);
   const float *W = j->have_W ? j->W : nullptr;
-  LC_HIP(j->ctx, hipMemcpyAsync(j->gm_c, j->par[LC_P_H], (size_t)NN * sizeof(float), hipMemcpyDeviceToDevice, stream));
   const bool l1_on = (j->cfg.lam_scales != 0.f || j->cfg.lam_hf != 0.f);
+  if (!pts_only) {
+  LC_HIP(j->ctx, hipMemcpyAsync(j->gm_c, j->par[LC_P_H], (size_t)NN * sizeof(float), hipMemcpyDeviceToDevice, stream));
   if (l1_on) {
     for (int s = 0; s < J; ++s) {
       const int d = 1 << s;
@@ -426,7 +430,14 @@ int launch_reg_gm(lc_joint *j, hipStream_t stream, bool with_pts, bool abar_from
   }
   hipLaunchKernelGGL(gm_positivity_kernel, grid, block, 0, stream, NN, j->par[LC_P_H], j->cfg.lam_positivity, j->greg, j->gm_pos);
   hipLaunchKernelGGL(gm_regs_kernel, dim3(1), dim3(64), 0, stream, l1_on ? J * nb : 0, nb, j->gm_l1, j->gm_pos, j->regs);
-  if (with_pts) {
+  }  // !pts_only
+  if (with_pts && pts_only && abar_from_shared && N % kPtT == 0 && !std::getenv("LCMI_PTS_CHAIN")) {  // (LCMI_PTS_CHAIN=1: the twelve-launch form, the cross-check)
+    // behind the all-reduce of a sharded fit, on the critical path: the term in one launch (joint_gm.h)
+    float *part = j->gm_pts + 8, *l1p = j->gm_l1 + (size_t)J * nb;
+    hipLaunchKernelGGL(gm_pts_direct_kernel, dim3((N / kPtT) * (N / kPtT)), block, 0, stream, N, j->ss, j->M, j->a_ref, j->shared,
+                       j->par[LC_P_CX], j->par[LC_P_CY], W, j->norms, j->cfg.lam_pts_source, part, l1p);
+    hipLaunchKernelGGL(gm_pts_final_kernel, dim3(1), dim3(64), 0, stream, (N / kPtT) * (N / kPtT), j->M, part, l1p, j->regs);
+  } else if (with_pts) {
     // point-source starlet term: scale 0 only, on Pbar (the work buffers of the chain above are free again)
     float *abar = j->gm_pts, *part = j->gm_pts + 8, *qp = j->qscr + (size_t)J * NN, *l1p = j->gm_l1 + (size_t)J * nb;
     hipLaunchKernelGGL(gm_abar_kernel, dim3(1), dim3(256), 0, stream, j->E, j->M, NN, j->par[LC_P_A], j->a_ref, j->shared,
@@ -594,12 +605,20 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
     if (reg_mode == 1) return launch_reg_gm(j, stream, j->pts_pending, false);
     if (reg_mode == 2) gm_pts_done = j->pts_pending;  // evaluated by the stream-B chain of this iteration
     if ((reg_mode == 0 && (reg_h_on(j) || want_pts)) || (reg_mode == 2 && want_pts && !gm_pts_done)) {
-      // inline (gradient evaluations, step-by-step / sharded drive): the mean fluxes come from the reduced block
-      int rc = launch_reg_gm(j, stream, want_pts, true);
+      // inline (gradient evaluations, step-by-step / sharded drive): the mean fluxes come from the reduced block; behind a
+      // chain that has already evaluated the background part (reg_mode 2) only the point-source term is left to do
+      int rc = launch_reg_gm(j, stream, want_pts, true, reg_mode == 2);
       if (rc) return rc;
       reg_mode = 2;
       gm_pts_done = want_pts;
     }
+  } else if (reg_mode == 2 && mode == 1 && j->gm_c && j->cfg.lam_pts_source != 0.f && j->M > 0 && !j->pts_pending) {
+    // LDS-spectrum sizes in the sharded drive: the chain on the second stream has the background part, the point-source
+    // term follows the all-reduce here - and the multi-block update takes over from the one-workgroup kernel, which would
+    // evaluate everything once more by itself (95 us at N = 128)
+    int rc = launch_reg_gm(j, stream, true, true, true);
+    if (rc) return rc;
+    gm_pts_done = true;
   }
   JointUpdArgs A;
   std::memset(&A, 0, sizeof(A));
@@ -849,7 +868,7 @@ static int joint_create_impl(lc_ctx *ctx, int E, int M, int n, int ss, const flo
     TRY(dmalloc(j, &j->a_ref_g, (size_t)G * kMaxSources));
     TRY(dmalloc(j, &j->out_loss_g, G));
   }
-  if (!v->uk && !lean) {
+  if (!lean) {  // (all sizes: the sharded drive evaluates the point-source term with these kernels at every N)
     const size_t nb = (NN + kGmThreads - 1) / kGmThreads;
     TRY(dmalloc(j, &j->gm_c, NN));
     TRY(dmalloc(j, &j->gm_t, NN));

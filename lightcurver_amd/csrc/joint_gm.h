@@ -194,6 +194,127 @@ __global__ void gm_pts_inner_kernel(int N, int ss, int M, const float *q, const 
     part[(size_t)blockIdx.x * 3 * kMaxSources + threadIdx.x] = acc;
   }
 }
+// The same term in ONE launch (the sharded drive evaluates it behind the all-reduce, on the critical path: twelve short launches
+// there cost 40 us).  Only scale 0 is involved - a 5 x 5 separable stencil - so a block can own a 16 x 16 tile: Pbar on the
+// tile and a halo of 4 (evaluated at clamped coordinates, which IS the edge replication), row and column smoothing on
+// shrinking halos, w and q on the tile + 2, the exact adjoint (the same end-of-line sums as gm_pass_adjoint_kernel: rows
+// 0..2 / N-3..N-1 of q are inside the halo of the tiles that need them) and the inner products of gm_pts_inner_kernel.
+// part / l1_part per tile in the layout gm_pts_final_kernel sums ((N / 16)^2 tiles = N^2 / 256 blocks).
+constexpr int kPtT = 16;
+__global__ __launch_bounds__(kGmThreads) void gm_pts_direct_kernel(int N, int ss, int M, const float *a_ref, const float *shared,
+                                                                    const float *cx, const float *cy, const float *W0,
+                                                                    const float *norm, float lam, float *part, float *l1_part) {
+  constexpr int T = kPtT, H4 = T + 8, H2 = T + 4;
+  __shared__ float P[H4][H4 + 1], R1[H4][H2 + 1], Q[H2][H2 + 1], TA[T][H2 + 1];
+  __shared__ float AB[kMaxSources], CX[kMaxSources], CY[kMaxSources];
+  __shared__ float red[kGmThreads / 64][kMaxSources * 3 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, NN = N * N;
+  const int tiles = N / T, tu0 = (blockIdx.x / tiles) * T, tv0 = (blockIdx.x % tiles) * T;
+  const float c0 = (N - 1) * 0.5f, inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm2 = 0.15915494309189535f * inv_s2;
+  if (tid < M) {
+    AB[tid] = a_ref[tid] + shared[NN + 2 * M + tid] / shared[NN + 4 * M + 1];
+    CX[tid] = c0 + ss * cx[tid];
+    CY[tid] = c0 + ss * cy[tid];
+  }
+  __syncthreads();
+  auto gauss = [&](int i, int u, int v, float &tx, float &ty) {
+    tx = (float)v - CX[i];
+    ty = (float)u - CY[i];
+    return nrm2 * expf(-0.5f * (tx * tx + ty * ty) * inv_s2);
+  };
+  for (int k = tid; k < H4 * H4; k += kGmThreads) {  // Pbar at the clamped coordinates of the tile + 4
+    const int ru = k / H4, rv = k % H4;
+    const int u = min(max(tu0 - 4 + ru, 0), N - 1), v = min(max(tv0 - 4 + rv, 0), N - 1);
+    float acc = 0.f, tx, ty;
+    for (int i = 0; i < M; ++i) acc = fmaf(AB[i], gauss(i, u, v, tx, ty), acc);
+    P[ru][rv] = acc;
+  }
+  __syncthreads();
+  for (int k = tid; k < H4 * H2; k += kGmThreads) {  // along the rows (axis 1), columns of the tile + 2
+    const int ru = k / H2, rv = k % H2;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = -2; t <= 2; ++t) acc = fmaf(gm_b3(t), P[ru][rv + 2 + t], acc);
+    R1[ru][rv] = acc;
+  }
+  __syncthreads();
+  for (int k = tid; k < H2 * H2; k += kGmThreads) {  // along the columns (axis 0); w, q on the tile + 2 (zero off the grid)
+    const int ru = k / H2, rv = k % H2;
+    const int u = tu0 - 2 + ru, v = tv0 - 2 + rv;
+    float q = 0.f;
+    if (u >= 0 && u < N && v >= 0 && v < N) {
+      float cn = 0.f;
+#pragma unroll
+      for (int t = -2; t <= 2; ++t) cn = fmaf(gm_b3(t), R1[ru + 2 + t][rv], cn);
+      const float w = P[ru + 2][rv + 2] - cn;
+      const float lw = lam * (W0 ? W0[u * N + v] : norm[0]);
+      q = (w > 0.f) ? lw : ((w < 0.f) ? -lw : 0.f);
+      if (ru >= 2 && ru < 2 + T && rv >= 2 && rv < 2 + T) P[ru + 2][rv + 2] = lw * fabsf(w);  // (own pixel: its share of the value)
+    }
+    Q[ru][rv] = q;
+  }
+  __syncthreads();
+  for (int k = tid; k < T * H2; k += kGmThreads) {  // adjoint along axis 0 at the tile's rows, columns of the tile + 2
+    const int r = k / H2, rv = k % H2, u = tu0 + r, ru = r + 2;
+    float acc;
+    if (u > 0 && u < N - 1) {
+      acc = 0.f;
+#pragma unroll
+      for (int t = -2; t <= 2; ++t) acc = fmaf(gm_b3(t), Q[ru - t][rv], acc);  // (q is zero off the grid)
+    } else if (u == 0) {
+      const float s1 = Q[ru][rv] + Q[ru + 1][rv], s2 = s1 + Q[ru + 2][rv];
+      acc = 0.375f * Q[ru][rv] + 0.25f * s1 + 0.0625f * s2;
+    } else {
+      const float e1 = Q[ru][rv] + Q[ru - 1][rv], e2 = e1 + Q[ru - 2][rv];
+      acc = 0.375f * Q[ru][rv] + 0.25f * e1 + 0.0625f * e2;
+    }
+    TA[r][rv] = acc;
+  }
+  __syncthreads();
+  float z = 0.f, l1 = 0.f;
+  const int r = tid / T, cc = tid % T, u = tu0 + r, v = tv0 + cc;
+  {  // adjoint along axis 1, z = q - adj at the thread's own pixel
+    const int rv = cc + 2;
+    float acc;
+    if (v > 0 && v < N - 1) {
+      acc = 0.f;
+#pragma unroll
+      for (int t = -2; t <= 2; ++t) acc = fmaf(gm_b3(t), TA[r][rv - t], acc);
+    } else if (v == 0) {
+      const float s1 = TA[r][rv] + TA[r][rv + 1], s2 = s1 + TA[r][rv + 2];
+      acc = 0.375f * TA[r][rv] + 0.25f * s1 + 0.0625f * s2;
+    } else {
+      const float e1 = TA[r][rv] + TA[r][rv - 1], e2 = e1 + TA[r][rv - 2];
+      acc = 0.375f * TA[r][rv] + 0.25f * e1 + 0.0625f * e2;
+    }
+    z = Q[r + 2][rv] - acc;
+    l1 = P[r + 4][cc + 4];
+  }
+  for (int i = 0; i < M; ++i) {
+    float tx, ty;
+    const float gq = z * gauss(i, u, v, tx, ty);
+    const float sa = wave_sum_shfl(gq), sx = wave_sum_shfl(gq * tx * inv_s2), sy = wave_sum_shfl(gq * ty * inv_s2);
+    if (lane == 0) {
+      red[wid][i * 3] = sa;
+      red[wid][i * 3 + 1] = sx;
+      red[wid][i * 3 + 2] = sy;
+    }
+  }
+  l1 = wave_sum_shfl(l1);
+  if (lane == 0) red[wid][kMaxSources * 3] = l1;
+  __syncthreads();
+  if (tid < 3 * M) {
+    float acc = 0.f;
+    for (int w = 0; w < kGmThreads / 64; ++w) acc += red[w][tid];
+    part[(size_t)blockIdx.x * 3 * kMaxSources + tid] = acc;
+  }
+  if (tid == 64) {
+    float acc = 0.f;
+    for (int w = 0; w < kGmThreads / 64; ++w) acc += red[w][kMaxSources * 3];
+    l1_part[blockIdx.x] = acc;
+  }
+}
+
 // ordered final sums -> regs[2] = value of the term, regs[4 + 3 i + q] = the three inner products of source i
 __global__ void gm_pts_final_kernel(int nblocks, int M, const float *part, const float *l1_part, float *regs) {
   // one wave: every quantity is summed by the 64 lanes striding over the blocks (4 independent loads in flight per

@@ -269,3 +269,50 @@ def test_device_resident_parameter_history(ctx, n, E, free):
         j.close()
     assert rows[0].shape == rows[1].shape and rows[0].shape[0] == T
     np.testing.assert_array_equal(rows[0], rows[1])
+
+
+@pytest.mark.parametrize('E,M,n', [(6, 2, 64), (5, 3, 32), (4, 2, 128)])
+def test_point_source_term_behind_the_all_reduce_in_one_launch(ctx, E, M, n):
+    """The step-by-step / sharded drive evaluates the point-source starlet term behind the all-reduce (it needs the mean
+    fluxes of ALL ranks): the background part stays with the chain on the second stream, the term itself is one launch
+    (gm_pts_direct_kernel: Pbar, scale-0 starlet, l1 sub-gradient, exact adjoint and the inner products on 16 x 16 tiles).
+    Against the twelve-launch form of the same term (LCMI_PTS_CHAIN=1) and against the device loop of one GPU, which
+    evaluates it with the matrix-core chain: same arithmetic in other orders, so equal to rounding."""
+    import os
+    from lightcurver_amd.joint import JointFit
+    from lightcurver_amd.synthetic import make_roi_dataset
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=300 + n)
+    T = 12
+
+    def run(stepwise, env=None):
+        os.environ.update(env or {})
+        try:
+            j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], 2, M, ctx)
+            p = dict(ds['truth'])
+            p['a'] = np.asarray(p['a']) * 0.9
+            j.set_params(**p)
+            j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.05, lam_flux_uniformity=10.0)
+            j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
+            if stepwise:
+                for _ in range(T):
+                    j.step_local()
+                    j.step_update(init_learning_rate=1e-3, schedule_learning_rate=False)
+            else:
+                j.run_adabelief(T, init_learning_rate=1e-3, schedule_learning_rate=False)
+            out = (np.asarray(j.loss_history(), np.float64), j.get_params())
+            j.close()
+            return out
+        finally:
+            for k in (env or {}):
+                os.environ.pop(k, None)
+
+    h_direct, p_direct = run(True)
+    h_chain, p_chain = run(True, {'LCMI_PTS_CHAIN': '1'})
+    h_loop, p_loop = run(False)
+    scale = np.abs(h_loop).max()
+    assert np.abs(h_direct - h_chain).max() <= 2e-6 * scale
+    assert np.abs(h_direct - h_loop).max() <= 2e-5 * scale
+    for k in ('a', 'c_x', 'c_y', 'dx', 'dy'):
+        ref = max(np.abs(p_loop[k]).max(), 1e-3)
+        assert np.abs(p_direct[k] - p_chain[k]).max() <= 2e-5 * ref, k
+        assert np.abs(p_direct[k] - p_loop[k]).max() <= 2e-4 * ref, k
