@@ -497,8 +497,9 @@ def star_photometry_workload(ctx, iters=2000, with_cpu=True):
     return out
 
 
-def sharded_joint_fit(ctx, rank, world, iters=500, transport='collective'):
-    """C4's 200 epochs sharded over the ranks; the shared block is all-reduced every iteration - in place by RCCL
+def sharded_joint_fit(ctx, rank, world, iters=500, transport='collective', config='C4'):
+    """C4's 200 epochs (or, config='C5', BASELINE.json configs[4]: 1000 epochs of 128 x 128 with 4 sources, the joint fit
+    that needs the eight GPUs) sharded over the ranks; the shared block is all-reduced every iteration - in place by RCCL
     (transport 'collective'; gloo staged through the host in the one-GPU rehearsal) or by the library's one-shot
     peer-memory kernel over HIP IPC (transport 'peer', csrc/peer.hip); the loop runs in C++ (lc_joint_run_sharded).
     Strong scaling: the total work is fixed."""
@@ -508,8 +509,8 @@ def sharded_joint_fit(ctx, rank, world, iters=500, transport='collective'):
     from lightcurver_amd.distributed import PeerGroup, ShardedJointOptimizer, shard_epochs
     from lightcurver_amd.joint import JointFit
     from lightcurver_amd.synthetic import make_roi_dataset
-    E, n, M, ss = 200, 64, 2, 2
-    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=104)  # same seed on every rank: identical full problem
+    E, n, M, ss, seed = (1000, 128, 4, 2, 105) if config == 'C5' else (200, 64, 2, 2, 104)
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=seed)  # same seed on every rank: identical full problem
     lo, hi = shard_epochs(E, world, rank)
 
     def all_ranks(step, fn):
@@ -572,7 +573,7 @@ def sharded_joint_fit(ctx, rank, world, iters=500, transport='collective'):
     transport = {'peer': 'one-shot peer-memory all-reduce (HIP IPC, every rank reads the others directly)',
                  'rccl': 'RCCL all-reduce in place in device memory',
                  'gloo': 'gloo all-reduce staged through the host (one-GPU rehearsal)'}[kind]
-    return {'workload': f'C4 sharded: {E} epochs x {n}x{n} ROI over {world} ranks, {transport} of the shared block '
+    return {'workload': f'{config} sharded: {E} epochs x {n}x{n} ROI over {world} ranks, {transport} of the shared block '
                         f'({n * ss * n * ss + 4 * M + 2} floats) once per iteration, {iters} iterations',
             'value': E * iters / dt, 'unit': 'cutouts/sec', 'us_per_iteration': dt * 1e6 / iters, 'scaling': 'strong',
             # what RCCL saw: the size of the nccl group the block was reduced over, 0 when the collective was gloo's
@@ -671,7 +672,7 @@ def main():
     finite = bool(np.all(np.isfinite(hist)))
     res = b.results()
 
-    sharded = sharded_peer = None
+    sharded = sharded_peer = sharded_c5 = None
     if world > 1 and not args.no_sharded_joint:
         try:
             sharded = sharded_joint_fit(ctx, rank, world)
@@ -681,6 +682,10 @@ def main():
             sharded_peer = sharded_joint_fit(ctx, rank, world, transport='peer')
         except Exception as e:
             sharded_peer = {'error': repr(e)}
+        try:   # C5, the configuration sharding is for: 1000 epochs of 128 x 128 (one GPU alone: ~1.54 ms per iteration)
+            sharded_c5 = sharded_joint_fit(ctx, rank, world, iters=100, transport='peer', config='C5')
+        except Exception as e:
+            sharded_c5 = {'error': repr(e)}
 
     if rank == 0:
         value = F * S * world * ITERS_PER_STEP * args.steps / elapsed
@@ -752,6 +757,8 @@ def main():
             out['config']['rccl_ranks'] = sharded.get('rccl_ranks')
         if sharded_peer is not None:
             out['config']['sharded_joint_fit_peer'] = sharded_peer
+        if sharded_c5 is not None:
+            out['config']['sharded_joint_fit_c5_peer'] = sharded_c5
         if not args.no_cpu_baseline and world == 1:
             try:
                 out['cpu_baseline'] = cpu_baseline(ds, weight, b, stars0, ss)
