@@ -328,6 +328,7 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
         if (rc) return rc;
       }
       JointPsArgs P;
+      std::memset(&P, 0, sizeof(P));  // (fields a launch does not use are passed as zeros, not as stack contents)
       P.J = A;
       P.psf = j->psf_dev;
       P.F = j->psF;
@@ -1378,6 +1379,7 @@ static int run_adabelief_persistent(lc_joint *j, int n_iter, const lc_adabelief_
   DevGuard g2{d_hist_e};
   LC_HIP(j->ctx, hipMemcpyAsync(d_sched, sched.data(), sched.size() * sizeof(float), hipMemcpyHostToDevice, q));
   JointPsArgs P;
+  std::memset(&P, 0, sizeof(P));  // (fields a launch does not use are passed as zeros, not as stack contents)
   std::memset(&P, 0, sizeof(P));
   JointArgs &A = P.J;
   A.E = j->E;
