@@ -261,6 +261,11 @@ int lc_joint_get_flux_reference(lc_joint *j, float *ref, int count /* = M */);
 int lc_joint_step_local(lc_joint *j);                      /* forward/backward of local epochs */
 int lc_joint_shared_buffer_dev(lc_joint *j, void **dev_ptr, int *count);
 int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg); /* regularise + AdaBelief */
+/* The gradient-only counterpart of lc_joint_step_update (the sharded L-BFGS stage: roi_modelling.py:278-280 with the epochs
+ * spread over ranks): behind lc_joint_step_local and the all-reduce of the shared block it returns the loss of the WHOLE fit
+ * and the gradients - those of the shared parameters complete, those of the per-epoch parameters for the local epochs -
+ * without stepping anything.  grads as in lc_joint_loss_grad. */
+int lc_joint_step_grad(lc_joint *j, float *loss, float *const grads[LC_P_COUNT]);
 /* host-staged access to the shared block (gloo / CPU collectives: D2H, all-reduce, H2D) */
 int lc_joint_shared_get(lc_joint *j, float *host, int count);
 int lc_joint_shared_set(lc_joint *j, const float *host, int count);

@@ -110,6 +110,7 @@ SIGNATURES = {
     'lc_joint_step_local': (C.c_int, [vp]),
     'lc_joint_shared_buffer_dev': (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int)]),
     'lc_joint_step_update': (C.c_int, [vp, C.POINTER(AdabeliefCfg)]),
+    'lc_joint_step_grad': (C.c_int, [vp, fp, C.POINTER(fp)]),
     'lc_joint_shared_get': (C.c_int, [vp, fp, C.c_int]),
     'lc_joint_shared_set': (C.c_int, [vp, fp, C.c_int]),
     'lc_joint_run_sharded': (C.c_int, [vp, C.c_int, C.POINTER(AdabeliefCfg), C.c_void_p, vp]),

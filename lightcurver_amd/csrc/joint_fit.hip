@@ -1284,6 +1284,27 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   return LC_OK;
 }
 
+int lc_joint_step_grad(lc_joint *j, float *loss, float *const grads[LC_P_COUNT]) {
+  if (!j) return LC_ERR_INVALID;
+  LC_ENTER(j->ctx);
+  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_step_grad: not available on a batched star-photometry object");
+  if (j->reg_pending) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
+  int rc = launch_update(j, 0, 0, nullptr, false, true, j->reg_pending ? 2 : 0);
+  if (rc) return rc;
+  LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));  // (the next lc_joint_step_local's chain waits for this one)
+  j->reg_pending = false;
+  j->fuse_pending = false;
+  j->fuse_full = false;
+  j->fuse_stencil = false;
+  j->pts_pending = false;
+  if (loss && (rc = d2h(j, loss, j->out_loss, sizeof(float)))) return rc;
+  if (grads)
+    for (int k = 0; k < LC_P_COUNT; ++k)
+      if (grads[k] && k != LC_P_ALPHA && (rc = d2h(j, grads[k], j->gout[k], (size_t)j->psize[k] * sizeof(float)))) return rc;
+  LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+  return LC_OK;
+}
+
 int lc_joint_run_sharded(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg, lc_allreduce_fn allreduce, void *user) {
   if (!j || n_iter < 0 || !allreduce) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);

@@ -230,6 +230,111 @@ class ShardedJointOptimizer:
             self.fit.step_update(**adabelief_cfg)
 
 
+PER_EPOCH = ('a', 'dx', 'dy', 'mean')     # blocks whose entries belong to one epoch (a: M per epoch)
+
+
+def sharded_lbfgs(optimizer, free, maxiter, lower=None, upper=None):
+    """The L-BFGS-B stage of the two-stage fit (reference lightcurver/processes/roi_modelling.py:278-280: positions, fluxes
+    and shifts with the background held) with the epochs spread over the ranks of ``optimizer`` (a ShardedJointOptimizer).
+
+    Every rank runs the same scipy L-BFGS-B on the FULL vector [shared blocks | per-epoch blocks of all epochs]; an evaluation
+    is local forward/backward (step_local), the all-reduce of the shared block the AdaBelief loop also uses, and
+    lc_joint_step_grad: the loss of the whole fit and the gradients of the shared parameters come out complete and identical
+    on every rank, the gradients of the per-epoch parameters for the local epochs - those are all-gathered.  Same numbers in,
+    same iterates on all ranks.  Returns (loss history per accepted iterate, scipy result); the fit holds the final point.
+
+    lower / upper: dicts name -> scalar or array over the rank's LOCAL entries of that block (missing = unbounded)."""
+    import torch
+    import torch.distributed as dist
+    from scipy.optimize import minimize
+    fit, group = optimizer.fit, optimizer.group
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    free = [k for k in ('c_x', 'c_y', 'h', 'a', 'dx', 'dy', 'mean') if k in free]
+    fit.set_free(free)
+    optimizer._agree_flux_reference()
+    # (set_params(a=...) re-centres the flux moments on the LOCAL mean flux: every evaluation puts the agreed reference back)
+    ref = fit.get_flux_reference() if hasattr(fit, 'get_flux_reference') else None
+    M = fit.M
+    cur = {k: np.asarray(v, np.float64) for k, v in fit.get_params().items()}
+
+    def gather(vec):
+        """local per-epoch block -> the block of all epochs, in rank order"""
+        if world == 1:
+            return np.asarray(vec, np.float64)
+        parts = [None] * world
+        dist.all_gather_object(parts, np.asarray(vec, np.float64), group=group)
+        return np.concatenate(parts)
+
+    sizes_local = {k: cur[k].size for k in free}
+    full = {k: (gather(cur[k]) if k in PER_EPOCH else cur[k]) for k in free}
+    offs, n = {}, 0
+    for k in free:
+        offs[k] = (n, n + full[k].size)
+        n += full[k].size
+    # where the rank's own entries sit inside the gathered per-epoch blocks
+    counts = [None] * world
+    if world > 1:
+        dist.all_gather_object(counts, int(fit.E), group=group)
+    else:
+        counts = [int(fit.E)]
+    rank = dist.get_rank(group) if world > 1 else 0
+    e0 = int(sum(counts[:rank]))
+
+    def own(k):
+        per = M if k == 'a' else 1
+        return slice(e0 * per, (e0 + fit.E) * per)
+
+    def bound(table, fill):
+        out = np.full(n, fill)
+        for k in free:
+            if table and k in table:
+                loc = np.broadcast_to(np.asarray(table[k], np.float64), (sizes_local[k],))
+                out[offs[k][0]:offs[k][1]] = gather(loc) if k in PER_EPOCH else loc
+        return out
+
+    lo, hi = bound(lower, -np.inf), bound(upper, np.inf)
+    x0 = np.concatenate([full[k] for k in free]) if free else np.zeros(0)
+    hist, last = [], {}
+
+    def fun(x):
+        p = {}
+        for k in free:
+            blk = x[offs[k][0]:offs[k][1]]
+            p[k] = blk[own(k)] if k in PER_EPOCH else blk
+        fit.set_params(**p)
+        if ref is not None:
+            fit.set_flux_reference(ref)
+        fit.step_local()
+        if optimizer.peer is not None:
+            import ctypes as C
+            fn, user = optimizer.peer.callback()
+            ptr, count = fit.shared_buffer()
+            stream, _ = fit.ctx.stream()
+            rc = optimizer.peer._l.lc_peer_allreduce(user, C.c_void_p(ptr), count, C.c_void_p(stream))
+            if rc:
+                raise RuntimeError(f'lc_peer_allreduce failed ({rc})')
+        elif optimizer._device_collective():
+            optimizer.all_reduce_device()
+        else:
+            fit.shared_set(optimizer.all_reduce(fit.shared_get()))
+        loss, g = fit.step_grad(tuple(free))
+        grad = np.concatenate([gather(g[k]) if k in PER_EPOCH else np.asarray(g[k], np.float64) for k in free])
+        last['x'], last['val'] = np.array(x, copy=True), float(loss)
+        return float(loss), grad
+
+    def record(xk):
+        hist.append(last['val'] if 'x' in last and np.array_equal(last['x'], xk) else fun(xk)[0])
+
+    res = minimize(fun, x0, jac=True, method='L-BFGS-B', bounds=list(zip(lo, hi)), callback=record,
+                   options=dict(maxiter=int(maxiter)))
+    fun(res.x)   # the fit holds the final point (and its loss is the last evaluation)
+    return np.asarray(hist, np.float64), res
+
+
+ShardedJointOptimizer.run_lbfgs = lambda self, free, maxiter, lower=None, upper=None: sharded_lbfgs(self, free, maxiter, lower, upper)
+ShardedJointOptimizer.run_lbfgs.__doc__ = 'The L-BFGS-B stage on the sharded fit: see sharded_lbfgs.'
+
+
 def gather_epoch_blocks(local_flat, n_sources, group=None):
     """All-gather the per-epoch parameters so that every rank holds the full kwargs again."""
     import torch.distributed as dist

@@ -100,6 +100,17 @@ class JointFit:
         self._chk(self._l.lc_joint_loss_grad(self.h, C.byref(loss), arr), 'loss_grad')
         return loss.value, bufs
 
+    def step_grad(self, names=('a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean')):
+        """Behind step_local() and the all-reduce of the shared block: loss of the whole fit and gradients (shared parameters
+        complete, per-epoch parameters for the local epochs), nothing stepped - lc_joint_step_grad."""
+        loss = C.c_float()
+        bufs = {k: np.empty(self.sizes[k], np.float32) for k in names}
+        arr = (_lib.fp * P_COUNT)()
+        for k, b in bufs.items():
+            arr[PARAM_INDEX[k]] = ptr(b)
+        self._chk(self._l.lc_joint_step_grad(self.h, C.byref(loss), arr), 'step_grad')
+        return loss.value, bufs
+
     def model(self):
         m = np.empty((self.E, self.n, self.n), np.float32)
         chi2 = np.empty(self.E, np.float32)

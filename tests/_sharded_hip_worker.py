@@ -32,8 +32,22 @@ def main():
     j.set_params(**shard_kwargs(p, E, M, world, rank))
     j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
     j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
-    peer = PeerGroup(j) if transport == 'peer' else None
+    lbfgs = transport.startswith('lbfgs')     # 'lbfgs' / 'lbfgs-peer': the sharded L-BFGS-B stage instead of the AdaBelief loop
+    peer = PeerGroup(j) if transport in ('peer', 'lbfgs-peer') else None
     opt = ShardedJointOptimizer(j, peer=peer)
+    if lbfgs:
+        from lightcurver_amd.distributed import sharded_lbfgs
+        hist_l, res = sharded_lbfgs(opt, ['a', 'c_x', 'c_y', 'dx', 'dy'], T, lower={'a': 0.0})
+        ctx.synchronize()
+        full = gather_epoch_blocks(j.get_params(), M)
+        if rank == 0:
+            np.savez(out, hist=hist_l, fun=float(res.fun), nit=int(res.nit), **{'p_' + k: v for k, v in full.items()})
+        dist.barrier()
+        if peer is not None:
+            peer.close()
+        j.close()
+        dist.destroy_process_group()
+        return
     opt.run(T // 2, init_learning_rate=1e-3)
     opt.run(T - T // 2, init_learning_rate=1e-3)     # a second run continues the first (flux reference agreed again)
     ctx.synchronize()
