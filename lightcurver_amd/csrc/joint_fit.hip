@@ -437,7 +437,7 @@ int launch_reg_gm(lc_joint *j, hipStream_t stream, bool with_pts, bool abar_from
     float *part = j->gm_pts + 8, *l1p = j->gm_l1 + (size_t)J * nb;
     hipLaunchKernelGGL(gm_pts_direct_kernel, dim3((N / kPtT) * (N / kPtT)), block, 0, stream, N, j->ss, j->M, j->a_ref, j->shared,
                        j->par[LC_P_CX], j->par[LC_P_CY], W, j->norms, j->cfg.lam_pts_source, part, l1p);
-    hipLaunchKernelGGL(gm_pts_final_kernel, dim3(1), dim3(64), 0, stream, (N / kPtT) * (N / kPtT), j->M, part, l1p, j->regs);
+    hipLaunchKernelGGL(gm_pts_final_kernel, dim3(1), dim3(1024), 0, stream, (N / kPtT) * (N / kPtT), j->M, part, l1p, j->regs);
   } else if (with_pts) {
     // point-source starlet term: scale 0 only, on Pbar (the work buffers of the chain above are free again)
     float *abar = j->gm_pts, *part = j->gm_pts + 8, *qp = j->qscr + (size_t)J * NN, *l1p = j->gm_l1 + (size_t)J * nb;
@@ -452,7 +452,7 @@ int launch_reg_gm(lc_joint *j, hipStream_t stream, bool with_pts, bool abar_from
     hipLaunchKernelGGL(gm_edge_kernel, dim3(N), dim3(64), 0, stream, N, 1, 1, j->gm_t, j->gm_edge);
     hipLaunchKernelGGL(gm_pass_adjoint_kernel, grid, block, 0, stream, N, 1, 1, j->gm_t, j->gm_edge, (const float *)nullptr, j->gm_y);
     hipLaunchKernelGGL(gm_pts_inner_kernel, grid, block, 0, stream, N, j->ss, j->M, qp, j->gm_y, j->par[LC_P_CX], j->par[LC_P_CY], part);
-    hipLaunchKernelGGL(gm_pts_final_kernel, dim3(1), dim3(64), 0, stream, nb, j->M, part, l1p, j->regs);
+    hipLaunchKernelGGL(gm_pts_final_kernel, dim3(1), dim3(1024), 0, stream, nb, j->M, part, l1p, j->regs);
   }
   LC_HIP(j->ctx, hipGetLastError());
   return LC_OK;

@@ -317,10 +317,11 @@ __global__ __launch_bounds__(kGmThreads) void gm_pts_direct_kernel(int N, int ss
 
 // ordered final sums -> regs[2] = value of the term, regs[4 + 3 i + q] = the three inner products of source i
 __global__ void gm_pts_final_kernel(int nblocks, int M, const float *part, const float *l1_part, float *regs) {
-  // one wave: every quantity is summed by the 64 lanes striding over the blocks (4 independent loads in flight per
-  // lane), then across the lanes in a fixed order - the serial loop of one thread per quantity cost 60 us at 256 blocks
-  const int lane = threadIdx.x;
-  for (int t = 0; t <= 3 * M; ++t) {
+  // one wave per quantity (the waves of the block take the 3 M + 1 quantities in turn): the 64 lanes stride over the blocks
+  // (4 independent loads in flight per lane), then across the lanes in a fixed order - the serial loop of one thread per
+  // quantity cost 60 us at 256 blocks, one wave for all of them 11.6 us (it sits behind the all-reduce of a sharded fit)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int t = wid; t <= 3 * M; t += nw) {
     float acc = 0.f;
     for (int b = lane; b < nblocks; b += 64) acc += (t < 3 * M) ? part[(size_t)b * 3 * kMaxSources + t] : l1_part[b];
     acc = wave_sum_shfl(acc);
