@@ -228,8 +228,12 @@ class Context:
             self.h = None
 
     def __del__(self):
+        # (not while the interpreter shuts down: objects are then torn down in no particular order, and destroying a device
+        #  object whose context has already gone is a crash at exit; the process is about to return everything anyway)
         try:
-            self.close()
+            import sys
+            if not sys.is_finalizing():
+                self.close()
         except Exception:
             pass
 

@@ -135,6 +135,91 @@ def model_roi_cutouts(data, noisemap, psf, subsampling_factor, xs_pixels, ys_pix
                 data=data, noisemap=noisemap, x_pixels=x_pix, y_pixels=y_pix, W=W)
 
 
+def model_roi_cutouts_sharded(data, noisemap, psf, subsampling_factor, xs_pixels, ys_pixels, initial_a, scale,
+                              group=None, use_peer=False, regularization=None, roi_deconv_translations_iters=300,
+                              roi_deconv_all_iters=2000, further_optimize_background=True, ctx=None):
+    """The two-stage fit of ``model_roi_cutouts`` with the epochs spread over the ranks of a torch.distributed group (one
+    process per GPU): every rank passes ITS epochs - data, noisemap (E_local, n, n), psf (E_local, N, N) - and the same
+    ``initial_a`` (M fluxes) and ``scale`` (nanmax of the data of ALL epochs: ``global_scale``).  The reference has no
+    counterpart (it keeps all epochs on one device, roi_modelling.py:154-160,213); this is what BASELINE configs[4] (1000
+    epochs of 128 x 128 over eight GPUs) runs.
+
+    Stage 1: fluxes and translations by L-BFGS-B (``distributed.sharded_lbfgs``: scipy on every rank, the evaluations sharded);
+    noise propagation: every rank its epochs, the levels added in quadrature over the ranks; stage 2: AdaBelief on everything
+    but the rotation (``ShardedJointOptimizer.run``: the loop in C++, one all-reduce of the shared block per iteration,
+    ``use_peer``: by the one-shot peer-memory kernel).  Returns, on every rank, the parameters of ALL epochs (gathered), the
+    loss histories and the Fisher 1-sigma of the fluxes at the final point."""
+    import torch
+    import torch.distributed as dist
+    from ..distributed import PeerGroup, ShardedJointOptimizer, gather_epoch_blocks
+    from ..joint import JointFit
+    from .. import _lib
+    reg = dict(DEFAULT_REGULARIZATION)
+    reg.update(regularization or {})
+    data = np.array(data, dtype=np.float64) / scale
+    noisemap = np.array(noisemap, dtype=np.float64) / scale
+    E, n, _ = data.shape
+    xs = np.atleast_1d(np.asarray(xs_pixels, dtype=np.float64))
+    ys = np.atleast_1d(np.asarray(ys_pixels, dtype=np.float64))
+    M, ss = xs.size, int(subsampling_factor)
+    offset = (n - 1) / 2.0
+    fit = JointFit(data, noisemap ** 2, psf, ss, M, ctx or _lib.default_context())
+    peer = None
+    try:
+        fit.set_params(a=np.tile(np.asarray(initial_a, np.float64) / scale, E), c_x=xs - offset, c_y=ys - offset, dx=np.zeros(E),
+                       dy=np.zeros(E), alpha=np.zeros(E), h=np.zeros((n * ss) ** 2), mean=np.zeros(E))
+        peer = PeerGroup(fit, group) if use_peer else None
+        opt = ShardedJointOptimizer(fit, group, peer=peer)
+        # ---- stage 1: translations + fluxes (roi_modelling.py:259-282) ----------------------------------------------
+        fit.set_loss(lam_flux_uniformity=reg['regularization_scatter_fluxes_pre_optim'])
+        half = n / 2.0
+        hist1, _ = opt.run_lbfgs(['a', 'dx', 'dy'], int(roi_deconv_translations_iters), lower={'a': 0.0, 'dx': -half, 'dy': -half},
+                                 upper={'dx': half, 'dy': half})
+        # ---- noise levels of the starlet coefficients: the epochs add in quadrature, over the ranks too -----------------
+        W2 = torch.from_numpy(np.square(fit.propagate_noise().astype(np.float64)))
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            if dist.get_backend(group) == 'nccl':
+                W2 = W2.to(torch.device('cuda', fit.ctx.stream()[1]))
+            dist.all_reduce(W2, op=dist.ReduceOp.SUM, group=group)
+            W2 = W2.cpu()
+        W = np.sqrt(W2.numpy())
+        # ---- stage 2: everything but the rotation (roi_modelling.py:284-335) -------------------------------------------
+        fit.set_loss(W=W, lam_scales=reg['regularization_strength_scales'], lam_hf=reg['regularization_strength_hf'],
+                     lam_positivity=reg['regularization_strength_positivity'],
+                     lam_pts_source=reg['regularization_strength_pts_source'],
+                     lam_flux_uniformity=reg['regularization_scatter_fluxes_main_optim'])
+        fit.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean'] + (['h'] if further_optimize_background else []))
+        opt.run(int(roi_deconv_all_iters), init_learning_rate=1e-4, schedule_learning_rate=False)
+        fit.ctx.synchronize()
+        final = gather_epoch_blocks(fit.get_params(), M, group)
+        sigma_loc = np.asarray(fit.fisher_flux_sigma(), np.float64)
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            parts = [None] * dist.get_world_size(group)
+            dist.all_gather_object(parts, sigma_loc, group=group)
+            sigma = np.concatenate(parts)
+        else:
+            sigma = sigma_loc
+        # (the entry lc_joint_get_loss_history appends for the final parameters is a local evaluation: dropped)
+        return dict(flat_final=final, loss_history=np.asarray(fit.loss_history(), np.float64)[:-1], loss_history_stage1=hist1,
+                    fluxes_sigma=sigma, scale=scale, W=W)
+    finally:
+        if peer is not None:
+            peer.close()
+        fit.close()
+
+
+def global_scale(data, group=None):
+    """nanmax of the data over the epochs of all ranks (what ``model_roi_cutouts`` divides by, roi_modelling.py:176)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(np.nanmax(data))], dtype=torch.float64)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == 'nccl':
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t[0])
+
+
 def fluxes_from_model(model, kwargs, kwargs_up, kwargs_down, data, noisemap, n_sources, model_scale,
                       normalization_errors):
     """Numeric part of get_fluxes_dataframe_from_model (roi_modelling.py:450-474): per-source light

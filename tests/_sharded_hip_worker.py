@@ -28,6 +28,21 @@ def main():
     p['a'] = p['a'] * 0.9
     lo, hi = shard_epochs(E, world, rank)
     ctx = _lib.Context(0)
+    if transport.startswith('roi'):   # 'roi' / 'roi-peer': the whole two-stage fit, sharded (processes/roi_modelling.py)
+        from lightcurver_amd.processes.roi_modelling import global_scale, initial_point_source_fluxes, model_roi_cutouts_sharded
+        off = (n - 1) / 2.0
+        xs, ys = np.asarray(ds['truth']['c_x']) + off, np.asarray(ds['truth']['c_y']) + off
+        scale = global_scale(ds['data'][lo:hi])
+        a0 = initial_point_source_fluxes(ds['data'] / scale, xs, ys, 3.0)     # (every rank from the full stack: same numbers)
+        res = model_roi_cutouts_sharded(ds['data'][lo:hi], ds['noisemap'][lo:hi], ds['psf'][lo:hi], ss, xs, ys,
+                                        np.asarray(a0) * scale, scale, use_peer=(transport == 'roi-peer'),
+                                        roi_deconv_translations_iters=T, roi_deconv_all_iters=300, ctx=ctx)
+        if rank == 0:
+            np.savez(out, hist=res['loss_history'], hist1=res['loss_history_stage1'], sigma=res['fluxes_sigma'], scale=res['scale'],
+                     **{'p_' + k: v for k, v in res['flat_final'].items()})
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     j = JointFit(ds['data'][lo:hi], ds['noisemap'][lo:hi].astype(np.float64) ** 2, ds['psf'][lo:hi], ss, M, ctx)
     j.set_params(**shard_kwargs(p, E, M, world, rank))
     j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)

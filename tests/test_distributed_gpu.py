@@ -201,3 +201,54 @@ def test_sharded_lbfgs_stage_equals_the_one_object_stage(ctx, tmp_path):
     assert np.abs(g['p_a'] - xs['a']).max() <= 2e-2 * np.abs(xs['a']).max()
     for k in ('c_x', 'c_y', 'dx', 'dy'):
         assert np.abs(g['p_' + k] - xs[k]).max() <= 2e-2, k
+
+
+def test_sharded_two_stage_roi_fit_equals_the_one_object_fit(ctx, tmp_path):
+    """processes/roi_modelling.model_roi_cutouts_sharded on two ranks (each its half of the epochs: sharded L-BFGS-B stage, noise
+    levels added in quadrature over the ranks, sharded AdaBelief stage, parameters gathered) against model_roi_cutouts on all
+    epochs in one object.  Stage 1 is scipy's L-BFGS-B there and the device L-BFGS here - two optimisers at the same optimum
+    level - so the comparison is at that level; the two transports of the sharded fit are bit-identical."""
+    import os
+    import subprocess
+    import sys
+    from lightcurver_amd.processes.roi_modelling import model_roi_cutouts
+    E, M, n, ss, T = 12, 2, 32, 2, 120
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=4242)
+    off = (n - 1) / 2.0
+    xs, ys = np.asarray(ds['truth']['c_x']) + off, np.asarray(ds['truth']['c_y']) + off
+    one = model_roi_cutouts(ds['data'].copy(), ds['noisemap'].copy(), ds['psf'], ss, xs, ys, roi_deconv_translations_iters=T,
+                            roi_deconv_all_iters=300)
+    from lightcurver_amd.starred.deconvolution.deconvolution import flatten_kwargs
+    pf = {k: np.asarray(v, np.float64) for k, v in flatten_kwargs(one['kwargs_final']).items()}
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_sharded_hip_worker.py')
+    results = {}
+    for transport in ('roi', 'roi-peer'):
+        out = tmp_path / f'sharded_{transport}.npz'
+        for attempt in range(2):
+            port = _free_port()
+            procs = []
+            for r in range(2):
+                env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                           HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+                procs.append(subprocess.Popen([sys.executable, worker, str(out), str(E), str(M), str(n), str(T), transport], env=env))
+            codes = [pr.wait(timeout=600) for pr in procs]
+            if codes == [0, 0]:
+                break
+        assert codes == [0, 0], (transport, codes)
+        results[transport] = np.load(out)
+    g, gp = results['roi'], results['roi-peer']
+    for k in g.files:
+        np.testing.assert_array_equal(gp[k], g[k], err_msg=k)
+    assert abs(float(g['scale']) - one['scale']) <= 1e-12 * one['scale']
+    h1, h = np.asarray(one['loss_history'], np.float64), g['hist']
+    print('loss', h[-1], h1[len(h) - 1], 'flux diff', np.abs(g['p_a'] - pf['a']).max() / np.abs(pf['a']).max(),
+          'pos diff', max(np.abs(g['p_' + k] - pf[k]).max() for k in ('c_x', 'c_y', 'dx', 'dy')))
+    assert len(h) == 300 and abs(h[-1] - h1[len(h) - 1]) <= 2e-3 * abs(h1[len(h) - 1])
+    # (measured: loss 7068.48 against 7067.06, fluxes within 1.1 %, positions within 0.012 px - the two stage-1 optimisers stop
+    #  at different points of a valley that is flat in flux against background and in c against the shifts)
+    assert np.abs(g['p_a'] - pf['a']).max() <= 3e-2 * np.abs(pf['a']).max()
+    for c, d in (('c_x', 'dx'), ('c_y', 'dy')):   # the position of every source in every epoch: c + shift
+        pos_s = g['p_' + c][None, :] + g['p_' + d][:, None]
+        pos_1 = pf[c][None, :] + pf[d][:, None]
+        assert np.abs(pos_s - pos_1).max() <= 3e-2, c
+    assert np.all(np.isfinite(g['sigma'])) and g['sigma'].shape == (E * M,) and np.all(g['sigma'] > 0)
