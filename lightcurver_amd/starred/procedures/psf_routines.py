@@ -182,14 +182,15 @@ DISTORTION_BOUND = 0.2   # |coefficient| <= 0.2: the resampling kernels assume a
 
 
 def quadratic_forms(theta, xy, ss):
-    """(fwhm_x, fwhm_y, phi, beta, 9 distortion coefficients) [F][13] and star coordinates [F][S][2] ->
-    q [F][S][4] = (q11, q12, q22, beta) of the Moffat each star sees: Q_i = A_i^-T Q A_i^-1 (csrc/psf_distort.h)."""
-    fx, fy, phi, beta = theta[:, 0, None], theta[:, 1, None], theta[:, 2, None], theta[:, 3, None]
-    c = theta[:, 4:13]
+    """(fwhm_x, fwhm_y, phi, beta, 9 distortion coefficients) [..., F, 13] and star coordinates [F][S][2] ->
+    q [..., F, S, 4] = (q11, q12, q22, beta) of the Moffat each star sees: Q_i = A_i^-T Q A_i^-1 (csrc/psf_distort.h).
+    Leading axes of theta (a batch of parameter sets, e.g. the 26 perturbed copies of a central-difference Jacobian) broadcast."""
+    fx, fy, phi, beta = theta[..., 0, None], theta[..., 1, None], theta[..., 2, None], theta[..., 3, None]
+    c = theta[..., 4:13]
     x, y = xy[..., 0], xy[..., 1]
-    a00 = 1.0 + c[:, 0, None] + c[:, 1, None] * x + c[:, 2, None] * y
-    a11 = 1.0 + c[:, 3, None] + c[:, 4, None] * x + c[:, 5, None] * y
-    a01 = c[:, 6, None] + c[:, 7, None] * x + c[:, 8, None] * y
+    a00 = 1.0 + c[..., 0, None] + c[..., 1, None] * x + c[..., 2, None] * y
+    a11 = 1.0 + c[..., 3, None] + c[..., 4, None] * x + c[..., 5, None] * y
+    a01 = c[..., 6, None] + c[..., 7, None] * x + c[..., 8, None] * y
     det = a00 * a11 - a01 * a01
     i00, i01, i11 = a11 / det, -a01 / det, a00 / det
     kb = 2.0 * np.sqrt(2.0 ** (1.0 / beta) - 1.0)
@@ -203,7 +204,7 @@ def quadratic_forms(theta, xy, ss):
     m12 = i00 * q12 + i01 * q22
     m21 = i01 * q11 + i11 * q12
     m22 = i01 * q12 + i11 * q22
-    out = np.stack([m11 * i00 + m12 * i01, m11 * i01 + m12 * i11, m21 * i01 + m22 * i11, np.broadcast_to(beta, x.shape)], axis=-1)
+    out = np.stack([m11 * i00 + m12 * i01, m11 * i01 + m12 * i11, m21 * i01 + m22 * i11, np.broadcast_to(beta, m11.shape)], axis=-1)
     return out
 
 
@@ -265,14 +266,15 @@ def _fit_with_distortion(images, data, weight, norms, stars, moffat, S_list, coo
             gq = out['grad_moffat'].astype(np.float64).reshape(F, S, 4)
             gs = out['grad_stars'].astype(np.float64).reshape(F, S, 4)
             G = np.zeros((F, D))
-            # chain rule through the (smooth) map theta -> q by central differences in double
-            for k in range(13):
-                h = 1e-6 * max(1.0, float(np.abs(X[:, k]).max()))
-                Xp_, Xm_ = X[:, :13].copy(), X[:, :13].copy()
-                Xp_[:, k] += h
-                Xm_[:, k] -= h
-                dq = (quadratic_forms(Xp_, xy, ss) - quadratic_forms(Xm_, xy, ss)) / (2.0 * h)
-                G[:, k] = (gq * dq).sum(axis=(1, 2))
+            # chain rule through the (smooth) map theta -> q by central differences in double: the 13 + 13 perturbed parameter
+            # sets go through quadratic_forms as ONE batch (27 calls on 800-element arrays per evaluation were two thirds of
+            # the analytic stage of a C2-sized fit)
+            hs = 1e-6 * np.maximum(1.0, np.abs(X[:, :13]).max(axis=0))             # [13]
+            step = np.eye(13)[:, None, :] * hs[:, None, None]                       # [13][1][13]
+            both = np.concatenate([X[None, :, :13] + step, X[None, :, :13] - step])  # [26][F][13]
+            qb = quadratic_forms(both, xy, ss)                                       # [26][F][S][4]
+            dq = (qb[:13] - qb[13:]) / (2.0 * hs[:, None, None, None])
+            G[:, :13] = (gq[None] * dq).sum(axis=(2, 3)).T
             G[:, 13:13 + S], G[:, 13 + S:13 + 2 * S], G[:, 13 + 2 * S:] = gs[..., 0], gs[..., 1], gs[..., 2]
             np.ctypeslib.as_array(Fp, shape=(F,))[:] = out['loss'].astype(np.float64).reshape(F, S).sum(axis=1)
             np.ctypeslib.as_array(Gp, shape=(F, D))[:] = G
