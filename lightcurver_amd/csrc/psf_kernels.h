@@ -1069,26 +1069,42 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
           Bp[p] -= lr * (mn * bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(sn * bc2) + eps);
         }
       }
-      float4 *bp = (float4 *)(Bg + gpix);
-      float4 *mp = (float4 *)(mBg + gpix);
-      float4 *sp = (float4 *)(sBg + gpix);
+      // (state in global memory, PX > 8: every load of the thread's pixels before the first store - the three arrays may
+      //  alias as far as the compiler knows, so a loop of load / step / store per 16 bytes ran as PX / 4 dependent memory
+      //  round trips: C3 shard 85.2 -> 82.4 us per iteration.  What is left of the update's 27 k cycles is the traffic itself: the
+      //  126 workgroups of a shard move 48 MB of state at the same moment.  Measured and left out: the next iteration's
+      //  T = Moffat + B written to LDS from here instead of P1 re-reading B - 61 spilled registers instead of 36, 90.6 us)
+      if constexpr (!STATE_REGS) {
+        float4 *bp = (float4 *)(Bg + gpix);
+        float4 *mp = (float4 *)(mBg + gpix);
+        float4 *sp = (float4 *)(sBg + gpix);
+        float4 bq[PX / 4], mq[PX / 4], sq[PX / 4];
 #pragma unroll
-      for (int q = 0; q < (STATE_REGS ? 0 : PX / 4); ++q) {
-        float4 b = bp[q], m = mp[q], s = sp[q];
-        float *bb = &b.x, *mm = &m.x, *ss_ = &s.x;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float g = gB[4 * q + e] + z[4 * q + e];
-          const float mn = b1 * mm[e] + (1.f - b1) * g;
-          const float dg = g - mn;
-          const float sn = b2 * ss_[e] + (1.f - b2) * dg * dg + eps_root;
-          mm[e] = mn;
-          ss_[e] = sn;
-          bb[e] -= lr * (mn * bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(sn * bc2) + eps);
+        for (int q = 0; q < PX / 4; ++q) {
+          bq[q] = bp[q];
+          mq[q] = mp[q];
+          sq[q] = sp[q];
         }
-        bp[q] = b;
-        mp[q] = m;
-        sp[q] = s;
+#pragma unroll
+        for (int q = 0; q < PX / 4; ++q) {
+          float *bb = &bq[q].x, *mm = &mq[q].x, *ss_ = &sq[q].x;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float g = gB[4 * q + e] + z[4 * q + e];
+            const float mn = b1 * mm[e] + (1.f - b1) * g;
+            const float dg = g - mn;
+            const float sn = b2 * ss_[e] + (1.f - b2) * dg * dg + eps_root;
+            mm[e] = mn;
+            ss_[e] = sn;
+            bb[e] -= lr * (mn * bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(sn * bc2) + eps);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < PX / 4; ++q) {
+          bp[q] = bq[q];
+          mp[q] = mq[q];
+          sp[q] = sq[q];
+        }
       }
       if constexpr (!SPLIT) update_stars_and_taps(tid);  // (the two-workgroup form did this beside its hand-off)
     }

@@ -44,3 +44,11 @@ for blk, label in ((0, 'block 0 (role 0 / single form)'), (64, 'block 8 (role 1)
     if blk == 0 and s[20]:
         print('   waves done with their tasks, ticks after the first barrier:', [int(s[20 + w] - s[1]) for w in range(16) if s[20 + w]])
     print('  total ticks', tot, '(s_memtime ticks @100MHz => us:', tot / 100.0, ')')
+if len(sys.argv) > 2 and sys.argv[2] == 'groups':   # non-WC kernels (N = 128): the four passes of every group of stars
+    s = allst[:64]
+    print('group: P2 row pass | P3 column pass + chi2 | P4 transposed column | P5 transposed row   (ticks, block 0, last iteration)')
+    for g in range(8):
+        a = [s[1 + 5 * g], s[2 + 5 * g], s[3 + 5 * g], s[4 + 5 * g]]
+        nxt = s[1 + 5 * (g + 1)] if g < 7 and s[1 + 5 * (g + 1)] else s[40]
+        if a[0]:
+            print(f'  {g}: {a[1]-a[0]:7d} {a[2]-a[1]:7d} {a[3]-a[2]:7d} {nxt-a[3]:7d}')
