@@ -11,9 +11,15 @@ sep's defaults for everything the call leaves unset:
      threshold and the peak of the group; descending the levels, an island of pixels above a level that carries at least
      ``deblend_cont`` of the group's total flux becomes a branch, and a group with two or more branches at some level is
      split there; the remaining pixels join the branch whose peak is closest in (distance / branch size) units.
-Not restated: sep's ``clean`` pass (removal of detections that would vanish without their neighbours' wings) and the
-exact weighting of its pixel re-attribution; positions are flux-weighted barycentres of the filtered image.  Unpinned
-against sep itself (absent here); tests/test_host_logic_cpu.py checks the behaviour on synthetic blends."""
+  4. cleaning (sep ``clean=True``, ``clean_param=1.0``: SExtractor's CLEAN step): every detection is compared with its
+     brighter neighbours; a neighbour is modelled as a Moffat profile of index ``clean_param`` with the neighbour's
+     central amplitude, stretched to its second-moment ellipse and scaled so that it crosses the detection threshold
+     at the neighbour's isophotal area.  A detection that would not have reached ``minarea`` pixels above the
+     threshold without the wing of such a neighbour under it (wing at its position > excess of its ``minarea``-th
+     brightest pixel over the threshold) is merged into the neighbour that contributes most.
+Positions are the barycentres of the filtered image over the object's pixels (SExtractor's first moments; sep's ``x``,
+``y``).  Not restated: the exact weighting of sep's pixel re-attribution after a split.  Unpinned against sep itself
+(absent here); tests/test_host_logic_cpu.py checks the behaviour on synthetic blends."""
 import numpy as np
 from scipy import ndimage
 
@@ -78,7 +84,65 @@ def _deblend(snr, group, thresh, nthresh, cont, minarea):
     return out
 
 
-def extract(data, noisemap, thresh=3.0, minarea=15, deblend_nthresh=32, deblend_cont=0.001):
+CLEAN_ZONE = 10.0   # SExtractor: neighbours further than 10 (a_1 + a_2) are not compared
+
+
+def _shape(m, snr, thresh, minarea):
+    """Moments of one object on the filtered image (SExtractor's pre-analysis): centre, ellipse coefficients, isophotal
+    area, central amplitude of the equivalent Gaussian and the largest background the object would survive."""
+    yy, xx = np.nonzero(m)
+    v = snr[yy, xx]
+    tot = v.sum()
+    mx, my = (v * xx).sum() / tot, (v * yy).sum() / tot
+    x2 = max((v * xx * xx).sum() / tot - mx * mx, 1.0 / 12.0)      # (a pixel's own variance: SExtractor's floor)
+    y2 = max((v * yy * yy).sum() / tot - my * my, 1.0 / 12.0)
+    xy = (v * xx * yy).sum() / tot - mx * my
+    det = x2 * y2 - xy * xy
+    if det < 1.0 / 144.0:                                           # singular: a round object of that floor
+        xy, det = 0.0, x2 * y2
+    half, root = 0.5 * (x2 + y2), np.sqrt(max(0.25 * (x2 - y2) ** 2 + xy * xy, 0.0))
+    a, b = np.sqrt(half + root), np.sqrt(max(half - root, 1.0 / 12.0))
+    srt = np.sort(v)[::-1]
+    mthresh = float(srt[minarea - 1] - thresh) if srt.size >= minarea else 0.0
+    area = np.pi * a * b
+    return dict(mx=mx, my=my, a=a, cxx=y2 / det, cyy=x2 / det, cxy=-2.0 * xy / det, fdflux=float(tot), npix=int(v.size),
+                unitarea=area, amp=float(tot / (2.0 * area)), mthresh=max(mthresh, 0.0))
+
+
+def clean(masks, snr, thresh, minarea, clean_param=1.0):
+    """Merges every detection that only exists on the wing of a brighter neighbour into that neighbour.  masks: list of
+    boolean images; returns the surviving list (merged pixels added to their neighbour's mask)."""
+    if len(masks) < 2:
+        return masks
+    beta = float(clean_param)
+    sh = [_shape(m, snr, thresh, minarea) for m in masks]
+    alive = [True] * len(masks)
+    masks = [m.copy() for m in masks]
+    for i in np.argsort([q['fdflux'] for q in sh]):                 # faintest first
+        best, into = 0.0, -1
+        for j in range(len(masks)):
+            if j == i or not alive[j] or sh[j]['fdflux'] <= sh[i]['fdflux']:
+                continue
+            dx, dy = sh[i]['mx'] - sh[j]['mx'], sh[i]['my'] - sh[j]['my']
+            if dx * dx + dy * dy >= (CLEAN_ZONE * (sh[i]['a'] + sh[j]['a'])) ** 2:
+                continue
+            q = sh[j]
+            ratio = q['amp'] / thresh
+            if ratio <= 1.0:
+                continue
+            alpha = (ratio ** (1.0 / beta) - 1.0) * q['unitarea'] / q['npix']
+            val = 1.0 + alpha * (q['cxx'] * dx * dx + q['cyy'] * dy * dy + q['cxy'] * dx * dy)
+            wing = q['amp'] * val ** (-beta) if 1.0 < val < 1e10 else 0.0
+            if wing > sh[i]['mthresh'] and wing > best:
+                best, into = wing, j
+        if into >= 0:
+            masks[into] |= masks[i]
+            alive[i] = False
+    return [m for m, ok in zip(masks, alive) if ok]
+
+
+def extract(data, noisemap, thresh=3.0, minarea=15, deblend_nthresh=32, deblend_cont=0.001, clean_detections=True,
+            clean_param=1.0):
     """-> (objects, segmentation map).  objects: structured array with 'x', 'y' (barycentres, pixel units, x = column),
     'npix', 'flux'; segmentation map: int array, pixels of object i carry i + 1, background 0 (sep's convention)."""
     data = np.asarray(data, dtype=np.float64)
@@ -88,18 +152,21 @@ def extract(data, noisemap, thresh=3.0, minarea=15, deblend_nthresh=32, deblend_
     det = snr > thresh
     lab, k = ndimage.label(det, structure=EIGHT)
     seg = np.zeros(data.shape, dtype=np.int32)
-    objs = []
+    found = []
     for g in range(1, k + 1):
         group = lab == g
         if group.sum() < minarea:
             continue
-        for m in _deblend(snr, group, thresh, deblend_nthresh, deblend_cont, minarea):
-            wgt = np.where(m, np.clip(snr - thresh, 0.0, None), 0.0)
-            tot = wgt.sum()
-            if tot <= 0:
-                continue
-            ys, xs = np.indices(data.shape)
-            objs.append((float((wgt * xs).sum() / tot), float((wgt * ys).sum() / tot), int(m.sum()), float(np.where(m, data, 0.0).sum())))
-            seg[m] = len(objs)
+        found.extend(m for m in _deblend(snr, group, thresh, deblend_nthresh, deblend_cont, minarea)
+                     if np.where(m, snr, 0.0).sum() > 0)
+    if clean_detections:
+        found = clean(found, snr, thresh, minarea, clean_param)
+    objs = []
+    ys, xs = np.indices(data.shape)
+    for m in found:
+        wgt = np.where(m, snr, 0.0)
+        tot = wgt.sum()
+        objs.append((float((wgt * xs).sum() / tot), float((wgt * ys).sum() / tot), int(m.sum()), float(np.where(m, data, 0.0).sum())))
+        seg[m] = len(objs)
     objects = np.array(objs, dtype=[('x', 'f8'), ('y', 'f8'), ('npix', 'i4'), ('flux', 'f8')])
     return objects, seg

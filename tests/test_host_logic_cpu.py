@@ -342,3 +342,35 @@ def test_blended_neighbour_is_split_off_and_masked():
     data2 = star(15.5, 15.5, 4000.0, s=2.5) + star(23.0, 15.5, 3.0, s=1.0) + rng.normal(0, 1.0, (n, n))
     objects2, seg2 = extract(data2, noise)
     assert len(objects2) == 1 and mask_surrounding_stars(data2, noise).all()
+
+
+def test_cleaning_merges_detections_that_exist_only_on_a_neighbours_wing():
+    """sep's clean pass (clean=True, clean_param=1.0 are the defaults the reference's call leaves in place,
+    psf_modelling.py:51-52): a fragment the de-blending split off that would not reach minarea pixels above the
+    threshold on its own is merged into the neighbour whose Moffat wing lies under it; real neighbours stay."""
+    from lightcurver_amd.processes.source_masking import extract, clean, _shape, matched_filter_snr
+    n = 48
+    yy, xx = np.mgrid[0:n, 0:n]
+
+    def star(x0, y0, amp, s):
+        return amp * np.exp(-0.5 * ((xx - x0) ** 2 + (yy - y0) ** 2) / s ** 2)
+
+    noise = np.ones((n, n))
+    data = star(23.5, 23.5, 3000.0, 2.0) + star(40, 23.5, 3.0, 2.5) + np.random.default_rng(7).normal(0, 1.0, (n, n))
+    raw, _ = extract(data, noise, clean_detections=False)
+    cleaned, seg = extract(data, noise)
+    assert len(raw) == 3 and raw['npix'].min() < 15           # the de-blending leaves a fragment below minarea
+    assert len(cleaned) == 2 and cleaned['npix'].min() >= 15
+    assert cleaned['npix'].sum() == raw['npix'].sum()         # merged, not dropped: its pixels stay in the map
+    assert sorted(np.unique(seg)) == [0, 1, 2]
+    # the wing model: a Moffat of index 1 through the threshold at the isophotal area of the bright star
+    snr = matched_filter_snr(data, noise)
+    bright = seg == seg[23, 23]
+    q = _shape(bright, snr, 3.0, 15)
+    r_t2 = q['npix'] / q['unitarea']
+    alpha = (q['amp'] / 3.0 - 1.0) * q['unitarea'] / q['npix']
+    assert abs(q['amp'] / (1.0 + alpha * r_t2) - 3.0) < 1e-9
+    # two real stars: nothing to clean
+    two = star(15.5, 23.5, 400.0, 1.8) + star(30.5, 25.0, 150.0, 1.8) + np.random.default_rng(5).normal(0, 1.0, (n, n))
+    assert len(extract(two, noise)[0]) == len(extract(two, noise, clean_detections=False)[0]) == 2
+    assert clean([bright], snr, 3.0, 15) == [bright] or len(clean([bright], snr, 3.0, 15)) == 1
