@@ -11,6 +11,8 @@ of the shared block (strong scaling, reported under config.sharded_joint_fit).
 Inputs are resident in HBM before the timed region; the Moffat stage and noise propagation are one-time setup.
 
 `--gpus N` without a launcher (WORLD_SIZE unset) starts N rank processes itself before anything touches the GPU.
+For N > 1 every rank process is a supervisor that stays off the GPU and runs the measurement in a child (supervise_rank):
+the headline line exists before the sharded joint fits start and survives whatever happens in them.
 """
 import argparse
 import csv
@@ -81,6 +83,71 @@ def spawn_ranks(n, argv):
     for p in procs:
         rc = max(rc, p.wait())
     return rc
+
+
+def supervise_rank(argv, grace_s=600.0, script=None):
+    """N > 1: the rank process the launcher started stays off the GPU and runs the bench as a child whose standard output
+    it reads.  The child writes a provisional line (rank 0) and the marker 'HEADLINE_DONE' once the headline measurement
+    is complete, then the final line after the sharded joint fits.  Whatever happens to the child in that last part - an
+    RCCL or peer-memory fault ends a process without a Python exception, a hung collective never returns - the LAST
+    complete line reaches this rank's standard output, once, and the launcher sees exit code 0: the headline number
+    does not depend on the part of the bench that only a multi-GPU node can run.  After the marker the child has
+    `grace_s` seconds; it is then killed by its exact PID."""
+    import signal
+    import threading
+    env = dict(os.environ, LCMI_BENCH_WORKER='1')
+    child = subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE)
+    state = {'line': None, 'marker_at': None}
+
+    def reader():
+        for raw in child.stdout:
+            text = raw.decode(errors='replace').strip()
+            if text == 'HEADLINE_DONE':
+                state['marker_at'] = time.monotonic()
+            elif text.startswith('{'):
+                state['line'] = text
+
+    def forward(signum, frame):
+        if child.poll() is None:
+            child.kill()
+        sys.exit(128 + signum)
+
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, forward)
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    killed = False
+    while True:
+        try:
+            child.wait(timeout=1.0)
+            break
+        except subprocess.TimeoutExpired:
+            if state['marker_at'] is not None and time.monotonic() - state['marker_at'] > grace_s:
+                print(f'bench.py: the sharded joint fits did not finish within {grace_s:.0f} s of the headline '
+                      f'measurement; rank {os.environ.get("RANK")} ends its worker (pid {child.pid})', file=sys.stderr)
+                child.kill()
+                child.wait()
+                killed = True
+                break
+    th.join(timeout=10.0)
+    if state['line'] is not None:
+        line = state['line']
+        if killed or child.returncode != 0:
+            try:
+                d = json.loads(line)
+                d['config'].setdefault('sharded_joint_fit', {})
+                if 'value' not in d['config']['sharded_joint_fit']:
+                    d['config']['sharded_joint_fit'] = {'error': 'the worker ended before the sharded joint fits did '
+                                                                 f'(killed after the grace period: {killed}, exit code '
+                                                                 f'{child.returncode})'}
+                line = json.dumps(d)
+            except Exception:
+                pass
+        sys.stdout.write(line + '\n')
+        sys.stdout.flush()
+    if state['marker_at'] is not None:
+        return 0
+    return child.returncode if child.returncode is not None else 1
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -602,6 +669,8 @@ def main():
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.gpus > 1 and os.environ.get('LCMI_BENCH_WORKER') != '1' and not args.no_sharded_joint:
+        sys.exit(supervise_rank(sys.argv[1:]))
 
     # stdout carries ONE line, the JSON of rank 0: libraries that chat on file descriptor 1 (gloo's "[Gloo] Rank 0 is connected
     # to ..." from C++) are sent to stderr for the rest of the run; the line itself is written to the saved descriptor
@@ -672,21 +741,6 @@ def main():
     finite = bool(np.all(np.isfinite(hist)))
     res = b.results()
 
-    sharded = sharded_peer = sharded_c5 = None
-    if world > 1 and not args.no_sharded_joint:
-        try:
-            sharded = sharded_joint_fit(ctx, rank, world)
-        except Exception as e:
-            sharded = {'error': repr(e)}
-        try:   # the same fit with the one-shot peer-memory all-reduce instead of the collective
-            sharded_peer = sharded_joint_fit(ctx, rank, world, transport='peer')
-        except Exception as e:
-            sharded_peer = {'error': repr(e)}
-        try:   # C5, the configuration sharding is for: 1000 epochs of 128 x 128 (one GPU alone: ~1.54 ms per iteration)
-            sharded_c5 = sharded_joint_fit(ctx, rank, world, iters=100, transport='peer', config='C5')
-        except Exception as e:
-            sharded_c5 = {'error': repr(e)}
-
     if rank == 0:
         value = F * S * world * ITERS_PER_STEP * args.steps / elapsed
         bytes_per = psf_bytes_per_cutout_iteration(n, ss, S)
@@ -752,6 +806,37 @@ def main():
                 except Exception as e:
                     extra[0]['cpu_baseline'] = {'value': None, 'error': repr(e)}
             out['config']['other_workloads'] = extra
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out['cpu_baseline'] = cpu_baseline(ds, weight, b, stars0, ss)
+            except Exception as e:  # the bench line must still be printed
+                out['cpu_baseline'] = {'value': None, 'error': repr(e)}
+
+    # N > 1: the headline is complete.  Under the supervisor (supervise_rank) rank 0 hands over a provisional line and every
+    # rank the marker, so that nothing in the sharded joint fits below - the part only a multi-GPU node can run - can
+    # take the headline with it.
+    worker = os.environ.get('LCMI_BENCH_WORKER') == '1'
+    if world > 1 and worker:
+        if rank == 0:
+            os.write(real_stdout, (json.dumps(out) + '\n').encode())
+        os.write(real_stdout, b'HEADLINE_DONE\n')
+
+    sharded = sharded_peer = sharded_c5 = None
+    if world > 1 and not args.no_sharded_joint:
+        try:
+            sharded = sharded_joint_fit(ctx, rank, world)
+        except Exception as e:
+            sharded = {'error': repr(e)}
+        try:   # the same fit with the one-shot peer-memory all-reduce instead of the collective
+            sharded_peer = sharded_joint_fit(ctx, rank, world, transport='peer')
+        except Exception as e:
+            sharded_peer = {'error': repr(e)}
+        try:   # C5, the configuration sharding is for: 1000 epochs of 128 x 128 (one GPU alone: ~1.54 ms per iteration)
+            sharded_c5 = sharded_joint_fit(ctx, rank, world, iters=100, transport='peer', config='C5')
+        except Exception as e:
+            sharded_c5 = {'error': repr(e)}
+
+    if rank == 0:
         if sharded is not None:
             out['config']['sharded_joint_fit'] = sharded
             out['config']['rccl_ranks'] = sharded.get('rccl_ranks')
@@ -759,11 +844,6 @@ def main():
             out['config']['sharded_joint_fit_peer'] = sharded_peer
         if sharded_c5 is not None:
             out['config']['sharded_joint_fit_c5_peer'] = sharded_c5
-        if not args.no_cpu_baseline and world == 1:
-            try:
-                out['cpu_baseline'] = cpu_baseline(ds, weight, b, stars0, ss)
-            except Exception as e:  # the bench line must still be printed
-                out['cpu_baseline'] = {'value': None, 'error': repr(e)}
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist:
         dist.barrier()
