@@ -703,7 +703,7 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
         return LC_OK;
       }
       int tiles = j->flag_sync ? 2 : (NN / kRedPix >= 4096 ? 4 : 1);
-      if (const char *tl = std::getenv("LCMI_UPDATE_TILES")) tiles = std::max(1, std::atoi(tl));
+      if (const char *tl = std::getenv("LCMI_UPDATE_TILES")) tiles = std::min(std::max(1, std::atoi(tl)), kUpdMaxTiles);
       if ((NN / kRedPix) % tiles) tiles = 1;
       const int nimg = NN / kRedPix / tiles;
       hipLaunchKernelGGL(joint_reduce_update_kernel, dim3(nimg + 2), dim3(kRedThreads), 0, stream, A, j->N, j->HG, tiles);

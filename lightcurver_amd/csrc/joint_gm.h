@@ -516,6 +516,7 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_groups_kernel(const J
 // nimg + 1 updates the per-epoch shifts and sky levels.
 // `tiles` 16-pixel tiles per image block (2 where the regulariser flag is checked in the kernel: at most two 256-thread
 // blocks per CU are then resident, so a chain that runs late always finds the wave slots and registers to finish).
+constexpr int kUpdMaxTiles = 4;  // tiles per block the kernel below holds side by side (the host never asks for more)
 __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointUpdArgs A, int N, const float *HG, int tiles) {
   static_assert(kRedThreads == kGmThreads, "one block size");
   __shared__ float4 part[kRedParts][kRedPix / 4];
@@ -525,27 +526,50 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointU
   const int tid = threadIdx.x;
   const float lr = A.lr, bc1 = A.bc1, bc2 = A.bc2;
   if ((int)blockIdx.x < nimg) {
-    for (int tl = 0; tl < tiles; ++tl) {
-      const int px0 = (blockIdx.x * tiles + tl) * kRedPix, px = px0 + tid;
-      // state of this thread's pixel: requested before the reduction, used after it
-      float hv = 0.f, m = 0.f, sv = 0.f;
-      if (tid < kRedPix) {
-        hv = A.h[px];
-        m = A.mh[px];
-        sv = A.sh[px];
+    // The tiles of a block side by side: state and slab loads of every tile requested first (one memory round trip for the
+    // block instead of one per tile), the tiles combined one after the other through the LDS buffer, the regulariser's flag,
+    // then its gradient for every tile in one more round trip.  Same sums in the same order as tile after tile.
+    float hv[kUpdMaxTiles], m[kUpdMaxTiles], sv[kUpdMaxTiles], tsum[kUpdMaxTiles], gr[kUpdMaxTiles];
+    float4 acc[kUpdMaxTiles];
+#pragma unroll
+    for (int tl = 0; tl < kUpdMaxTiles; ++tl) {
+      hv[tl] = m[tl] = sv[tl] = tsum[tl] = gr[tl] = 0.f;
+      acc[tl] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tl < tiles) {
+        const int px0 = (blockIdx.x * tiles + tl) * kRedPix, px = px0 + tid;
+        if (tid < kRedPix) {
+          hv[tl] = A.h[px];
+          m[tl] = A.mh[px];
+          sv[tl] = A.sh[px];
+        }
+        acc[tl] = reduce_pixels16_partial(E, NN, HG, px0, tid);
       }
-      const float t = reduce_pixels16(E, NN, HG, px0, part, tid);
-      if (tl == 0) wait_for_flag(A.wait_flag, A.wait_seq, A.wait_err);  // the regulariser of this iteration (second stream)
-      if (tid < kRedPix) {
-        const float gr = (A.reg_mode == 2) ? ld_coherent(A.greg + px, A.wait_flag != nullptr) : 0.f;
-        A.shared_w[px] = t;
-        adabelief_step(hv, m, sv, t + gr, lr, bc1, bc2, A.ab);
-        A.h[px] = hv;
-        A.mh[px] = m;
-        A.sh[px] = sv;
-        phist_put(A, LC_P_H, px, hv);
+    }
+#pragma unroll
+    for (int tl = 0; tl < kUpdMaxTiles; ++tl) {
+      if (tl < tiles) {
+        if (tl > 0) __syncthreads();  // the partial sums in LDS are rewritten
+        tsum[tl] = reduce_pixels16_combine(acc[tl], part, tid);
       }
-      __syncthreads();  // the partial sums in LDS are rewritten by the next tile
+    }
+    wait_for_flag(A.wait_flag, A.wait_seq, A.wait_err);  // the regulariser of this iteration (second stream)
+    if (tid < kRedPix) {
+#pragma unroll
+      for (int tl = 0; tl < kUpdMaxTiles; ++tl)
+        if (tl < tiles && A.reg_mode == 2)
+          gr[tl] = ld_coherent(A.greg + (blockIdx.x * tiles + tl) * kRedPix + tid, A.wait_flag != nullptr);
+#pragma unroll
+      for (int tl = 0; tl < kUpdMaxTiles; ++tl) {
+        if (tl < tiles) {
+          const int px = (blockIdx.x * tiles + tl) * kRedPix + tid;
+          A.shared_w[px] = tsum[tl];
+          adabelief_step(hv[tl], m[tl], sv[tl], tsum[tl] + gr[tl], lr, bc1, bc2, A.ab);
+          A.h[px] = hv[tl];
+          A.mh[px] = m[tl];
+          A.sh[px] = sv[tl];
+          phist_put(A, LC_P_H, px, hv[tl]);
+        }
+      }
     }
     return;
   }

@@ -1363,8 +1363,9 @@ __global__ void joint_epoch_finish_kernel(JointArgs A, int SS, int nparts) {
 // in flight at once instead of trickling through a few waves per CU), then the 64 partials of a pixel are added in a
 // fixed order, so the result does not depend on scheduling.  Scalars: last block, in double.
 constexpr int kRedPix = 16, kRedParts = 64, kRedThreads = (kRedPix / 4) * kRedParts;
-// sum over the epochs of HG[e][px0 .. px0 + 15] -> one value per pixel in threads tid < 16 (others: 0)
-__device__ __forceinline__ float reduce_pixels16(int E, int NN, const float *HG, int px0, float4 (*part)[kRedPix / 4], int tid) {
+// sum over the epochs of HG[e][px0 .. px0 + 15] -> one value per pixel in threads tid < 16 (others: 0); in two steps, so that
+// a block with several tiles can have the loads of all of them in flight before it combines the first
+__device__ __forceinline__ float4 reduce_pixels16_partial(int E, int NN, const float *HG, int px0, int tid) {
   const int quad = tid & (kRedPix / 4 - 1), grp = tid / (kRedPix / 4);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const float *src = HG + px0 + 4 * quad;
@@ -1382,6 +1383,11 @@ __device__ __forceinline__ float reduce_pixels16(int E, int NN, const float *HG,
     const float4 v = *(const float4 *)(src + (size_t)e * NN);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
+  return acc;
+}
+// (every thread of the block calls; one barrier inside, and the caller puts one between two uses of `part`)
+__device__ __forceinline__ float reduce_pixels16_combine(float4 acc, float4 (*part)[kRedPix / 4], int tid) {
+  const int quad = tid & (kRedPix / 4 - 1), grp = tid / (kRedPix / 4);
   part[grp][quad] = acc;
   __syncthreads();
   float t = 0.f;
@@ -1391,6 +1397,9 @@ __device__ __forceinline__ float reduce_pixels16(int E, int NN, const float *HG,
     for (int g = 0; g < kRedParts; ++g) t += p[g * kRedPix];
   }
   return t;
+}
+__device__ __forceinline__ float reduce_pixels16(int E, int NN, const float *HG, int px0, float4 (*part)[kRedPix / 4], int tid) {
+  return reduce_pixels16_combine(reduce_pixels16_partial(E, NN, HG, px0, tid), part, tid);
 }
 // Scalars of the shared block: dc_x, dc_y, sum (a - ref), sum (a - ref)^2 per source, then chi2 and the epoch count.
 // Every thread strides over the epochs with all 4 M + 1 running sums in double (the loads of an epoch are independent of
