@@ -290,3 +290,171 @@ class StarPhotometryBatch(JointFit):
             return [flat[g * self.M:(g + 1) * self.M] for g in range(self.G)]
         k = self.M if name == 'a' else 1
         return [flat[self.starts[g] * k:self.starts[g + 1] * k] for g in range(self.G)]
+
+
+def joint_fit_size(n, ss):
+    """The stamp size the device fits an n x n joint problem at: n itself when an epoch kernel is instantiated for it,
+    otherwise the next instantiated size of the same parity (EmbeddedJointFit)."""
+    l = _lib.lib()
+    if l.lc_joint_supported(int(n), int(ss)):
+        return int(n)
+    for m in range(int(n) + 2, 129, 2):
+        if l.lc_joint_supported(m, int(ss)):
+            return m
+    raise _lib.LcError(f'no joint-fit kernel for {n}x{n} stamps at subsampling {ss} (instantiated at ss = 2: multiples of 8 up '
+                       f'to 64, and 128; other even sizes up to 128 are fitted embedded in the next of these)')
+
+
+def make_joint_fit(data, sigma2, psf, ss, M, ctx=None):
+    """JointFit at a size with a kernel of its own, EmbeddedJointFit otherwise."""
+    n = np.asarray(data).shape[-1]
+    n_fit = joint_fit_size(n, ss)
+    if n_fit == n:
+        return JointFit(data, sigma2, psf, ss, M, ctx)
+    return EmbeddedJointFit(data, sigma2, psf, ss, M, ctx, n_fit)
+
+
+class EmbeddedJointFit(JointFit):
+    """The reference's ``stamp_size_ROI`` / ``stamp_size_stars`` are free integers (config.yaml:205-206); the epoch kernels exist
+    for n = 8 k <= 64 and 128.  An even n in between is fitted EMBEDDED in the next of those, as a declared fall-back: the
+    stamps in the centre of the larger frame, no weight on the ring (variance 1e20), the narrow PSFs zero-padded, the
+    background h fitted on the larger grid.  Towards the caller everything keeps the caller's size: ``h`` goes in padded
+    with zeros and comes out cropped (values, gradients, bounds, parameter history), models and deconvolved images are
+    cropped.  Inside the caller's window the model is the native-size one (the convolution window is alias-free in both)
+    except at the edges: a translated epoch samples h with zeros beyond the window where the native grid clamps to its
+    edge pixel, and the part of a point source's profile that falls beyond the window is convolved back in here and cut
+    there - 1e-4 ... 1e-3 of the model's peak on the synthetic ROIs of tests/test_joint_sizes_gpu.py, growing with the
+    background's amplitude at the edge.  (Measured and left out: the ring of h as a copy of the edge - the scene beyond
+    the window is then not zero any more and convolves into it: three times further from the native model.)  Also
+    different from a fit at a kernel of its own: the regulariser sees the larger grid (J = log2 of it, other edges), and
+    the ring pixels of h are free, held at zero by the regulariser alone.  The noise levels W of the regulariser are propagated with the ring at the stamps'
+    median variance (a ring of 'infinite' noise would inflate every coarse scale)."""
+    RING_VARIANCE = 1e20
+
+    def __init__(self, data, sigma2, psf, ss, M, ctx, n_fit):
+        data, sigma2, psf = f32(data), f32(sigma2), f32(psf)
+        E, n, _ = data.shape
+        ss = int(ss)
+        if (n_fit - n) % 2 or n_fit <= n:
+            raise ValueError('embedding needs a larger size of the same parity')
+        if psf.shape != (E, n * ss, n * ss):
+            raise ValueError(f'psf must be ({E}, {n * ss}, {n * ss}), got {psf.shape}')
+        self.pad, self.n_user, self.N_user = (n_fit - n) // 2, n, n * ss
+        p, P = self.pad, self.pad * ss
+        big = np.zeros((E, n_fit, n_fit), np.float32)
+        big[:, p:p + n, p:p + n] = data
+        var = np.full((E, n_fit, n_fit), self.RING_VARIANCE, np.float32)
+        var[:, p:p + n, p:p + n] = sigma2
+        self._psf_fit = np.zeros((E, n_fit * ss, n_fit * ss), np.float32)
+        self._psf_fit[:, P:P + n * ss, P:P + n * ss] = psf
+        # (for the noise propagation: the ring at each epoch's median variance)
+        self._var_w = var.copy()
+        med = np.median(sigma2.reshape(E, -1), axis=1).astype(np.float32)
+        ring = np.ones((n_fit, n_fit), bool)
+        ring[p:p + n, p:p + n] = False
+        self._var_w[:, ring] = med[:, None]
+        super().__init__(big, var, self._psf_fit, ss, M, ctx)
+        self._dev_dims = (self.n, self.N, dict(self.sizes))
+        self._user_dims = (n, n * ss, dict(self.sizes, h=(n * ss) ** 2))
+        self.n, self.N, self.sizes = self._user_dims
+
+    class _Dev:
+        def __init__(self, fit):
+            self.fit = fit
+
+        def __enter__(self):
+            self.fit.n, self.fit.N, self.fit.sizes = self.fit._dev_dims
+
+        def __exit__(self, *exc):
+            self.fit.n, self.fit.N, self.fit.sizes = self.fit._user_dims
+
+    def _dev(self):
+        return EmbeddedJointFit._Dev(self)
+
+    def _crop_h(self, v):
+        Nf, Nu, P = self._dev_dims[1], self.N_user, self.pad * self.ss
+        return np.ascontiguousarray(np.asarray(v).reshape(Nf, Nf)[P:P + Nu, P:P + Nu]).ravel()
+
+    def _pad_h(self, v, fill=0.0):
+        Nf, Nu, P = self._dev_dims[1], self.N_user, self.pad * self.ss
+        out = np.full((Nf, Nf), fill, np.float32)
+        out[P:P + Nu, P:P + Nu] = np.broadcast_to(np.asarray(v, dtype=np.float32).ravel(), (Nu * Nu,)).reshape(Nu, Nu)
+        return out.ravel()
+
+    def set_params(self, **params):
+        if 'h' in params:
+            params = dict(params, h=self._pad_h(params['h']))
+        with self._dev():
+            super().set_params(**params)
+
+    def get_params(self, names=None):
+        names = list(names or self.sizes)
+        with self._dev():
+            out = super().get_params(names)
+        if 'h' in out:
+            out['h'] = self._crop_h(out['h'])
+        return out
+
+    def set_loss(self, **kw):
+        with self._dev():
+            super().set_loss(**kw)
+
+    def propagate_noise(self):
+        with self._dev():
+            data0 = np.zeros((self.E, self.n, self.n), np.float32)
+            temp = JointFit(data0, self._var_w, self._psf_fit, self.ss, self.M, self.ctx)
+        try:
+            return temp.propagate_noise()      # (J + 1, N_fit, N_fit): handed back to set_loss as it is
+        finally:
+            temp.close()
+
+    def loss_grad(self, names=('a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean')):
+        with self._dev():
+            loss, bufs = super().loss_grad(names)
+        if 'h' in bufs:
+            bufs['h'] = self._crop_h(bufs['h'])
+        return loss, bufs
+
+    def model(self):
+        with self._dev():
+            m, chi2 = super().model()
+        p, n = self.pad, self.n_user
+        return np.ascontiguousarray(m[:, p:p + n, p:p + n]), chi2
+
+    def deconvolved(self, epoch=0):
+        with self._dev():
+            s, b = super().deconvolved(epoch)
+        P, Nu = self.pad * self.ss, self.N_user
+        return np.ascontiguousarray(s[P:P + Nu, P:P + Nu]), np.ascontiguousarray(b[P:P + Nu, P:P + Nu])
+
+    def run_lbfgs(self, maxiter, lower=None, upper=None):
+        def ring(d, fill):
+            return None if d is None else {k: (self._pad_h(v, fill) if k == 'h' else v) for k, v in d.items()}
+        with self._dev():
+            return super().run_lbfgs(maxiter, ring(lower, -1e10), ring(upper, 1e10))
+
+    def param_history_begin(self, capacity):
+        super().param_history_begin(capacity)
+        return sum(self.sizes[k] for k in self._free_names)
+
+    def param_history(self, first=0, count=None):
+        with self._dev():
+            rows = super().param_history(first, count)
+            dev_sizes = self.sizes
+        if 'h' not in self._free_names:
+            return rows
+        off = 0
+        parts = []
+        for k in self._free_names:
+            blk = rows[:, off:off + dev_sizes[k]]
+            off += dev_sizes[k]
+            if k == 'h':
+                Nf, Nu, P = self._dev_dims[1], self.N_user, self.pad * self.ss
+                blk = blk.reshape(-1, Nf, Nf)[:, P:P + Nu, P:P + Nu].reshape(rows.shape[0], Nu * Nu)
+            parts.append(blk)
+        return np.ascontiguousarray(np.concatenate(parts, axis=1))
+
+    def _no_shards(self, *a, **k):
+        raise NotImplementedError('an embedded joint fit is not sharded over ranks: use a stamp size with a kernel of its own')
+
+    step_local = step_grad = shared_buffer = shared_get = shared_set = run_sharded = step_update = _no_shards

@@ -5,7 +5,7 @@ import hashlib
 
 import numpy as np
 
-from ...joint import JointFit
+from ...joint import JointFit, make_joint_fit
 
 ANALYTIC = ('a', 'c_x', 'c_y', 'dx', 'dy', 'alpha')
 BACKGROUND = ('h', 'mean')
@@ -63,7 +63,7 @@ class Deconv:
         if self._fit is None or key != self._fit_key:
             if self._fit is not None:
                 self._fit.close()
-            self._fit = JointFit(data, sigma_2, self.psf, self.upsampling_factor, self.M, self._ctx)
+            self._fit = make_joint_fit(data, sigma_2, self.psf, self.upsampling_factor, self.M, self._ctx)
             self._fit_key = key
             self._sigma2_f32 = np.asarray(sigma_2, dtype=np.float32).copy()  # what propagate_noise compares with
         return self._fit

@@ -2,7 +2,7 @@
 lightcurver/processes/star_photometry.py:108-110, roi_modelling.py:299-301)."""
 import numpy as np
 
-from ...joint import JointFit
+from ...joint import make_joint_fit
 
 
 def propagate_noise(model, noise_maps, kwargs=None, masks=None, wavelet_type_list=('starlet',), method='SLIT',
@@ -27,7 +27,7 @@ def propagate_noise(model, noise_maps, kwargs=None, masks=None, wavelet_type_lis
     same = (fit is not None and fit.E == noise_maps.shape[0] and getattr(model, '_sigma2_f32', None) is not None
             and model._sigma2_f32.shape == sigma2.shape and np.array_equal(model._sigma2_f32, sigma2.astype(np.float32)))
     if not same:
-        temp = fit = JointFit(np.zeros_like(sigma2), sigma2, model.psf, model.upsampling_factor, model.M, model._ctx)
+        temp = fit = make_joint_fit(np.zeros_like(sigma2), sigma2, model.psf, model.upsampling_factor, model.M, model._ctx)
     try:
         W = fit.propagate_noise()
     finally:

@@ -77,3 +77,21 @@ def test_embedded_fit_sizes_are_chosen_from_the_kernel_table():
         _fit_size(66, 2)
     with pytest.raises(_lib.LcError):
         _fit_size(20, 3)
+
+
+def test_embedded_joint_fit_sizes_are_chosen_from_the_kernel_table():
+    """The same for the joint fit (lightcurver_amd.joint.joint_fit_size): lc_joint_supported is a host-side table look-up."""
+    import pytest
+    from lightcurver_amd import _lib
+    from lightcurver_amd.joint import joint_fit_size
+    l = _lib.lib()
+    native = [n for n in range(2, 130, 2) if l.lc_joint_supported(n, 2)]
+    assert native == [16, 24, 32, 40, 48, 56, 64, 128]
+    for n in range(10, 130, 2):
+        m = joint_fit_size(n, 2)
+        assert m in native and m >= n and (m - n) % 2 == 0 and (m == n) == (n in native)
+        assert all(k < n for k in native if k < m)
+    with pytest.raises(_lib.LcError):
+        joint_fit_size(130, 2)
+    with pytest.raises(_lib.LcError):
+        joint_fit_size(21, 2)           # odd sizes have no embedding: the stamp centre would move by half a pixel

@@ -1,0 +1,116 @@
+"""Joint fits at stamp sizes without an epoch kernel of their own (the reference's stamp_size_ROI / stamp_size_stars are free
+integers, config.yaml:205-206): lightcurver_amd.joint.EmbeddedJointFit fits them in the centre of the next instantiated
+size, a declared fall-back.  Checked here: (1) without the starlet term the embedded evaluation is the native-size one up
+to edge effects - model, chi2, loss and gradients against the float64 oracle AT THE CALLER'S SIZE, with the measured
+differences as tolerances; (2) everything the caller sees keeps the caller's size; (3) the reference-shaped two-stage ROI
+fit and the one-star fit run through the facade at such a size and end where native sizes end."""
+import numpy as np
+import pytest
+
+from oracle import model as om, optim as oo
+from lightcurver_amd.synthetic import make_roi_dataset
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('n,n_fit', [(20, 24), (28, 32), (50, 56)])
+def test_embedded_evaluation_is_the_native_size_one(ctx, n, n_fit):
+    from lightcurver_amd.joint import make_joint_fit, EmbeddedJointFit, joint_fit_size
+    E, M, ss = 3, 2, 2
+    assert joint_fit_size(n, ss) == n_fit
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=300 + n)
+    rng = np.random.default_rng(n)
+    p = {k: np.array(v, dtype=np.float64) for k, v in ds['truth'].items()}
+    p['a'] = p['a'] * rng.uniform(0.9, 1.1, p['a'].shape)
+    p['dx'] = p['dx'] + rng.normal(0, 0.05, E)
+    p['mean'] = rng.normal(0, 1e-3, E)
+    p['h'] = p['h'] * rng.uniform(0.8, 1.2, p['h'].shape)
+    sig2 = ds['noisemap'].astype(np.float64) ** 2
+    j = make_joint_fit(ds['data'], sig2, ds['psf'], ss, M, ctx)
+    assert isinstance(j, EmbeddedJointFit) and j.n == n and j.N == n * ss and j.sizes['h'] == (n * ss) ** 2
+    j.set_params(**p)
+    j.set_loss(lam_positivity=20.0, lam_positivity_ps=5.0, lam_flux_uniformity=0.7)   # (no starlet term: it sees the larger grid)
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean']
+    j.set_free(free)
+    po = {k: om.T(v) for k, v in p.items()}
+    data, s2, psf = om.T(ds['data']), om.T(sig2), om.T(ds['psf'])
+    model, chi2_e = j.model()
+    mo = om.deconv_model(po, psf, ss, n)
+    assert model.shape == (E, n, n)
+    e_model = H.rel_err(model, mo.numpy())
+    e_chi = H.rel_err(chi2_e, (((data - mo) ** 2) / s2).sum((-1, -2)).numpy())
+    fn = lambda q: om.deconv_loss(q, data, s2, psf, ss, lam_pos=20.0, lam_pos_ps=5.0, lam_fu=0.7)
+    L, g = oo.value_and_grad(fn, po, free)
+    loss, grads = j.loss_grad(free)
+    e_loss = abs(loss - L) / abs(L)
+    e_grad = {k: H.rel_err(grads[k], g[k].numpy()) for k in free if k != 'h'}
+    for k in free:
+        assert grads[k].shape == g[k].numpy().ravel().shape, k
+    Nn, mg = n * ss, 8
+    gh, gho = grads['h'].reshape(Nn, Nn), g['h'].numpy().reshape(Nn, Nn)
+    e_gh = np.abs(gh - gho)[mg:-mg, mg:-mg].max() / np.abs(gho).max()
+    got = j.get_params()
+    assert got['h'].shape == (Nn ** 2,) and np.allclose(got['h'], p['h'].astype(np.float32).ravel())
+    sc, bg = j.deconvolved(1)
+    so, bo = om.deconv_deconvolved(po, 1, Nn, ss)
+    assert sc.shape == (Nn, Nn) and bg.shape == (Nn, Nn)
+    e_sc = np.abs(sc - so.numpy())[mg:-mg, mg:-mg].max() / np.abs(so.numpy()).max()
+    print('EMB', n, e_model, e_chi, e_loss, e_grad, e_gh, e_sc)
+    # What the embedding changes inside the caller's window, all of it at the edges: an epoch's translated background is
+    # sampled with zeros beyond the window where the native grid clamps to its edge pixel, and the part of a point
+    # source's profile that falls beyond the window is convolved back in instead of being cut.  Measured on these
+    # scenes (n = 20 / 28 / 50): 7e-5 / 1.3e-3 / <1e-3 of the model's peak, 1e-4 / 2.2e-3 in chi2, 3e-5 / 1.5e-3 in the
+    # loss, gradients of fluxes, positions, shifts and sky levels within 3e-3 / 9e-2 of their largest element (the
+    # residuals of these jittered parameters are large everywhere, the edges included); the gradient of h and the
+    # deconvolved image agree away from the edges (8 high-resolution pixels).
+    assert e_model < 4e-3 and e_chi < 7e-3 and e_loss < 5e-3
+    assert max(e_grad.values()) < 0.2, e_grad
+    assert e_gh < 0.1 and e_sc < 1e-4
+    W = j.propagate_noise()
+    assert W.shape[1:] == (n_fit * ss, n_fit * ss) and np.isfinite(W).all()
+    # inside the caller's window the noise levels of the fine scales are those of the native propagation (the ring only
+    # carries the median variance instead of the stamp's own edge values)
+    Wo = om.propagate_noise_deconv(s2, psf, ss).numpy()
+    P = (n_fit - n) // 2 * ss
+    inner = W[0, P + 8:P + n * ss - 8, P + 8:P + n * ss - 8]
+    assert H.rel_err(inner, Wo[0, 8:-8, 8:-8]) < 2e-2
+    j.close()
+
+
+def test_two_stage_roi_fit_and_star_fit_at_a_size_without_a_kernel(ctx):
+    """The reference-shaped fits through the facade at n = 28 (embedded in 32): caller-sized outputs everywhere, and the
+    fit ends where fits at sizes with kernels of their own end on the same kind of scene (reduced chi2 of the final model
+    between those of n = 24 and n = 32, each within 30 %)."""
+    from lightcurver_amd.joint import EmbeddedJointFit, JointFit
+    from lightcurver_amd.processes.roi_modelling import model_roi_cutouts
+    from lightcurver_amd.processes.star_photometry import do_one_star_forward_modelling
+    ss, E, M = 2, 12, 2
+    chi, kinds = {}, {}
+    for n in (24, 28, 32):
+        ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=77)
+        t = ds['truth']
+        off = (n - 1) / 2.0
+        xs = np.asarray(t['c_x']) + off + np.asarray(t['dx'])[0]
+        ys = np.asarray(t['c_y']) + off + np.asarray(t['dy'])[0]
+        out = model_roi_cutouts(ds['data'].copy(), ds['noisemap'].copy(), ds['psf'], ss, xs, ys,
+                                roi_deconv_translations_iters=60, roi_deconv_all_iters=400)
+        k = out['kwargs_final']
+        kinds[n] = type(out['model']._fit)
+        model = np.asarray(out['model'].model(k))
+        assert model.shape == (E, n, n)
+        assert np.asarray(k['kwargs_background']['h']).size == (n * ss) ** 2
+        assert np.isfinite(out['loss_history']).all() and out['loss_history'][-1] < out['loss_history'][0]
+        assert np.abs(out['x_pixels'] - xs).max() < 0.5 and np.abs(out['y_pixels'] - ys).max() < 0.5
+        chi[n] = float(np.mean(((out['data'] - model) / out['noisemap']) ** 2))
+    assert kinds[28] is EmbeddedJointFit and kinds[24] is JointFit and kinds[32] is JointFit
+    lo, hi = min(chi[24], chi[32]), max(chi[24], chi[32])
+    assert 0.7 * lo < chi[28] < 1.3 * hi, chi
+    # one star, point source only
+    n = 28
+    ds1 = make_roi_dataset(E=8, M=1, n=n, ss=ss, seed=78)
+    res = do_one_star_forward_modelling(ds1['data'].copy(), ds1['noisemap'].copy(), ds1['psf'], ss, n_iter=300,
+                                        starlet_global_background=False)
+    assert res['residuals'].shape == (8, n, n) and np.isfinite(res['chi2']) and np.isfinite(res['fluxes']).all()
+    assert res['deconvolved_image'].shape == (n * ss, n * ss)
+    assert res['loss_curve'][-1] < res['loss_curve'][0]
