@@ -354,8 +354,11 @@ __device__ __forceinline__ void gm_flux_preload(const JointUpdArgs &A, FluxPre &
     P.ps1 = A.ps[LC_P_A][tid + kGmThreads];
   }
 }
+// rl: (optional, LDS) the 4 + 3 M values of A.regs, fetched by the caller in one round trip behind the flag; without it every
+// use below is a coherent load of its own
 __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, float lr, float bc1, float bc2, const float *sc,
-                                                int parts, const FluxPre *pre = nullptr) {
+                                                int parts, const FluxPre *pre = nullptr, const float *rl = nullptr) {
+  auto reg_at = [&](int k) { return rl ? rl[k] : ld_coherent(A.regs + k, A.wait_flag != nullptr); };
   __shared__ float red[kGmThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int E = A.E, M = A.M, NN = N * N;
@@ -375,7 +378,7 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
       const float sd = sqrtf(var);
       if (sd > 0.f) ga += A.lam_fu * ((av - A.a_ref[i]) - meanc) / (Etot * sd);
     }
-    if (pts) ga += ld_coherent(A.regs + (4 + i * 3), A.wait_flag != nullptr) / Etot;
+    if (pts) ga += reg_at(4 + i * 3) / Etot;
     if (A.mode == 0) {
       if (A.gout[LC_P_A]) A.gout[LC_P_A][idx] = ga;
     } else if (A.free_mask[LC_P_A]) {
@@ -396,6 +399,7 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
     for (int idx = first; idx < E * M; idx += kGmThreads)
       flux(idx, A.par[LC_P_A][idx], A.g_a[idx], A.pm[LC_P_A][idx], A.ps[LC_P_A][idx]);
   }
+  if (parts & 1) LC_USTAMP(5);
   if (parts & 2)
   for (int idx = tid; idx < 3 * E; idx += kGmThreads) {
     const int which = (idx / E == 0) ? LC_P_DX : (idx / E == 1) ? LC_P_DY : LC_P_MEAN;
@@ -416,7 +420,7 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
     const int which = (tid < M) ? LC_P_CX : LC_P_CY, i = tid % M;
     float gv = sc[(which == LC_P_CX ? 0 : M) + i];
     float cv = A.par[which][i];
-    if (pts) gv += (A.a_ref[i] + sc[2 * M + i] / Etot) * A.ss * ld_coherent(A.regs + (4 + i * 3 + (which == LC_P_CX ? 1 : 2)), A.wait_flag != nullptr);
+    if (pts) gv += (A.a_ref[i] + sc[2 * M + i] / Etot) * A.ss * reg_at(4 + i * 3 + (which == LC_P_CX ? 1 : 2));
     if (A.n_prior > 0) {
       const float mu = (which == LC_P_CX) ? A.prior_cx_mean[i] : A.prior_cy_mean[i];
       const float sg = (which == LC_P_CX) ? A.prior_cx_sigma[i] : A.prior_cy_sigma[i];
@@ -432,15 +436,17 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
       phist_put(A, which, i, cv);
     }
   }
+  LC_USTAMP(6);
   // loss = 0.5 chi2 + l1 + positivity + positivity of fluxes + flux uniformity + prior
   float part = wave_sum_shfl(pos_ps + (float)prior_loss);
   if (lane == 0) red[wid] = part;
   __syncthreads();
+  LC_USTAMP(7);
   if (tid == 0) {
     double loss = 0.5 * (double)sc[4 * M];
     for (int w = 0; w < kGmThreads / 64; ++w) loss += red[w];
-    if (use_reg) loss += (double)ld_coherent(A.regs + (0), A.wait_flag != nullptr) + (double)ld_coherent(A.regs + (1), A.wait_flag != nullptr);
-    if (pts) loss += (double)ld_coherent(A.regs + (2), A.wait_flag != nullptr);
+    if (use_reg) loss += (double)reg_at(0) + (double)reg_at(1);
+    if (pts) loss += (double)reg_at(2);
     if (A.lam_fu != 0.f && Etot > 1.f)
       for (int i = 0; i < M; ++i) {
         const double meanc = sc[2 * M + i] / Etot;
@@ -525,18 +531,24 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointU
   const int nimg = NN / kRedPix / tiles;  // image blocks
   const int tid = threadIdx.x;
   const float lr = A.lr, bc1 = A.bc1, bc2 = A.bc2;
-  if ((int)blockIdx.x < nimg) {
+  // The two single blocks come FIRST in the grid: the scalar block is the longest chain of the launch (tools/update_stamps.py)
+  // and, dispatched behind the image blocks, it waited for one of them to leave a CU before it even started (4.5 us into the
+  // launch at 512 image blocks, 10.9 us at the 1024 of a 256 x 256 grid).  bid: block among the image blocks, then the two.
+  const int bid = ((int)blockIdx.x >= 2) ? (int)blockIdx.x - 2 : nimg + (int)blockIdx.x;
+  if (bid < nimg) {
     // The tiles of a block side by side: state and slab loads of every tile requested first (one memory round trip for the
     // block instead of one per tile), the tiles combined one after the other through the LDS buffer, the regulariser's flag,
     // then its gradient for every tile in one more round trip.  Same sums in the same order as tile after tile.
     float hv[kUpdMaxTiles], m[kUpdMaxTiles], sv[kUpdMaxTiles], tsum[kUpdMaxTiles], gr[kUpdMaxTiles];
     float4 acc[kUpdMaxTiles];
+    if (bid == 0) LC_USTAMP(0);
+    const bool seen = flag_seen(A.wait_flag, A.wait_seq);
 #pragma unroll
     for (int tl = 0; tl < kUpdMaxTiles; ++tl) {
       hv[tl] = m[tl] = sv[tl] = tsum[tl] = gr[tl] = 0.f;
       acc[tl] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (tl < tiles) {
-        const int px0 = (blockIdx.x * tiles + tl) * kRedPix, px = px0 + tid;
+        const int px0 = (bid * tiles + tl) * kRedPix, px = px0 + tid;
         if (tid < kRedPix) {
           hv[tl] = A.h[px];
           m[tl] = A.mh[px];
@@ -552,16 +564,16 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointU
         tsum[tl] = reduce_pixels16_combine(acc[tl], part, tid);
       }
     }
-    wait_for_flag(A.wait_flag, A.wait_seq, A.wait_err);  // the regulariser of this iteration (second stream)
+    wait_for_flag(A.wait_flag, A.wait_seq, A.wait_err, seen);  // the regulariser of this iteration (second stream)
     if (tid < kRedPix) {
 #pragma unroll
       for (int tl = 0; tl < kUpdMaxTiles; ++tl)
         if (tl < tiles && A.reg_mode == 2)
-          gr[tl] = ld_coherent(A.greg + (blockIdx.x * tiles + tl) * kRedPix + tid, A.wait_flag != nullptr);
+          gr[tl] = ld_coherent(A.greg + (bid * tiles + tl) * kRedPix + tid, A.wait_flag != nullptr);
 #pragma unroll
       for (int tl = 0; tl < kUpdMaxTiles; ++tl) {
         if (tl < tiles) {
-          const int px = (blockIdx.x * tiles + tl) * kRedPix + tid;
+          const int px = (bid * tiles + tl) * kRedPix + tid;
           A.shared_w[px] = tsum[tl];
           adabelief_step(hv[tl], m[tl], sv[tl], tsum[tl] + gr[tl], lr, bc1, bc2, A.ab);
           A.h[px] = hv[tl];
@@ -571,19 +583,32 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointU
         }
       }
     }
+    if (bid == nimg - 1) LC_USTAMP(1);
     return;
   }
-  if ((int)blockIdx.x == nimg + 1) {  // shifts and sky levels: nothing to wait for
+  if (bid == nimg + 1) {  // shifts and sky levels: nothing to wait for
     gm_small_blocks(A, N, lr, bc1, bc2, nullptr, 2);
     return;
   }
   __shared__ float scl[4 * kMaxSources + 2];
+  __shared__ float regl[4 + 3 * kMaxSources];
   FluxPre pre;
+  LC_USTAMP(2);
+  const bool seen = flag_seen(A.wait_flag, A.wait_seq);
   gm_flux_preload(A, pre);
   reduce_scalars(E, M, NN, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.a_ref, A.shared_w, lanes, tid, scl);
   __syncthreads();
-  wait_for_flag(A.wait_flag, A.wait_seq, A.wait_err);
-  gm_small_blocks(A, N, lr, bc1, bc2, scl, 1, &pre);
+  LC_USTAMP(3);
+  wait_for_flag(A.wait_flag, A.wait_seq, A.wait_err, seen);
+  // what the chain left in regs (values of its terms, inner products of the point-source term): one round trip for the block
+  const bool have_regs = (A.regs != nullptr) && (A.reg_mode == 2 || (A.lam_pts != 0.f && A.pts_early == 2));
+  if (have_regs) {
+    if (tid < 4 + 3 * M) regl[tid] = ld_coherent(A.regs + tid, A.wait_flag != nullptr);
+    __syncthreads();
+  }
+  LC_USTAMP(4);
+  gm_small_blocks(A, N, lr, bc1, bc2, scl, 1, &pre, have_regs ? regl : nullptr);
+  LC_USTAMP(8);
 }
 
 // The same launch with the T_e^T step folded into the reduction (global-spectrum kernels, every epoch a pure translation):

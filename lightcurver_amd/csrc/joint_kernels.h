@@ -22,8 +22,11 @@ __device__ long long g_jstamps[16];
   do {                                                              \
     if (blockIdx.x == 0 && threadIdx.x == 0) g_jstamps[k] = clock64(); \
   } while (0)
+// (the fused reduction + update launch: thread 0 of whichever block calls, 100 MHz wall clock - tools/update_stamps.py)
+#define LC_USTAMP(k) do { if (threadIdx.x == 0) g_jstamps[k] = wall_clock64(); } while (0)
 #else
 #define LC_JSTAMP(k) do {} while (0)
+#define LC_USTAMP(k) do {} while (0)
 #endif
 
 struct JointArgs {
@@ -1410,6 +1413,21 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
 }
+template <int MM>
+__device__ __forceinline__ void wave_sums_f64(double (&acc)[4 * kMaxSources + 1], double *out, int lane) {
+  constexpr int NQ = 4 * kMaxSources + 1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      if ((q % kMaxSources) < MM || q == 4 * kMaxSources) acc[q] += __shfl_down(acc[q], off, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      if ((q % kMaxSources) < MM || q == 4 * kMaxSources) out[q] = acc[q];
+  }
+}
 __device__ __forceinline__ void reduce_scalars(int E, int M, int NN, const float *g_cx_e, const float *g_cy_e,
                                                const float *chi2_e, const float *a, const float *a_ref, float *shared,
                                                double *lanes, int tid, float *scl = nullptr) {
@@ -1432,12 +1450,18 @@ __device__ __forceinline__ void reduce_scalars(int E, int M, int NN, const float
     }
     acc[4 * kMaxSources] += (double)chi2_e[e];
   }
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    if ((q % kMaxSources) < M || q == 4 * kMaxSources) {
-      const double v = wave_sum_f64(acc[q]);
-      if (lane == 0) lanes[wid * NQ + q] = v;
-    }
+  // The 4 M + 1 shuffle trees side by side (wave_sums_f64: per quantity the same additions in the same order as one tree
+  // after the other, which is what the loop over the quantities compiled to with M known at run time only - every tree
+  // six dependent LDS-crossbar round trips, 2.9 us of this block's 5.9 at M = 2 and E = 200).
+  switch (M) {
+    case 1: wave_sums_f64<1>(acc, lanes + wid * NQ, lane); break;
+    case 2: wave_sums_f64<2>(acc, lanes + wid * NQ, lane); break;
+    case 3: wave_sums_f64<3>(acc, lanes + wid * NQ, lane); break;
+    case 4: wave_sums_f64<4>(acc, lanes + wid * NQ, lane); break;
+    case 5: wave_sums_f64<5>(acc, lanes + wid * NQ, lane); break;
+    case 6: wave_sums_f64<6>(acc, lanes + wid * NQ, lane); break;
+    case 7: wave_sums_f64<7>(acc, lanes + wid * NQ, lane); break;
+    default: wave_sums_f64<8>(acc, lanes + wid * NQ, lane); break;
   }
   __syncthreads();
   if (tid < NQ && ((tid % kMaxSources) < M || tid == 4 * kMaxSources)) {
@@ -1519,9 +1543,15 @@ __device__ __forceinline__ void phist_put(const JointUpdArgs &A, int which, int 
 // All threads of a block: block until *flag has reached seq (thread 0 polls, bounded: ~0.2 s).  No acquire fence follows: an
 // agent-scope acquire invalidates the L2 of the XCD, and a thousand blocks doing that cost 33 us; the few values the
 // chain produced are read with ld_coherent (L2-bypassing loads) instead, and the chain wrote its L2 back before the flag.
-__device__ __forceinline__ void wait_for_flag(const unsigned int *flag, unsigned int seq, unsigned int *err) {
+// (seen: what flag_seen() returned to thread 0 earlier in the kernel - a look at the flag requested together with the kernel's
+//  first loads, so that in the usual case, the chain long finished, the wait costs no memory round trip of its own)
+__device__ __forceinline__ bool flag_seen(const unsigned int *flag, unsigned int seq) {
+  return flag && threadIdx.x == 0 &&
+         (int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0;
+}
+__device__ __forceinline__ void wait_for_flag(const unsigned int *flag, unsigned int seq, unsigned int *err, bool seen = false) {
   if (flag) {
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !seen) {
       int spins = 0;
       while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
         __builtin_amdgcn_s_sleep(32);
