@@ -114,3 +114,38 @@ def test_two_stage_roi_fit_and_star_fit_at_a_size_without_a_kernel(ctx):
     assert res['residuals'].shape == (8, n, n) and np.isfinite(res['chi2']) and np.isfinite(res['fluxes']).all()
     assert res['deconvolved_image'].shape == (n * ss, n * ss)
     assert res['loss_curve'][-1] < res['loss_curve'][0]
+
+
+def test_embedded_parameter_history_and_bounds_keep_the_callers_layout(ctx):
+    """return_param_history=True (the reference's call sites pass it, roi_modelling.py:331): the device rows carry h at the
+    fitted size; the caller gets rows in its own layout, the last one equal to the final parameters.  Bounds on h given at
+    the caller's size are padded for the device L-BFGS."""
+    from lightcurver_amd.joint import make_joint_fit
+    n, ss, E, M = 20, 2, 3, 1
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=5)
+    j = make_joint_fit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
+    p = dict(ds['truth'])
+    p['a'] = np.asarray(p['a']) * 0.9
+    j.set_params(**p)
+    j.set_loss(lam_positivity=10.0)
+    free = ['a', 'dx', 'dy', 'h', 'mean']
+    j.set_free(free)
+    P = sum(j.sizes[k] for k in free)
+    assert j.param_history_begin(4) == P == E * M + 3 * E + (n * ss) ** 2
+    j.run_adabelief(4, init_learning_rate=1e-3, schedule_learning_rate=False)
+    rows = j.param_history(0, 4)
+    j.param_history_end()
+    assert rows.shape == (4, P)
+    final = j.get_params()
+    last = np.concatenate([np.ravel(final[k]) for k in ('a', 'dx', 'dy', 'h', 'mean')])
+    assert np.array_equal(rows[-1], last.astype(np.float32))
+    assert not np.array_equal(rows[0], rows[-1])
+    # bounded L-BFGS with a box on h at the caller's size
+    j.set_params(**p)
+    lo = {'h': np.full((n * ss) ** 2, -1e-3), 'a': np.zeros(E * M)}
+    hi = {'h': np.full((n * ss) ** 2, 1e-3), 'a': np.full(E * M, 1e10)}
+    hist, nit, nev = j.run_lbfgs(5, lo, hi)
+    h = j.get_params(['h'])['h']
+    assert h.shape == ((n * ss) ** 2,) and h.min() >= -1e-3 - 1e-9 and h.max() <= 1e-3 + 1e-9
+    assert np.isfinite(hist).all() and hist[-1] <= hist[0]
+    j.close()
