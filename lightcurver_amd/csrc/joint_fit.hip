@@ -84,6 +84,9 @@ struct lc_joint {
   float *mr_l1b = nullptr, *mr_posb = nullptr, *mr_S = nullptr, *mr_T = nullptr;  // second form of the chain: per-block values, S planes, product scratch
   hipStream_t streamB = nullptr;      // the h regulariser runs here, concurrently with the epoch kernel
   hipEvent_t evReg = nullptr, evUpd = nullptr;
+  const void *ps_attr_fn = nullptr;   // point-source kernel whose dynamic-LDS attribute has been set
+  std::vector<hipStream_t> gstreams;  // batched star photometry: the parts of the batch beyond the first run on these
+  std::vector<hipEvent_t> gevents;
   bool reg_pending = false;
   hipEvent_t *tl_events = nullptr;  // LCMI_TIMELINE diagnostic (lc_joint_run_adabelief)
   bool in_device_loop = false, fuse_pending = false;
@@ -279,7 +282,9 @@ void find_ps_kernel(int N, int ss, ps_fn *fn, int *lds, bool persist = false) {
 #undef LC_PS
 }
 
-int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model_out) {
+// (e0, e1, stream: the point-source-only kernel over the epochs [e0, e1) on `stream` - batched star photometry; default: all epochs)
+int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model_out, int e0 = 0, int e1 = -1,
+                  hipStream_t ps_stream = nullptr) {
   const JointVariant *v = j->v;
   JointArgs A;
   std::memset(&A, 0, sizeof(A));
@@ -332,8 +337,13 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
       P.J = A;
       P.psf = j->psf_dev;
       P.F = j->psF;
-      LC_HIP(j->ctx, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
-      hipLaunchKernelGGL(pk, dim3(j->E), dim3(kPsThreads), plds, j->ctx->stream, P);
+      if (j->ps_attr_fn != (const void *)pk) {  // (once per kernel, not per launch: the batched loop enqueues thousands)
+        LC_HIP(j->ctx, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
+        j->ps_attr_fn = (const void *)pk;
+      }
+      if (e1 < 0) e1 = j->E;
+      P.e_off = e0;
+      hipLaunchKernelGGL(pk, dim3(e1 - e0), dim3(kPsThreads), plds, ps_stream ? ps_stream : j->ctx->stream, P);
       LC_HIP(j->ctx, hipGetLastError());
       return 0;
     }
@@ -990,6 +1000,11 @@ void lc_joint_destroy(lc_joint *j) {
     hipStreamSynchronize(j->streamB);
     hipStreamDestroy(j->streamB);
   }
+  for (hipStream_t st : j->gstreams) {
+    hipStreamSynchronize(st);
+    hipStreamDestroy(st);
+  }
+  for (hipEvent_t ev : j->gevents) hipEventDestroy(ev);
   if (j->evReg) hipEventDestroy(j->evReg);
   if (j->evUpd) hipEventDestroy(j->evUpd);
   for (void *p : j->allocs) hipFree(p);
@@ -1511,25 +1526,75 @@ int upload_group_views(lc_joint *j, const lc_adabelief_cfg *cfg) {
   }
   return h2d(j, j->views_dev, views.data(), views.size() * sizeof(JointUpdArgs));
 }
-int group_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg) {
+int group_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, int g0 = 0, int g1 = -1, hipStream_t stream = nullptr) {
   lc_adabelief_cfg ab;
   if (cfg) ab = *cfg; else lc_adabelief_defaults(&ab);
   float lr, bc1, bc2;
   adabelief_schedule(ab, t, lr, bc1, bc2);
-  hipLaunchKernelGGL(joint_update_groups_kernel, dim3(2 * j->G), dim3(kGmThreads), 0, j->ctx->stream, j->views_dev, mode, t, lr, bc1, bc2);
+  if (g1 < 0) g1 = j->G;
+  hipLaunchKernelGGL(joint_update_groups_kernel, dim3(2 * (g1 - g0)), dim3(kGmThreads), 0, stream ? stream : j->ctx->stream,
+                     j->views_dev + g0, mode, t, lr, bc1, bc2);
   LC_HIP(j->ctx, hipGetLastError());
   return LC_OK;
 }
 int run_adabelief_groups(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg) {
   int rc = ensure_group_hist(j, j->iters_done + n_iter + 2);
   if (rc || (rc = upload_group_views(j, cfg))) return rc;
-  for (int it = 0; it < n_iter; ++it) {
-    int need = launch_epochs(j, 0, 0, false, nullptr);
-    if (need < 0) return need;
-    if ((rc = group_update(j, 1, j->iters_done, cfg))) return rc;
-    j->iters_done += 1;
+  // The stars are independent fits, and the update of a batch is a launch of two short blocks per star (a chain of memory
+  // round trips, ~15 us with the machine idle around it).  The batch therefore runs as K parts on K streams, each part its
+  // own sequence of kernel pairs, the first launches staggered: while one part steps, the point-source kernels of the
+  // others have the CUs.  Same kernels on the same operands per star: same bits.  (LCMI_GROUP_STREAMS=<K>, default 4;
+  // 1: every star in one kernel pair per iteration.)
+  int K = 4;
+  if (const char *ks = std::getenv("LCMI_GROUP_STREAMS")) K = std::atoi(ks);
+  K = std::max(1, std::min(std::min(K, j->G), 8));
+  if (K == 1) {
+    for (int it = 0; it < n_iter; ++it) {
+      int need = launch_epochs(j, 0, 0, false, nullptr);
+      if (need < 0) return need;
+      if ((rc = group_update(j, 1, j->iters_done, cfg))) return rc;
+      j->iters_done += 1;
+    }
+    return LC_OK;
   }
-  return LC_OK;
+  // contiguous parts of about E / K epochs each: part k = stars [gb[k], gb[k + 1])
+  std::vector<int> gb(K + 1, j->G);
+  gb[0] = 0;
+  for (int k = 1, g = 0; k < K; ++k) {
+    while (g < j->G - (K - k) && (long long)j->gstart[g + 1] * K <= (long long)j->E * k) ++g;
+    g = std::max(g, gb[k - 1] + 1);
+    gb[k] = g;
+  }
+  while ((int)j->gstreams.size() < K - 1) {
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    LC_HIP(j->ctx, hipStreamCreate(&st));
+    j->gstreams.push_back(st);
+    LC_HIP(j->ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    j->gevents.push_back(ev);
+  }
+  auto stream_of = [&](int k) { return k == 0 ? j->ctx->stream : j->gstreams[k - 1]; };
+  // fork: every part starts behind what the caller has enqueued, and part k's first kernel behind part k - 1's first
+  // point-source kernel (the stagger; afterwards the parts keep out of each other's way by themselves)
+  LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
+  for (int k = 1; k < K; ++k) LC_HIP(j->ctx, hipStreamWaitEvent(stream_of(k), j->evUpd, 0));
+  for (int it = 0; it < n_iter && !rc; ++it) {
+    for (int k = 0; k < K && !rc; ++k) {
+      hipStream_t q = stream_of(k);
+      if (it == 0 && k > 0) rc = (hipStreamWaitEvent(q, j->gevents[k - 1], 0) == hipSuccess) ? LC_OK : LC_ERR_DEVICE;
+      int need = rc ? -1 : launch_epochs(j, 0, 0, false, nullptr, j->gstart[gb[k]], j->gstart[gb[k + 1]], q);
+      if (!rc && need < 0) rc = need;
+      if (!rc && it == 0 && k < K - 1) rc = (hipEventRecord(j->gevents[k], q) == hipSuccess) ? LC_OK : LC_ERR_DEVICE;
+      if (!rc) rc = group_update(j, 1, j->iters_done, cfg, gb[k], gb[k + 1], q);
+    }
+    if (!rc) j->iters_done += 1;
+  }
+  // join (also on an error: nothing may be left running on the other streams behind the caller's back)
+  for (int k = 1; k < K; ++k) {
+    (void)hipEventRecord(j->gevents[k - 1], stream_of(k));
+    (void)hipStreamWaitEvent(j->ctx->stream, j->gevents[k - 1], 0);
+  }
+  return rc;
 }
 }  // namespace
 

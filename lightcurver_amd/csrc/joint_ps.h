@@ -56,6 +56,7 @@ struct JointPsArgs {
   // return_param_history: rows [T][phist_P] of the device-resident history; offsets of the free blocks in a row (-1: fixed)
   float *phist;
   int phist_P, poff_a, poff_dx, poff_dy, poff_mean;
+  int e_off;  // first epoch of this launch (a launch over a range of the epochs: batched star photometry, two halves on two streams)
 };
 
 // PERSIST: when every free parameter belongs to one epoch (fluxes, shifts, sky levels; the shared positions c_x, c_y held
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(kPsThreads) __attribute__((amdgpu_waves_per_eu((N <
   float *TAP = Rx + N * RS;            // [4][NT]  tx, dtx, ty, dty
   float *RED = TAP + 4 * NT;           // [NWV + 1][NQ]
   __shared__ int BQ[2];
-  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, M = A.M;
+  const int e = blockIdx.x + P.e_off, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, M = A.M;
   const float c0 = (N - 1) * 0.5f, c_off = c0 - (float)((N - 1) / 2);
   const float al = A.alpha[e] * 0.017453292519943295f;
   const float ca = cosf(al), sa = sinf(al);
