@@ -111,9 +111,23 @@ def do_many_stars_forward_modelling(stacks, subsampling_factor, n_iter=2000):
     ``star_photometry_uniform_background_per_epoch: false``, config.yaml:254-258): fluxes, the star's position and the
     per-epoch shifts free, no background.  Returns one dictionary per star with the keys of
     ``do_one_star_forward_modelling``; each star's numbers are bit for bit those of its own one-star fit."""
-    from ..joint import StarPhotometryBatch
+    from ..joint import StarPhotometryBatch, EmbeddedJointFit, joint_fit_size
     from ..starred.deconvolution.deconvolution import nest_kwargs
     ss = int(subsampling_factor)
+    # a stamp size without a kernel of its own: the stamps in the centre of the next instantiated size, no weight on the ring
+    # (what joint.EmbeddedJointFit does for the one-star fit; no background here, so only the model has to be cut back)
+    n_user = int(np.asarray(stacks[0][0]).shape[-1])
+    n_fit = joint_fit_size(n_user, ss)
+    pad = (n_fit - n_user) // 2
+
+    def embed(a, fill, f=1):
+        if pad == 0:
+            return a
+        a = np.asarray(a)
+        out = np.full((a.shape[0], n_fit * f, n_fit * f), fill, dtype=a.dtype)
+        out[:, pad * f:pad * f + n_user * f, pad * f:pad * f + n_user * f] = a
+        return out
+
     scales, guesses, dev_stacks = [], [], []
     for data, noisemap, psf in stacks:
         scale = np.nanmax(data)
@@ -121,7 +135,7 @@ def do_many_stars_forward_modelling(stacks, subsampling_factor, n_iter=2000):
         noisemap /= scale
         scales.append(scale)
         guesses.append(np.nansum(data, axis=(1, 2)) - data[0].size * _border_level(data))
-        dev_stacks.append((data, noisemap ** 2, psf))
+        dev_stacks.append((embed(data, 0.0), embed(noisemap ** 2, EmbeddedJointFit.RING_VARIANCE), embed(psf, 0.0, ss)))
     batch = StarPhotometryBatch(dev_stacks, ss, M=1)
     try:
         E, G, N = batch.E, batch.G, batch.N
@@ -133,6 +147,7 @@ def do_many_stars_forward_modelling(stacks, subsampling_factor, n_iter=2000):
         final = batch.get_params()
         hist = batch.loss_history()
         model, _ = batch.model()
+        model = model[:, pad:pad + n_user, pad:pad + n_user]
         sigma_a = batch.fisher_flux_sigma()
     finally:
         batch.close()
@@ -140,7 +155,7 @@ def do_many_stars_forward_modelling(stacks, subsampling_factor, n_iter=2000):
     for g, (data, noisemap, psf) in enumerate(stacks):
         e0, e1 = batch.starts[g], batch.starts[g + 1]
         flat = dict(a=final['a'][e0:e1], c_x=final['c_x'][g:g + 1], c_y=final['c_y'][g:g + 1], dx=final['dx'][e0:e1],
-                    dy=final['dy'][e0:e1], alpha=final['alpha'][e0:e1], h=np.zeros(N * N, np.float32), mean=final['mean'][e0:e1])
+                    dy=final['dy'][e0:e1], alpha=final['alpha'][e0:e1], h=np.zeros((n_user * ss) ** 2, np.float32), mean=final['mean'][e0:e1])
         k_final = nest_kwargs(flat)
         residuals = data - model[e0:e1]
         chi2_per_frame = np.nansum(residuals ** 2 / noisemap ** 2, axis=(1, 2)) / data.shape[1] ** 2

@@ -149,3 +149,20 @@ def test_embedded_parameter_history_and_bounds_keep_the_callers_layout(ctx):
     assert h.shape == ((n * ss) ** 2,) and h.min() >= -1e-3 - 1e-9 and h.max() <= 1e-3 + 1e-9
     assert np.isfinite(hist).all() and hist[-1] <= hist[0]
     j.close()
+
+
+def test_batched_star_photometry_at_a_size_without_a_kernel_equals_the_one_star_fits(ctx):
+    """do_many_stars_forward_modelling embeds the stamps as the one-star path does (joint.EmbeddedJointFit behind Deconv): per
+    star the same fluxes, caller-sized residuals."""
+    from lightcurver_amd.processes.star_photometry import do_one_star_forward_modelling, do_many_stars_forward_modelling
+    n, ss = 28, 2
+    sets = [make_roi_dataset(E=E, M=1, n=n, ss=ss, seed=90 + E) for E in (6, 9)]
+    ones = [do_one_star_forward_modelling(d['data'].copy(), d['noisemap'].copy(), d['psf'], ss, n_iter=200,
+                                          starlet_global_background=False) for d in sets]
+    many = do_many_stars_forward_modelling([(d['data'].copy(), d['noisemap'].copy(), d['psf']) for d in sets], ss, n_iter=200)
+    for a, b, d in zip(ones, many, sets):
+        assert b['residuals'].shape == d['data'].shape
+        assert np.asarray(b['kwargs_final']['kwargs_background']['h']).size == (n * ss) ** 2
+        assert np.allclose(a['fluxes'], b['fluxes'], rtol=1e-5, atol=0.0)
+        assert np.allclose(a['fluxes_uncertainties'], b['fluxes_uncertainties'], rtol=1e-4)
+        assert abs(a['chi2'] - b['chi2']) < 1e-4 * abs(a['chi2'])
