@@ -42,6 +42,40 @@ def shard_kwargs(flat, n_epochs, n_sources, world_size, rank):
     return out
 
 
+_HOST_GROUPS = {}
+
+
+def host_group(group=None):
+    """A gloo group over the ranks of ``group`` for the object collectives of this module (errors, IPC handles, per-epoch
+    blocks): they carry pickled host objects, which an NCCL group would stage through device tensors on whatever device
+    happens to be current.  ``group`` itself when it is gloo already; otherwise a gloo group created once per group -
+    COLLECTIVELY: every rank of ``group`` must make its first call at the same point (PeerGroup and ShardedJointOptimizer do
+    it in their constructors)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_backend(group) == 'gloo':
+        return group
+    key = id(group) if group is not None else None
+    if key not in _HOST_GROUPS:
+        ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+        _HOST_GROUPS[key] = dist.new_group(ranks=ranks, backend='gloo')
+    return _HOST_GROUPS[key]
+
+
+def raise_together(err, what, group=None):
+    """Every rank hands in its error (None = fine); if any rank has one, EVERY rank raises - a rank that raised alone would
+    leave the others waiting for it in their next collective until the backend's time-out."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if err:
+            raise RuntimeError(f'{what}: {err}')
+        return
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, err, group=host_group(group))
+    bad = [(r, e) for r, e in enumerate(parts) if e]
+    if bad:
+        raise RuntimeError(f'{what}: ' + '; '.join(f'rank {r}: {e}' for r, e in bad))
+
+
 class PeerGroup:
     """One-shot peer-memory all-reduce of a fit's shared block (include/lcmi.h "peer group", csrc/peer.hip): every rank
     publishes its block in an exchange buffer the other ranks map with HIP IPC and reads the N - 1 peers directly, adding
@@ -54,6 +88,7 @@ class PeerGroup:
         self._l = _lib.lib()
         self.fit = local_fit
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.group = group = host_group(group)
         _, count = local_fit.shared_buffer()
         # a rank whose step fails still takes part in the exchanges that follow, so that every rank raises instead of one
         # raising and the others waiting for it in a collective
@@ -83,7 +118,7 @@ class PeerGroup:
     def _raise_if_any(self, errors, what):
         bad = [(r, e) for r, e in enumerate(errors) if e]
         if bad:
-            self.close()
+            self.close(barrier=False)   # (every rank is here with the same list, and no kernel has touched the buffers yet)
             raise RuntimeError(f'peer group ({what}): ' + '; '.join(f'rank {r}: {e}' for r, e in bad))
 
     def callback(self):
@@ -92,10 +127,36 @@ class PeerGroup:
         return C.cast(self._l.lc_peer_allreduce, C.c_void_p), self.h
 
     def check(self):
+        """Raises on THIS rank if one of its waits ran out (synchronises the library's stream)."""
         self.fit.ctx.check(self._l.lc_peer_group_status(self.h), 'peer all-reduce')
 
-    def close(self):
+    def status(self):
+        """The same as a string (None = every wait was answered), for raise_together."""
+        try:
+            self.check()
+            return None
+        except Exception as e:  # noqa: BLE001
+            return repr(e)
+
+    def check_together(self):
+        """Every rank raises if ANY rank's wait ran out (one small host collective)."""
+        raise_together(self.status(), 'peer all-reduce', self.group)
+
+    def close(self, barrier=True):
+        """Unmaps the peers and frees the exchange buffer.  A peer may still be inside its last read of this rank's buffer
+        when the local stream has drained, so the ranks first meet at a host barrier (bounded: a rank that died must not
+        hang the others' clean-up; after a time-out the buffer is freed anyway - the peer is gone or broken)."""
         if getattr(self, 'h', None):
+            if barrier:
+                try:
+                    import datetime
+                    import torch.distributed as dist
+                    if dist.is_initialized() and self.world > 1:
+                        if hasattr(self.fit.ctx, 'synchronize'):
+                            self.fit.ctx.synchronize()
+                        dist.monitored_barrier(group=self.group, timeout=datetime.timedelta(seconds=20))
+                except Exception:  # noqa: BLE001
+                    pass
             self._l.lc_peer_group_destroy(self.h)
             self.h = None
 
@@ -105,7 +166,7 @@ class PeerGroup:
         try:
             import sys
             if not sys.is_finalizing():
-                self.close()
+                self.close(barrier=False)   # (a collective has no place in a finaliser: the caller's close() is the clean path)
         except Exception:
             pass
 
@@ -124,6 +185,7 @@ class ShardedJointOptimizer:
         self.fit = local_fit
         self.group = group
         self.peer = peer
+        self.host_group = host_group(group)   # (collective on first use: see host_group)
         self._dev = None  # (tensor view of the shared block, torch ExternalStream of the library's stream)
         self._ref_agreed = False
 
@@ -200,9 +262,17 @@ class ShardedJointOptimizer:
         if hasattr(self.fit, 'run_sharded'):
             # the loop itself runs in C++ (lc_joint_run_sharded): per iteration step_local, this callback, step_update
             if self.peer is not None:
-                fn, user = self.peer.callback()
-                self.fit.run_sharded(int(n_iter), fn, user, **adabelief_cfg)
-                self.peer.check()
+                # a wait that ran out leaves that rank's block un-reduced and is latched in its status word only: the ranks
+                # agree on the outcome, so that all of them raise instead of one raising and the rest walking into their
+                # next collective alone
+                err = None
+                try:
+                    fn, user = self.peer.callback()
+                    self.fit.run_sharded(int(n_iter), fn, user, **adabelief_cfg)
+                    self.peer.check()
+                except Exception as e:  # noqa: BLE001
+                    err = repr(e)
+                raise_together(err, 'sharded joint fit (peer all-reduce)', self.host_group)
                 return
             failure = []
 
@@ -252,6 +322,7 @@ def sharded_lbfgs(optimizer, free, maxiter, lower=None, upper=None):
     import torch.distributed as dist
     from scipy.optimize import minimize
     fit, group = optimizer.fit, optimizer.group
+    hgroup = getattr(optimizer, 'host_group', None) or host_group(group)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     free = [k for k in ('c_x', 'c_y', 'h', 'a', 'dx', 'dy', 'mean') if k in free]
     fit.set_free(free)
@@ -266,8 +337,22 @@ def sharded_lbfgs(optimizer, free, maxiter, lower=None, upper=None):
         if world == 1:
             return np.asarray(vec, np.float64)
         parts = [None] * world
-        dist.all_gather_object(parts, np.asarray(vec, np.float64), group=group)
+        dist.all_gather_object(parts, np.asarray(vec, np.float64), group=hgroup)
         return np.concatenate(parts)
+
+    def gather_all(vecs, err):
+        """the local per-epoch blocks of one evaluation and this rank's error in ONE host collective: every rank learns of a
+        failure anywhere (and raises with it) before it uses the numbers"""
+        if world == 1:
+            if err:
+                raise RuntimeError(f'sharded L-BFGS-B: {err}')
+            return [np.asarray(v, np.float64) for v in vecs]
+        parts = [None] * world
+        dist.all_gather_object(parts, (err, [np.asarray(v, np.float64) for v in vecs]), group=hgroup)
+        bad = [(r, p[0]) for r, p in enumerate(parts) if p[0]]
+        if bad:
+            raise RuntimeError('sharded L-BFGS-B: ' + '; '.join(f'rank {r}: {e}' for r, e in bad))
+        return [np.concatenate([p[1][i] for p in parts]) for i in range(len(vecs))]
 
     sizes_local = {k: cur[k].size for k in free}
     full = {k: (gather(cur[k]) if k in PER_EPOCH else cur[k]) for k in free}
@@ -278,7 +363,7 @@ def sharded_lbfgs(optimizer, free, maxiter, lower=None, upper=None):
     # where the rank's own entries sit inside the gathered per-epoch blocks
     counts = [None] * world
     if world > 1:
-        dist.all_gather_object(counts, int(fit.E), group=group)
+        dist.all_gather_object(counts, int(fit.E), group=hgroup)
     else:
         counts = [int(fit.E)]
     rank = dist.get_rank(group) if world > 1 else 0
@@ -305,24 +390,45 @@ def sharded_lbfgs(optimizer, free, maxiter, lower=None, upper=None):
         for k in free:
             blk = x[offs[k][0]:offs[k][1]]
             p[k] = blk[own(k)] if k in PER_EPOCH else blk
-        fit.set_params(**p)
-        if ref is not None:
-            fit.set_flux_reference(ref)
-        fit.step_local()
-        if optimizer.peer is not None:
-            import ctypes as C
-            fn, user = optimizer.peer.callback()
-            ptr, count = fit.shared_buffer()
-            stream, _ = fit.ctx.stream()
-            rc = optimizer.peer._l.lc_peer_allreduce(user, C.c_void_p(ptr), count, C.c_void_p(stream))
-            if rc:
-                raise RuntimeError(f'lc_peer_allreduce failed ({rc})')
-        elif optimizer._device_collective():
-            optimizer.all_reduce_device()
-        else:
-            fit.shared_set(optimizer.all_reduce(fit.shared_get()))
-        loss, g = fit.step_grad(tuple(free))
-        grad = np.concatenate([gather(g[k]) if k in PER_EPOCH else np.asarray(g[k], np.float64) for k in free])
+        # A failure on one rank must stop every rank at the same evaluation: none may optimise on with local-only numbers or
+        # wait alone in a collective.  The local step's outcome is agreed BEFORE the data all-reduce (a rank that skipped it
+        # would leave the others waiting in it); what the all-reduce itself reports - a peer wait that ran out leaves that
+        # rank's block un-reduced and latches a status word - travels with the gradient gather below.
+        err, loss, g = None, float('nan'), None
+        try:
+            fit.set_params(**p)
+            if ref is not None:
+                fit.set_flux_reference(ref)
+            fit.step_local()
+        except Exception as e:  # noqa: BLE001
+            if world == 1:
+                raise
+            err = repr(e)
+        if world > 1:
+            raise_together(err, 'sharded L-BFGS-B (local step)', hgroup)
+        try:
+            if optimizer.peer is not None:
+                import ctypes as C
+                fn, user = optimizer.peer.callback()
+                ptr, count = fit.shared_buffer()
+                stream, _ = fit.ctx.stream()
+                rc = optimizer.peer._l.lc_peer_allreduce(user, C.c_void_p(ptr), count, C.c_void_p(stream))
+                if rc:
+                    raise RuntimeError(f'lc_peer_allreduce failed ({rc})')
+                optimizer.peer.check()       # (synchronises the stream, as the gradient read-back below would anyway)
+            elif optimizer._device_collective():
+                optimizer.all_reduce_device()
+            else:
+                fit.shared_set(optimizer.all_reduce(fit.shared_get()))
+            loss, g = fit.step_grad(tuple(free))
+        except Exception as e:  # noqa: BLE001
+            if world == 1:
+                raise
+            err = repr(e)
+        per_epoch = [k for k in free if k in PER_EPOCH]
+        local = [g[k] if g is not None else np.zeros(sizes_local[k]) for k in per_epoch]
+        gathered = dict(zip(per_epoch, gather_all(local, err)))
+        grad = np.concatenate([gathered[k] if k in PER_EPOCH else np.asarray(g[k], np.float64) for k in free])
         last['x'], last['val'] = np.array(x, copy=True), float(loss)
         return float(loss), grad
 
@@ -346,8 +452,9 @@ def gather_epoch_blocks(local_flat, n_sources, group=None):
         return dict(local_flat)
     world = dist.get_world_size(group)
     out = dict(local_flat)
-    for k in ('a', 'dx', 'dy', 'alpha', 'mean'):
-        parts = [None] * world
-        dist.all_gather_object(parts, np.asarray(local_flat[k]), group=group)
-        out[k] = np.concatenate(parts)
+    keys = ('a', 'dx', 'dy', 'alpha', 'mean')
+    parts = [None] * world
+    dist.all_gather_object(parts, [np.asarray(local_flat[k]) for k in keys], group=host_group(group))
+    for i, k in enumerate(keys):
+        out[k] = np.concatenate([p[i] for p in parts])
     return out

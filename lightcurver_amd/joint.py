@@ -155,11 +155,16 @@ class JointFit:
         return n.value
 
     def _flush_pending_history(self):
-        """A history handed out lazily (starred/optim/optimization.py) comes to the host before its buffer goes away."""
-        pending = getattr(self, '_pending_param_history', None)
-        if pending is not None:
+        """A history handed out lazily (starred/optim/optimization.py: a weak reference to it is kept here) comes to the host
+        before its buffer goes away - if somebody still holds it; a history nobody kept is dropped on the device, uncopied."""
+        ref = getattr(self, '_pending_param_history', None)
+        if ref is not None:
             self._pending_param_history = None
-            pending.materialize()
+            pending = ref()
+            if pending is not None:
+                pending.materialize()
+            elif getattr(self, 'h', None):
+                self._l.lc_joint_param_history_end(self.h)
 
     def param_history(self, first=0, count=None):
         rows = self._l.lc_joint_param_history_rows(self.h)

@@ -151,7 +151,7 @@ def model_roi_cutouts_sharded(data, noisemap, psf, subsampling_factor, xs_pixels
     loss histories and the Fisher 1-sigma of the fluxes at the final point."""
     import torch
     import torch.distributed as dist
-    from ..distributed import PeerGroup, ShardedJointOptimizer, gather_epoch_blocks
+    from ..distributed import PeerGroup, ShardedJointOptimizer, gather_epoch_blocks, host_group
     from ..joint import JointFit
     from .. import _lib
     reg = dict(DEFAULT_REGULARIZATION)
@@ -195,7 +195,7 @@ def model_roi_cutouts_sharded(data, noisemap, psf, subsampling_factor, xs_pixels
         sigma_loc = np.asarray(fit.fisher_flux_sigma(), np.float64)
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             parts = [None] * dist.get_world_size(group)
-            dist.all_gather_object(parts, sigma_loc, group=group)
+            dist.all_gather_object(parts, sigma_loc, group=host_group(group))
             sigma = np.concatenate(parts)
         else:
             sigma = sigma_loc
@@ -203,6 +203,8 @@ def model_roi_cutouts_sharded(data, noisemap, psf, subsampling_factor, xs_pixels
         return dict(flat_final=final, loss_history=np.asarray(fit.loss_history(), np.float64)[:-1], loss_history_stage1=hist1,
                     fluxes_sigma=sigma, scale=scale, W=W)
     finally:
+        # (errors of the sharded stages are agreed over the ranks before they are raised - distributed.raise_together - so every
+        #  rank arrives here, and the bounded host barrier inside peer.close() finds its partners)
         if peer is not None:
             peer.close()
         fit.close()

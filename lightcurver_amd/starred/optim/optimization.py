@@ -39,13 +39,22 @@ class Optimizer:
         cfg = dict(init_learning_rate=init_learning_rate, schedule_learning_rate=bool(schedule_learning_rate),
                    decay_rate=decay_rate, transition_steps=transition_steps)
         param_history = []
-        if n_iter > 0 and not stop_at_loss_increase:
-            # one call: the whole loop stays on the device.  return_param_history=True - what the reference's own call
-            # sites pass (star_photometry.py:119, roi_modelling.py:331) - records the free blocks after every update in a
-            # device-resident history; it comes to the host when extra_fields['param_history'] is first looked at
-            if return_param_history:
-                if fit.param_history_begin(n_iter) != p.num_parameters:
+        on_device = n_iter > 0 and not stop_at_loss_increase
+        if on_device and return_param_history:
+            # return_param_history=True - what the reference's own call sites pass (star_photometry.py:119,
+            # roi_modelling.py:331) - records the free blocks after every update in a device-resident history; it comes to
+            # the host only if extra_fields['param_history'] is looked at.  A history that does not fit in device memory
+            # (n_iter x P floats) must not fail the fit: the rows are then collected by the host loop below
+            from ..._lib import LcError
+            try:
+                rows = fit.param_history_begin(n_iter)
+            except LcError:
+                on_device = False
+            else:
+                if rows != p.num_parameters:
                     raise RuntimeError('parameter history: row length differs from the number of free parameters')
+        if on_device:
+            # one call: the whole loop stays on the device
             fit.run_adabelief(n_iter, **cfg)
             if return_param_history:
                 param_history = _DeviceParamHistory(fit, n_iter)
@@ -129,17 +138,21 @@ class Optimizer:
 class _DeviceParamHistory:
     """``extra_fields['param_history']``: the parameter vector after every update (a sequence of ``max_iterations``
     float64 vectors in kwargs2args order).  The rows live on the device until the sequence is first read; then one copy
-    brings them over and the device buffer is released.  ``materialize()`` is also called by whatever next needs the fit."""
+    brings them over and the device buffer is released.  The fit keeps only a WEAK reference to this object: when the fit
+    next needs its history buffer (set_free, another param_history_begin, close) it calls ``materialize()`` if somebody
+    still holds the sequence, and just releases the device rows if nobody does (no copy for a history nobody read)."""
 
     def __init__(self, fit, n_rows):
+        import weakref
         self._fit, self._n, self._rows = fit, int(n_rows), None
-        fit._pending_param_history = self
+        fit._pending_param_history = weakref.ref(self)
 
     def materialize(self):
         if self._rows is None:
             self._rows = np.asarray(self._fit.param_history(0, self._n), dtype=np.float64)
             self._fit.param_history_end()
-            if getattr(self._fit, '_pending_param_history', None) is self:
+            ref = getattr(self._fit, '_pending_param_history', None)
+            if ref is not None and ref() is self:
                 self._fit._pending_param_history = None
             self._fit = None
         return self._rows

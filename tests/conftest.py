@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'perf: wall-clock expectations (kept apart from the correctness tests; tests/test_zz_perf_gpu.py)')
 
 
 @pytest.fixture(scope='session')

@@ -6,6 +6,9 @@ import torch
 
 from oracle import model as om
 
+# wall-clock ratios measured inside correctness tests; asserted by tests/test_zz_perf_gpu.py only (marker `perf`)
+PERF = {}
+
 
 def psf_oracle_inputs(ds, f, ss):
     data = om.T(ds['data'][f])

@@ -170,6 +170,41 @@ def test_param_history_and_early_stop():
     assert 5 <= lh.size < 400 and lh[-1] > lh[-2] and np.all(np.diff(lh[4:-1]) <= 0)
 
 
+def test_param_history_is_copied_only_if_somebody_holds_it():
+    """The device-resident history costs a device-to-host copy only when it is read: a history the caller dropped is
+    released on the device when the fit next needs the buffer (weak reference in the fit), a history the caller still
+    holds comes over before the buffer goes away, and a history that cannot be allocated on the device falls back to the
+    host-collected rows instead of failing the fit."""
+    from lightcurver_amd.starred.optim.optimization import Optimizer
+    from lightcurver_amd import _lib
+    T = 8
+    kw = dict(max_iterations=T, init_learning_rate=1e-3, schedule_learning_rate=True, restart_from_init=True,
+              return_param_history=True)
+    model, pars, loss, *_ = _small_fit()
+    fit = loss.configure()
+    copies = []
+    real = fit.param_history
+    fit.param_history = lambda *a, **k: (copies.append(1), real(*a, **k))[1]
+    opt = Optimizer(loss, pars, method='adabelief')
+    best, _, extra, _ = opt.minimize(**kw)
+    del extra                                  # nobody holds the history
+    fit.set_free(pars.free)                    # the fit needs its buffer again: dropped on the device, no copy
+    assert copies == [] and fit._l.lc_joint_param_history_rows(fit.h) == 0
+    best, _, extra, _ = opt.minimize(**kw)
+    held = extra['param_history']
+    fit.set_free(pars.free)                    # held: copied before the buffer goes away
+    assert copies == [1] and np.array_equal(np.asarray(held[-1]), np.asarray(best))
+    # allocation failure -> host-collected rows, same numbers
+    real_begin = fit.param_history_begin
+    def failing(capacity):
+        raise _lib.LcError('lc_joint_param_history_begin: out of memory (test)')
+    fit.param_history_begin = failing
+    best2, _, extra2, _ = opt.minimize(**kw)
+    fit.param_history_begin = real_begin
+    assert np.array_equal(np.asarray(extra2['param_history'], dtype=np.float32), np.asarray(held, dtype=np.float32))
+    assert np.array_equal(np.asarray(best2), np.asarray(best))
+
+
 def test_edited_pixels_are_seen_by_the_device_object():
     """Deconv re-uploads its inputs whenever ANY byte of data / variance changed (full hash), e.g. after masking a
     single pixel between two calls as star_photometry.py:309-316 does."""

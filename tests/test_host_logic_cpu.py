@@ -315,6 +315,78 @@ def test_sharded_lbfgs_stage_equals_single_rank_gloo():
         assert np.allclose(got[k], ref.x[offs[i]:offs[i + 1]], rtol=1e-5, atol=1e-7), k
 
 
+class _FailingPeer:
+    """Stands in for distributed.PeerGroup on CPU: the callback is never called (the stand-in fit's run_sharded ignores it),
+    check() reports a wait that ran out on ``bad_rank`` only - what csrc/peer.hip leaves behind after a time-out."""
+
+    def __init__(self, rank, bad_rank):
+        self.rank, self.bad = rank, bad_rank
+
+    def callback(self):
+        return None, None
+
+    def check(self):
+        if self.rank == self.bad:
+            raise RuntimeError('peer all-reduce: a rank did not publish its block in time')
+
+
+def _rank_main_errors(rank, world, port, ret):
+    import torch.distributed as dist
+    from lightcurver_amd.distributed import ShardedJointOptimizer, shard_epochs, shard_kwargs
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    ds, p, data, sig2, psf = _problem()
+    lo, hi = shard_epochs(4, world, rank)
+    flat = {k: v.numpy() for k, v in p.items()}
+    loc = {k: om.T(v) for k, v in shard_kwargs(flat, 4, 2, world, rank).items()}
+    fit = OracleLocalFit(data[lo:hi], sig2[lo:hi], psf[lo:hi], 2, loc, dict(sc=0.0, hf=0.0, pos=0.0, fu=0.4))
+    out = {}
+    # (1) AdaBelief loop over the peer transport: rank 1's wait ran out -> both ranks raise, naming rank 1
+    fit.run_sharded = lambda n_iter, fn, user, **cfg: None
+    opt = ShardedJointOptimizer(fit, peer=_FailingPeer(rank, 1))
+    try:
+        opt.run(3, init_learning_rate=1e-3)
+        out['run'] = 'no error'
+    except RuntimeError as e:
+        out['run'] = str(e)
+    del fit.run_sharded
+    # (2) L-BFGS-B stage: rank 1's third evaluation fails -> both ranks raise at that evaluation, nobody hangs in a gather
+    calls = [0]
+    real = fit.step_local
+
+    def flaky():
+        calls[0] += 1
+        if rank == 1 and calls[0] == 3:
+            raise RuntimeError('device step failed (test)')
+        real()
+
+    fit.step_local = flaky
+    try:
+        ShardedJointOptimizer(fit).run_lbfgs(['a', 'dx', 'dy'], 30, lower={'a': 0.0})
+        out['lbfgs'] = 'no error'
+    except RuntimeError as e:
+        out['lbfgs'] = str(e)
+    out['calls'] = calls[0]
+    ret[rank] = out
+    dist.barrier()        # both ranks are still in step: the next collective finds its partner
+    dist.destroy_process_group()
+
+
+def test_a_failure_on_one_rank_raises_on_every_rank_gloo():
+    """a peer wait that ran out (or any failing step) on ONE rank must stop ALL ranks together - the others would
+    otherwise optimise on and hang in their next host collective until the gloo time-out."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_rank_main_errors, args=(2, port, ret), nprocs=2, join=True)
+    for rank in (0, 1):
+        assert 'rank 1' in ret[rank]['run'] and 'did not publish' in ret[rank]['run'], ret[rank]
+        assert 'rank 1' in ret[rank]['lbfgs'] and 'device step failed' in ret[rank]['lbfgs'], ret[rank]
+        assert ret[rank]['calls'] == 3
+
+
 def test_blended_neighbour_is_split_off_and_masked():
     """A neighbour whose wings touch the central star forms ONE connected group with it above 3 sigma; sep's
     multi-threshold de-blending (deblend_cont = 0.001, psf_modelling.py:51-52) splits the group, so the neighbour is

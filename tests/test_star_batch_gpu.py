@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from lightcurver_amd.synthetic import make_roi_dataset
+from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
@@ -123,5 +124,6 @@ def test_thirty_stars_in_one_call_against_the_loop(ctx):
         assert out[g]['chi2'] == ref[g]['chi2'] and np.array_equal(out[g]['residuals'], ref[g]['residuals'])
     # measured on MI355X: loop 1.6 s, batch 0.19 - 0.22 s (7 - 8.5 x; 62 us per iteration for all 30 stars against 30 x 26 us:
     # the batch is bound by the throughput of 3000 epoch workgroups, the loop by launch latency)
-    # (the bound leaves room for a slow box and for one-time costs inside the timed call - a second stream's first use)
-    assert t_loop / t_batch >= 3.0
+    # Timing is NOT asserted here: a noisy box must not turn a correctness test red under -x and hide what is collected after
+    # it.  The ratio is handed to tests/test_zz_perf_gpu.py (marker `perf`, last file of the run).
+    H.PERF['star_batch_over_loop'] = t_loop / t_batch
