@@ -225,6 +225,15 @@ int lc_joint_run_lbfgs(lc_joint *j, int maxiter, const float *const lower[LC_P_C
                        int *n_iterations, int *n_evaluations);
 int lc_joint_get_loss_history(lc_joint *j, float *history, int count);
 int lc_joint_iterations_done(lc_joint *j);
+/* Few epochs per GPU (a rank's share of a sharded fit; the reference keeps all epochs on one device,
+ * lightcurver/processes/roi_modelling.py:154-160,213, and has no counterpart): inside lc_joint_run_adabelief /
+ * lc_joint_run_sharded the epoch kernel of a 64 x 64 fit runs as a CLUSTER launch - several workgroups per epoch in one
+ * launch, phases separated by arrival counters in device memory - when all of them are resident together.  Every wait is
+ * bounded; a run in which one gave up is redone by the library with one workgroup per epoch (lc_joint_run_adabelief) or
+ * reported (lc_joint_run_sharded), and the object keeps the one-workgroup kernel afterwards.  parts_last: workgroups per epoch
+ * of the most recent epoch launch (0 = one-workgroup kernel); fallbacks: runs in which a wait gave up.  LCMI_CLUSTER=0
+ * switches the form off, LCMI_CLUSTER=<P> forces the count. */
+int lc_joint_cluster_info(lc_joint *j, int *parts_last, int *fallbacks);
 /* Optimizer.minimize(..., return_param_history=True) - what the reference's own call sites pass
  * (lightcurver/processes/star_photometry.py:115-122, roi_modelling.py:326-334).  begin: from now on every AdaBelief update
  * also stores the free parameter blocks (in block order a, c_x, c_y, dx, dy, h, mean; *n_params = their total length) into

@@ -102,6 +102,7 @@ SIGNATURES = {
     'lc_joint_run_lbfgs': (C.c_int, [vp, C.c_int, C.POINTER(fp), C.POINTER(fp), fp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'lc_joint_get_loss_history': (C.c_int, [vp, fp, C.c_int]),
     'lc_joint_iterations_done': (C.c_int, [vp]),
+    'lc_joint_cluster_info': (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'lc_joint_param_history_begin': (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
     'lc_joint_param_history_rows': (C.c_int, [vp]),
     'lc_joint_param_history_get': (C.c_int, [vp, C.c_int, C.c_int, fp]),

@@ -37,15 +37,21 @@ struct JointVariant {
   epoch_fn ek_phase_tile[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int e_lds_lite = 0, e_lds_lite_tile = 0;  // LDS of the column phases and of phase D (JointCfg::LDS_LITE)
   int lpf = 16;                             // lanes per transform (JointCfg::LPF)
+  // cluster form (joint_kernels.h, PHASE = 7): several workgroups per epoch in ONE launch, spectrum in the global scratch;
+  // a build of its own beside an LDS-spectrum kernel (same N, SS, L: same spectra)
+  epoch_fn ek_cluster = nullptr;
+  int cl_lds = 0, cl_thr = 0, cl_lpf = 16;
 };
 
 typedef void (*mreg_fn)(MregArgs);
 typedef void (*mreg_mm_fn)(MmBatch);
+typedef void (*mreg_chain_fn)(MregChainArgs);
 struct MregKernels {
   int N;
   mreg_fn fwd, adj;
   int lds_fwd, lds_adj, nthr;
   mreg_mm_fn mm;  // batched tiled products of the second form of the chain (joint_reg_mfma.h)
+  mreg_chain_fn chain;  // the whole second form as one launch (null: not built for this N)
 };
 
 struct lc_joint {
@@ -105,6 +111,14 @@ struct lc_joint {
   JointUpdArgs *views_dev = nullptr;
   float *ghist = nullptr, *shared_g = nullptr, *a_ref_g = nullptr, *out_loss_g = nullptr;
   int ghist_cap = 0;
+  // cluster launches of the epoch kernel (few epochs per GPU): flag words [E][kClStride], then the abort word
+  unsigned int *cl_ctr = nullptr;
+  unsigned int cl_base = 0;
+  unsigned int *chain_flags = nullptr;  // one-launch regulariser chain: [kChainBlocks] sync words, then the abort word
+  unsigned int chain_base = 0;
+  bool chain_off = false, chain_used = false;
+  bool cluster_off = false, in_sharded_loop = false;
+  int cl_parts_last = 0, cl_fallbacks = 0;
   // return_param_history: device-resident [phist_cap][phist_P] rows of the free blocks, one per AdaBelief update
   float *phist = nullptr;
   int phist_cap = 0, phist_P = 0, phist_rows = 0, phist_off[LC_P_COUNT] = {};
@@ -137,6 +151,17 @@ JointVariant make_jv() {
   typedef JointCfg<N, SS, L, NW, false, LPF> C;
   return JointVariant{C::n, SS, L, joint_epoch_kernel<C>, C::LDS_BYTES, C::NTHR, joint_update_kernel<N, PX>, N * N / PX,
                       (int)(StarletLds<N>::FLOATS * sizeof(float)), false, joint_epoch_kernel<C, true>};
+}
+// ... with the cluster form beside it: four-wave workgroups (one wave per SIMD), spectrum in the global scratch
+template <int N, int SS, int L, int PX, int NW, int LPF, int CNW, int CLPF>
+JointVariant make_jv_cl() {
+  JointVariant v = make_jv<N, SS, L, PX, NW, LPF>();
+  typedef JointCfg<N, SS, L, CNW, true, CLPF> CC;
+  v.ek_cluster = joint_epoch_kernel<CC, false, 7>;
+  v.cl_lds = CC::LDS_BYTES;
+  v.cl_thr = CC::NTHR;
+  v.cl_lpf = CLPF;
+  return v;
 }
 // stamp sizes beside the tuned ones (any multiple of 8 up to 64 at ss = 2): the same epoch kernel at that N, regulariser and
 // update as the run-time-N multi-block kernels (joint_gm.h) instead of a single-workgroup kernel built per size
@@ -200,7 +225,7 @@ const JointVariant *find_jv(int n, int ss, int E = 0, int n_cu = 0) {
       make_jv_plain<96, 2, 192, 8>(),    // n = 48
       make_jv_plain<112, 2, 192, 8>(),   // n = 56
       // n = 64 (C4); 16 waves with 32-lane transforms (4 waves per SIMD, 128 registers, 34 spilled) measured 2 % slower
-      make_jv<128, 2, 192, 16, 8>(),
+      make_jv_cl<128, 2, 192, 16, 8, 16, 4, 16>(),
       // n = 128 (C5): transforms over 32 lanes (12 registers per lane like the n = 64 kernel; at 16 lanes the 24-register
       // transforms spilled 200+ registers, and 4 waves with 436 registers each measured 1.23 x slower than that)
       make_jv_gm<256, 2, 384, 8, 32>(),
@@ -282,6 +307,26 @@ void find_ps_kernel(int N, int ss, ps_fn *fn, int *lds, bool persist = false) {
 #undef LC_PS
 }
 
+// Workgroups per epoch of the cluster form for the next forward + backward launch of this object (0: the one-workgroup
+// kernel).  Inside the library's own loops only, and all workgroups of the launch resident together, one per CU.  P
+// four-wave workgroups per epoch: six turn every phase into one sweep (24 waves x 4 transforms = the 96 column transforms).
+// OPT-IN (LCMI_CLUSTER=<P>; "auto": as many as fit, up to six), not the default.  Measured on MI355X at 25 epochs of 64 x 64 (a
+// rank's share of a sharded C4; profiles/r04_cluster_*): the epoch kernel itself takes 42.2 us as a cluster of six against
+// 53.5 us with one workgroup per epoch, and an iteration WITHOUT the starlet regulariser 47.0 against 61.1 us - but with the
+// regulariser on (the reference's ROI fit) the iteration is bound by the regulariser chain on the second stream (~60 us for
+// its eight stages, as launches or as one launch: each stage is a cross-CU hand-off of 5 - 7 us), which the 53 us kernel
+// hides and the 42 us kernel does not: 66.8 against 65.0 us per iteration.  The form pays once the chain is shorter than it.
+int cluster_parts(const lc_joint *j) {
+  const JointVariant *v = j->v;
+  if (!(v->ek_cluster && j->cl_ctr && !j->cluster_off && (j->in_device_loop || j->in_sharded_loop) && !j->fuse_stencil)) return 0;
+  const char *cl = std::getenv("LCMI_CLUSTER");
+  if (!cl) return 0;
+  const int per_wg = v->cl_thr / v->cl_lpf, full = (j->L / 2 + per_wg - 1) / per_wg;
+  const int want = (std::strcmp(cl, "auto") == 0) ? full : std::max(0, std::atoi(cl));
+  const int P = std::min({kMaxParts, want, j->ctx->n_cu / std::max(j->E, 1)});
+  return P >= 2 ? P : 0;
+}
+
 // (e0, e1, stream: the point-source-only kernel over the epochs [e0, e1) on `stream` - batched star photometry; default: all epochs)
 int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model_out, int e0 = 0, int e1 = -1,
                   hipStream_t ps_stream = nullptr) {
@@ -356,6 +401,20 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   // (C5 shard, 125 epochs: 425 us per iteration as one kernel, 295 us with two workgroups per epoch; 64 epochs 409 -> 198 us
   //  with four; 150 epochs and up: the single kernel, whose workgroups overlap each other's phases, is as fast or faster -
   //  200 epochs 451 against 469 us.  LCMI_EPOCH_PARTS_COL: the count for the column phases alone, a tuning switch.)
+  if (const int P = (mode == 0 && !A.skip_D) ? cluster_parts(j) : 0) {
+    A.cl_ctr = j->cl_ctr;
+    A.cl_abort = j->cl_ctr + (size_t)j->E * kClStride;
+    A.cl_base = j->cl_base;
+    A.cl_parts = P;
+    const int groups = (j->E + 7) / 8;
+    LC_HIP(j->ctx, hipFuncSetAttribute((const void *)v->ek_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, v->cl_lds));
+    hipLaunchKernelGGL(v->ek_cluster, dim3(8 * groups * P), dim3(v->cl_thr), v->cl_lds, j->ctx->stream, A);
+    LC_HIP(j->ctx, hipGetLastError());
+    j->cl_base += (unsigned int)kClBarriers;
+    j->cl_parts_last = P;
+    return A.need_hgrad;
+  }
+  j->cl_parts_last = 0;
   int parts = 1, parts_col = 1;
   if (v->ek_phase[0] && mode == 0 && j->part) {
     // as many workgroups per epoch as leave no CU idle, and no more than one sweep of a phase has work for: the row phases
@@ -471,10 +530,16 @@ int launch_reg_gm(lc_joint *j, hipStream_t stream, bool with_pts, bool abar_from
 template <int N>
 MregKernels make_mreg() {
   return MregKernels{N, mreg_forward_kernel<N>, mreg_adjoint_kernel<N>, MregCfg<N>::LDS_FWD, MregCfg<N>::LDS_ADJ, MregCfg<N>::NTHR,
-                     mreg_mm_kernel<N>};
+                     mreg_mm_kernel<N>, nullptr};
+}
+template <int N>
+MregKernels make_mreg_chain() {
+  MregKernels k = make_mreg<N>();
+  k.chain = mreg_chain_kernel<N>;
+  return k;
 }
 const MregKernels *find_mreg(int N) {
-  static const MregKernels table[] = {make_mreg<128>(), make_mreg<256>()};
+  static const MregKernels table[] = {make_mreg_chain<128>(), make_mreg<256>()};
   if (std::getenv("LCMI_REG_CASCADE")) return nullptr;  // the a-trous cascade kernels instead (cross-check)
   for (const auto &k : table)
     if (k.N == N) return &k;
@@ -533,9 +598,11 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
   A.l1p = j->mr_l1;
   if (const char *dly = std::getenv("LCMI_REG_DELAY_US"))  // test hook: a chain that finishes after the epoch kernel
     hipLaunchKernelGGL(mreg_delay_kernel, dim3(1), dim3(64), 0, stream, (long long)(std::atof(dly) * 100.0));  // wall_clock64: 100 MHz
-  if (with_pts)
-    hipLaunchKernelGGL(mreg_pbar_kernel, dim3(nb), dim3(kGmThreads), 0, stream, N, j->ss, j->E, j->M, j->par[LC_P_A],
-                       j->par[LC_P_CX], j->par[LC_P_CY], j->mr_pbar);
+  auto launch_pbar = [&]() {
+    if (with_pts)
+      hipLaunchKernelGGL(mreg_pbar_kernel, dim3(nb), dim3(kGmThreads), 0, stream, N, j->ss, j->E, j->M, j->par[LC_P_A],
+                         j->par[LC_P_CX], j->par[LC_P_CY], j->mr_pbar);
+  };
   if (!std::getenv("LCMI_REG_MFMA_V1")) {
     // second form (default): batched tiled products over the scales, telescoped adjoint
     const size_t NNs = (size_t)NN;
@@ -563,7 +630,48 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
       for (int s = 1; s <= J; ++s) add(s, j->par[LC_P_H], j->mr_C + (size_t)s * NNs, j->mr_S + (size_t)s * NNs, j->mr_Z + (size_t)s * NNs);
     if (with_pts) add(1, j->mr_pbar, j->mr_C + (size_t)(J + 1) * NNs, j->mr_S + (size_t)(J + 1) * NNs, j->mr_Z + (size_t)(J + 1) * NNs);
     f1.nb = f2.nb = a1.nb = a2.nb = nbch;
+    // The whole chain as ONE launch (mreg_chain_kernel; LCMI_REG_CHAIN=1) where its kChainBlocks workgroups are resident beside
+    // the epoch kernel's.  Same stages, same bits (tests/test_joint_cluster_gpu.py).  Built on the premise that the eight
+    // launches (5 - 7.5 us each for 1 - 2 us of work, ~60 us per iteration at N = 128) are launch overhead; measured, they
+    // are not: the one launch takes 59.4 us per iteration (profiles/r04_cluster_*) - every stage boundary is a hand-off
+    // between CUs (write-through stores, drain, flag, L1-bypassing loads from the memory side), 5 - 7 us whether a launch
+    // boundary or an in-kernel sync delivers it.  NOT the default; what shortens the chain is fewer stages, not cheaper ones.
+    const int epoch_wgs = j->E * std::max(1, cluster_parts(j));
+    const char *rc_env = std::getenv("LCMI_REG_CHAIN");
+    if (k->chain && j->chain_flags && j->reg_flag && !j->chain_off && epoch_wgs + kChainBlocks <= j->ctx->n_cu && rc_env && std::atoi(rc_env) != 0) {
+      MregChainArgs Q;
+      std::memset(&Q, 0, sizeof(Q));
+      Q.mm[0] = f1; Q.mm[1] = f2; Q.mm[2] = a1; Q.mm[3] = a2;
+      Q.xa[0] = 0; Q.xb[0] = 0;   // T = X AT_s (h or Pbar: Pbar is a product of this launch)
+      Q.xa[1] = 0; Q.xb[1] = 1;   // c_s = A_s T
+      Q.xa[2] = 1; Q.xb[2] = 0;   // T' = S_s A_s
+      Q.xa[3] = 0; Q.xb[3] = 1;   // Z_s = AT_s T'
+      if (with_pts) Q.xa[0] = 2;  // (the last product of the batch reads Pbar: see chain_mm_tile's caller)
+      Q.G.B = A;
+      Q.G.lam_pos = j->cfg.lam_positivity;
+      Q.G.has_l1 = l1_on ? 1 : 0;
+      Q.G.S = j->mr_S;
+      Q.G.l1b = j->mr_l1b;
+      Q.G.posb = j->mr_posb;
+      Q.sslots = (l1_on ? J + 1 : 1) + (with_pts ? 1 : 0);
+      Q.with_pts = with_pts ? 1 : 0;
+      Q.N = N; Q.ss = j->ss; Q.E = j->E; Q.M = j->M; Q.J = J; Q.has_l1 = l1_on ? 1 : 0;
+      Q.a = j->par[LC_P_A]; Q.cx = j->par[LC_P_CX]; Q.cy = j->par[LC_P_CY];
+      Q.pbar = j->mr_pbar;
+      Q.S = j->mr_S; Q.Z = j->mr_Z;
+      Q.greg = j->greg; Q.pts_part = j->mr_part;
+      Q.regs = j->regs;
+      j->reg_seq += 1;
+      Q.done_flag = j->reg_flag; Q.done_seq = j->reg_seq;
+      Q.flags = j->chain_flags; Q.base = j->chain_base;
+      j->chain_base = (j->chain_base + (unsigned int)kChainSyncs) & 0x0fffffffu;
+      hipLaunchKernelGGL(k->chain, dim3(kChainBlocks), dim3(kMmThreads), 0, stream, Q);
+      LC_HIP(j->ctx, hipGetLastError());
+      j->chain_used = true;
+      return LC_OK;
+    }
     const dim3 mgrid(N / 64, N / 64, nbch), mblock(kMmThreads);
+    launch_pbar();
     if (nbch > 0) {
       hipLaunchKernelGGL(k->mm, mgrid, mblock, 0, stream, f1);
       hipLaunchKernelGGL(k->mm, mgrid, mblock, 0, stream, f2);
@@ -590,6 +698,7 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
     LC_HIP(j->ctx, hipGetLastError());
     return LC_OK;
   }
+  launch_pbar();
   const int slots = (l1_on ? J : 0) + (with_pts ? 1 : 0);
   if (slots > 0) {
     hipLaunchKernelGGL(k->fwd, dim3(N / 32, slots), dim3(k->nthr), k->lds_fwd, stream, A);
@@ -862,8 +971,11 @@ static int joint_create_impl(lc_ctx *ctx, int E, int M, int n, int ss, const flo
   TRY(dmalloc(j, &j->out_loss, 4));
   TRY(dmalloc(j, &j->greg, NN));
   TRY(dmalloc(j, &j->regs, 4 + 3 * kMaxSources + 4));
-  if (v->gspec && !lean) TRY(dmalloc(j, &j->spec, (size_t)E * N * ((KH + 15) / 16 * 16)));  // rows padded to 128-byte lines (JointCfg::KS)
-  if (v->gspec && !lean) TRY(dmalloc(j, &j->part, (size_t)E * kMaxParts * (4 + 3 * kMaxSources)));
+  const bool cluster_ok = v->ek_cluster && !lean && E <= ctx->n_cu / 2;  // (at least two workgroups per epoch, all resident)
+  if ((v->gspec || cluster_ok) && !lean) TRY(dmalloc(j, &j->spec, (size_t)E * N * ((KH + 15) / 16 * 16)));  // rows padded to 128-byte lines (JointCfg::KS)
+  if ((v->gspec || cluster_ok) && !lean) TRY(dmalloc(j, &j->part, (size_t)E * kMaxParts * (4 + 3 * kMaxSources)));
+  if (cluster_ok) TRY(dmalloc(j, &j->cl_ctr, (size_t)(E + 1) * kClStride));
+  if (!lean) TRY(dmalloc(j, &j->chain_flags, kChainBlocks + 32));
   if (v->gspec && !lean) TRY(dmalloc(j, &j->tshift, (size_t)E * 2));
   if (lean) {
     std::vector<int> grp(E);
@@ -1299,6 +1411,7 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   return LC_OK;
 }
 
+static int chain_check(lc_joint *j);
 int lc_joint_step_grad(lc_joint *j, float *loss, float *const grads[LC_P_COUNT]) {
   if (!j) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
@@ -1317,7 +1430,42 @@ int lc_joint_step_grad(lc_joint *j, float *loss, float *const grads[LC_P_COUNT])
     for (int k = 0; k < LC_P_COUNT; ++k)
       if (grads[k] && k != LC_P_ALPHA && (rc = d2h(j, grads[k], j->gout[k], (size_t)j->psize[k] * sizeof(float)))) return rc;
   LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+  return chain_check(j);
+}
+
+// Cluster launches (joint_kernels.h, PHASE = 7): did a barrier wait of the launches since the last check run out?  Reads the
+// abort word (synchronises the stream); if it is set, clears it together with the arrival counters and takes the cluster
+// form out of use for this object.  *aborted = 1 then: the numbers those launches produced are not to be used.
+static int cluster_check(lc_joint *j, int *aborted) {
+  *aborted = 0;
+  if (!j->cl_ctr || j->cluster_off) return LC_OK;
+  unsigned int word = 0;
+  int rc = d2h(j, &word, j->cl_ctr + (size_t)j->E * kClStride, sizeof(word));
+  if (rc) return rc;
+  if (!word) return LC_OK;
+  LC_HIP(j->ctx, hipMemsetAsync(j->cl_ctr, 0, (size_t)(j->E + 1) * kClStride * sizeof(unsigned int), j->ctx->stream));
+  LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+  j->cl_base = 0;
+  j->cluster_off = true;
+  j->cl_fallbacks += 1;
+  *aborted = 1;
   return LC_OK;
+}
+
+// One-launch regulariser chains since the last check: did a sync of one give up (its workgroups were not resident together)?
+// Then its outputs were never completed: the numbers of the run are invalid; the object keeps the launch form from here on.
+static int chain_check(lc_joint *j) {
+  if (!j->chain_flags || !j->chain_used) return LC_OK;
+  j->chain_used = false;
+  unsigned int word = 0;
+  int rc = d2h(j, &word, j->chain_flags + kChainBlocks, sizeof(word));
+  if (rc || !word) return rc;
+  LC_HIP(j->ctx, hipStreamSynchronize(j->streamB));
+  LC_HIP(j->ctx, hipMemsetAsync(j->chain_flags, 0, (kChainBlocks + 32) * sizeof(unsigned int), j->ctx->stream));
+  LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+  j->chain_base = 0;
+  j->chain_off = true;
+  LC_FAIL(j->ctx, LC_ERR_DEVICE, "joint fit: the one-launch regulariser chain gave up (its workgroups were not resident together); this run's numbers are invalid - the object has switched to the launch form, run again (LCMI_REG_CHAIN=0 selects it from the start)");
 }
 
 int lc_joint_run_sharded(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg, lc_allreduce_fn allreduce, void *user) {
@@ -1325,13 +1473,25 @@ int lc_joint_run_sharded(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg, l
   LC_ENTER(j->ctx);
   if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_run_sharded: not available on a batched star-photometry object");
   int rc = ensure_hist(j, j->iters_done + n_iter + 2);
+  const bool may_cluster = j->cl_ctr && !j->cluster_off;
+  j->in_sharded_loop = true;
   for (int it = 0; it < n_iter && !rc; ++it) {
     if ((rc = lc_joint_step_local(j))) break;
     if (allreduce(user, j->shared, j->shared_count, (void *)j->ctx->stream)) {
       j->ctx->err = "lc_joint_run_sharded: the all-reduce callback failed";
-      return LC_ERR_DEVICE;
+      rc = LC_ERR_DEVICE;
+      break;
     }
     rc = lc_joint_step_update(j, cfg);
+  }
+  j->in_sharded_loop = false;
+  if (!rc) rc = chain_check(j);
+  if (!rc && may_cluster && j->cl_parts_last > 0) {
+    // a sharded run cannot be redone by one rank alone (the others have moved on through the same all-reduces): report it;
+    // the object runs the one-workgroup kernel from here on
+    int aborted = 0;
+    if ((rc = cluster_check(j, &aborted))) return rc;
+    if (aborted) LC_FAIL(j->ctx, LC_ERR_DEVICE, "lc_joint_run_sharded: the workgroups of an epoch were not resident together (cluster launch gave up); this run's numbers are invalid - the object has switched to the one-workgroup kernel, run again");
   }
   return rc;
 }
@@ -1625,8 +1785,36 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
   if (rc) return rc;
   bool done = false;
   if ((rc = run_adabelief_persistent(j, n_iter, cfg, &done)) || done) return rc;
+  // Cluster launches (few epochs per GPU) rely on all workgroups of an epoch being resident together; every wait in them is
+  // bounded, and a run in which one gave up is REDONE here with the one-workgroup kernel from a copy of the state taken now
+  // (parameters, both moments: the epoch kernels only read them) - self-healing, like the two-workgroup PSF kernel.
+  const bool may_cluster = j->cl_ctr && !j->cluster_off && j->v->ek_cluster;
+  const int it0 = j->iters_done, ph0 = j->phist_rows;
+  struct SnapGuard {
+    float *p = nullptr;
+    ~SnapGuard() { if (p) (void)hipFree(p); }
+  } snap;
+  auto snapshot = [&](bool restore) -> int {
+    size_t total = 0;
+    for (int k = 0; k < LC_P_COUNT; ++k) total += 3 * (size_t)std::max(j->psize[k], 1);
+    if (!restore) LC_HIP(j->ctx, hipMalloc((void **)&snap.p, total * sizeof(float)));
+    float *c = snap.p;
+    for (int k = 0; k < LC_P_COUNT; ++k)
+      for (float *blk : {j->par[k], j->pm[k], j->ps[k]}) {
+        const size_t cnt = (size_t)std::max(j->psize[k], 1);
+        LC_HIP(j->ctx, hipMemcpyAsync(restore ? blk : c, restore ? c : blk, cnt * sizeof(float), hipMemcpyDeviceToDevice, j->ctx->stream));
+        c += cnt;
+      }
+    return LC_OK;
+  };
+  if (may_cluster && (rc = snapshot(false))) return rc;
+  if (may_cluster && std::getenv("LCMI_CLUSTER_TEST_ABORT")) {  // test hook: the first cluster launch finds the abort word set
+    const unsigned int one = 1;
+    if ((rc = h2d(j, j->cl_ctr + (size_t)j->E * kClStride, &one, sizeof(one)))) return rc;
+  }
   j->in_device_loop = true;
   bool flags_used = false;
+ redo:
   // LCMI_TIMELINE=1 (diagnostic): HIP events around the parts of ONE iteration in the middle of the run - where the epoch
   // kernels, the regulariser chain on the second stream and the update start and end relative to each other
   hipEvent_t tl[5] = {};
@@ -1658,8 +1846,27 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
     std::fprintf(stderr, "\n");
     for (auto &e : tl) (void)hipEventDestroy(e);
   }
+  if (!rc && may_cluster && !j->cluster_off && j->cl_parts_last > 0) {
+    int aborted = 0;
+    if ((rc = cluster_check(j, &aborted))) return rc;
+    if (aborted) {  // (cluster_off is set now: the same iterations again, one workgroup per epoch)
+      if ((rc = snapshot(true))) return rc;
+      // (the next regulariser chain, on the second stream, starts behind this event: it must see the restored background)
+      LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
+      if (std::getenv("LCMI_CLUSTER_DEBUG") && j->reg_flag) {
+        unsigned int w[2] = {0, 0};
+        (void)d2h(j, w, j->reg_flag, sizeof(w));
+        std::fprintf(stderr, "cluster fall-back: regulariser flag %u (host %u), wait error %u, flags_used %d\n", w[0], j->reg_seq, w[1], (int)flags_used);
+      }
+      j->iters_done = it0;
+      j->phist_rows = ph0;
+      j->reg_pending = j->fuse_pending = j->fuse_full = j->pts_pending = false;
+      goto redo;
+    }
+  }
   j->in_device_loop = false;
   j->flag_sync = false;
+  if (!rc) rc = chain_check(j);
   if (!rc && flags_used) {  // an update that gave up waiting for its regulariser would have used stale numbers: report it
     unsigned int err = 0;
     if ((rc = d2h(j, &err, j->reg_flag + 1, sizeof(err)))) return rc;
@@ -1673,6 +1880,12 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
   return rc;
 }
 int lc_joint_iterations_done(lc_joint *j) { return j ? j->iters_done : LC_ERR_INVALID; }
+int lc_joint_cluster_info(lc_joint *j, int *parts_last, int *fallbacks) {
+  if (!j) return LC_ERR_INVALID;
+  if (parts_last) *parts_last = j->cl_parts_last;
+  if (fallbacks) *fallbacks = j->cl_fallbacks;
+  return LC_OK;
+}
 
 int lc_joint_param_history_end(lc_joint *j) {
   if (!j) return LC_ERR_INVALID;
@@ -1901,7 +2114,10 @@ int lc_joint_fisher_flux_sigma(lc_joint *j, float *sigma_a) {
 
 #ifdef LC_STAMPS
 int lc_debug_get_jstamps(long long *out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::g_jstamps), 16 * sizeof(long long)) == hipSuccess ? 0 : -2;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::g_jstamps), 32 * sizeof(long long)) == hipSuccess ? 0 : -2;
+}
+int lc_debug_get_ustamps(long long *out) {  // (the fused reduction + update launch: tools/update_stamps.py)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::g_ustamps), 16 * sizeof(long long)) == hipSuccess ? 0 : -2;
 }
 #endif
 

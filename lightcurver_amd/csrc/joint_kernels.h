@@ -17,13 +17,14 @@ namespace lc {
 constexpr int kMaxSources = 8;
 
 #ifdef LC_STAMPS
-__device__ long long g_jstamps[16];
+__device__ long long g_jstamps[32];
+__device__ long long g_ustamps[16];
 #define LC_JSTAMP(k)                                                \
   do {                                                              \
     if (blockIdx.x == 0 && threadIdx.x == 0) g_jstamps[k] = clock64(); \
   } while (0)
 // (the fused reduction + update launch: thread 0 of whichever block calls, 100 MHz wall clock - tools/update_stamps.py)
-#define LC_USTAMP(k) do { if (threadIdx.x == 0) g_jstamps[k] = wall_clock64(); } while (0)
+#define LC_USTAMP(k) do { if (threadIdx.x == 0) g_ustamps[k] = wall_clock64(); } while (0)
 #else
 #define LC_JSTAMP(k) do {} while (0)
 #define LC_USTAMP(k) do {} while (0)
@@ -55,7 +56,108 @@ struct JointArgs {
   // in the spectrum scratch and writes no slab
   int skip_D;
   float *tshift;              // [E][2] the shifts (dx, dy) this evaluation used: the reduction runs beside the update of dx, dy
+  // cluster launch (PHASE = 7): the cl_parts workgroups of an epoch run in ONE launch, their phases separated by arrival
+  // counters in global memory instead of launch boundaries (joint_epoch_kernel, cluster_sync)
+  unsigned int *cl_ctr;       // [E][kClStride] one flag word per workgroup of the epoch: (sequence number << 4) | XCC id
+  unsigned int cl_base;       // sequence number of the last sync before this launch (kept by the host: + kClBarriers per launch)
+  unsigned int *cl_abort;     // [1] a wait ran out (sticky until the host clears it): every later wait gives up at once
+  int cl_parts;
 };
+constexpr int kClStride = 32;    // flag words per epoch (one 128-byte line; kMaxParts <= 16 of them in use)
+constexpr int kClBarriers = 6;   // start | A | B | C | B' | C' | D: every cluster launch passes exactly six syncs
+
+// Data handed from one workgroup of an epoch to the others inside ONE launch (cluster form).  Two forms, chosen per launch
+// by what the workgroups find out about each other at their first sync (MI355X_MICROARCH.md, inter-workgroup visibility):
+//  * general: every store write-through and every load L1-bypassing (agent-scope relaxed atomics = global_store /
+//    global_load ... sc1), the storing waves drain vmcnt, workgroup barrier, one lane raises an sc1 flag - valid wherever
+//    the workgroups run, but an sc1 store drops its line from the XCD's L2 and every reader goes to the memory side;
+//  * all workgroups of the epoch on ONE XCD (each reads HW_REG_XCC_ID; a workgroup never moves): plain stores, which stay in
+//    the L2 they share, and the same L1-bypassing loads, now served from that L2; the flag likewise.  Speed only: a wrong
+//    guess is impossible (the ids are exchanged, not assumed) and either form is correct under any placement.
+// Relaxed atomics stay in flight like plain accesses (the compiler counts them in vmcnt; nothing waits here).
+template <bool CL>
+__device__ __forceinline__ float2 xwg_load(const float2 *p) {
+  if constexpr (CL) {
+    const unsigned long long v = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned int)v), __uint_as_float((unsigned int)(v >> 32)));
+  } else {
+    return *p;
+  }
+}
+template <bool CL>
+__device__ __forceinline__ void xwg_store(float2 *p, float2 v, bool same_xcd = false) {
+  if constexpr (CL) {
+    if (same_xcd) {
+      *p = v;
+    } else {
+      const unsigned long long u = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+      __hip_atomic_store((unsigned long long *)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    *p = v;
+  }
+}
+template <bool CL>
+__device__ __forceinline__ float xwg_loadf(const float *p) {
+  if constexpr (CL) return __uint_as_float(__hip_atomic_load((const unsigned int *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else return *p;
+}
+template <bool CL>
+__device__ __forceinline__ void xwg_storef(float *p, float v, bool same_xcd = false) {
+  if constexpr (CL) {
+    if (same_xcd) *p = v;
+    else __hip_atomic_store((unsigned int *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *p = v;
+  }
+}
+// Sync over the `nparts` workgroups of one epoch (every thread of the workgroup calls; st: two LDS words).  Every wave drains
+// its stores, the workgroup meets, one lane raises the workgroup's flag - (sequence number << 4) | XCC id; the sequence
+// number grows by one per sync over all launches, so nothing is ever reset - and lanes 0 .. nparts - 1 of the first wave
+// poll one flag each (L1-bypassing, relaxed) until all have reached the number.  Bounded by the wall clock (s_memrealtime,
+// 100 MHz: ~0.5 s): a workgroup whose partners are not resident - the one way this can fail - is reported through the abort
+// word instead of waited for, and once the word is set every later wait gives up at once (the launches enqueued behind
+// this one included: `first`).  Returns false when the wait was given up.  At the launch's first sync the lanes also
+// compare the partners' XCC ids with their own: st[1] = 1 when all of them run on this XCD.
+__device__ __forceinline__ bool cluster_sync(unsigned int *flags, int part, int nparts, unsigned int seq, unsigned int xcc,
+                                             bool same_xcd, unsigned int *abort_word, int tid, int *st, bool first) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid < 64) {
+    const unsigned int word = (seq << 4) | xcc;
+    if (tid == 0) {
+      if (same_xcd) asm volatile("global_store_dword %0, %1, off" ::"v"(flags + part), "v"(word) : "memory");
+      else __hip_atomic_store(flags + part, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int good = 1;
+    if (first && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) good = 0;
+    const unsigned int *mine = flags + (tid < nparts ? tid : 0);
+    unsigned int got = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (28-bit sequence numbers compared modulo 2^28: the shifted words wrap with the 32-bit arithmetic)
+    if (good && !__all((int)((got & ~15u) - (seq << 4)) >= 0)) {
+      const long long t0 = wall_clock64();
+      int spins = 0;
+      for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        got = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((int)((got & ~15u) - (seq << 4)) >= 0)) break;
+        if ((++spins & 63) == 0 &&
+            (wall_clock64() - t0 > 50000000ll || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+          good = 0;
+          break;
+        }
+      }
+    }
+    if (!good && tid == 0) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int same = __all((got & 15u) == xcc) ? 1 : 0;
+    if (tid == 0) {
+      st[0] = good;
+      if (first) st[1] = same;
+    }
+  }
+  __syncthreads();
+  return st[0] != 0;
+}
 
 __device__ __forceinline__ void sample_coords(int u, int v, float c0, float ca, float sa, float sdx, float sdy,
                                               float &Xs, float &Ys) {
@@ -139,12 +241,24 @@ struct JointCfg {
 
 // Phased launches: the totals of an epoch are the sums of its workgroups' partial sums (in workgroup order); the outputs are
 // those of the reductions at the end of the one-workgroup kernel.  Every thread of the workgroup calls (barrier inside); TOT: LDS.
+template <bool SC1 = false>
 __device__ __forceinline__ void joint_epoch_totals(const JointArgs &A, int e, int tid, int SS, int nparts, float *TOT) {
   constexpr int NQ = 4 + 3 * kMaxSources;
   const int M = A.M, nq = 4 + 3 * M;
   if (tid < nq) {
     float acc = 0.f;
-    for (int p = 0; p < nparts; ++p) acc += A.part[((size_t)e * nparts + p) * NQ + tid];
+    if constexpr (SC1) {
+      // (L1-bypassing loads are not speculated by the compiler: all of them requested at once from clamped addresses, then
+      //  added in workgroup order - one round trip instead of one per workgroup)
+      constexpr int MAXP = 16;
+      float v[MAXP];
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p) v[p] = xwg_loadf<true>(&A.part[((size_t)e * nparts + min(p, nparts - 1)) * NQ + tid]);
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p) acc += (p < nparts) ? v[p] : 0.f;
+    } else {
+      for (int p = 0; p < nparts; ++p) acc += A.part[((size_t)e * nparts + p) * NQ + tid];
+    }
     TOT[tid] = acc;
   }
   __syncthreads();
@@ -179,18 +293,58 @@ template <class C, bool AUX = false, int PHASE = 0>
 //  split of the C5 shard: 367 - 405 us per iteration against 338.)
 __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   static_assert(PHASE == 0 || (C::GSPEC && !AUX), "one phase per launch: spectrum in global memory");
+  // PHASE = 7, the CLUSTER form: all six phases in ONE launch by `cl_parts` workgroups per epoch that share the phases' rows /
+  // columns / pixels exactly as the phased launches do, with an arrival counter per epoch where those have a launch boundary
+  // (cluster_sync) and the spectrum handed over through write-through stores and L1-bypassing loads (xwg_*).  Built for
+  // fits that leave most CUs idle with one workgroup per epoch (a sharded C4: 25 epochs per GPU): every phase becomes ONE
+  // sweep of one wave per SIMD.  Grid: 1-D, 8 * ceil(E / 8) * cl_parts blocks; block b serves epoch 8 (b / 8 / parts) + b % 8,
+  // part (b / 8) % parts, so that the workgroups of an epoch have equal b % 8 - one XCD under the observed round-robin
+  // placement (speed only: correctness does not depend on where a block lands).  All workgroups of an epoch must be
+  // resident together: the host launches this form only when the whole grid fits on the device, every wait is bounded.
+  constexpr bool CL = (PHASE == 7);
+  constexpr bool ALLPH = (PHASE == 0 || PHASE == 7);
+  static_assert(!CL || !C::TILECOLS, "cluster form: element-wise column access");
   // workgroup of the epoch, workgroups per epoch.  (0, 1 in the one-kernel form: compile-time constants for the LDS-spectrum
   // kernels; the global-spectrum build reads them from the grid there too - with run-time sweep strides the compiler keeps
   // fewer values in flight and its 256 registers hold everything, with constants it spilled 64 - 110 of them.)
   constexpr bool ONE = (PHASE == 0) && !C::GSPEC;
-  const int part = ONE ? 0 : (int)blockIdx.y, nparts = ONE ? 1 : (int)gridDim.y;
+  const int part = CL ? (int)((blockIdx.x >> 3) % (unsigned)A.cl_parts) : (ONE ? 0 : (int)blockIdx.y);
+  const int nparts = CL ? A.cl_parts : (ONE ? 1 : (int)gridDim.y);
+  const int e = CL ? (int)(8 * ((blockIdx.x >> 3) / (unsigned)A.cl_parts) + (blockIdx.x & 7)) : (int)blockIdx.x;
+  if constexpr (CL) {
+    if (e >= A.E) return;  // (the grid is rounded up to whole groups of eight epochs: no such block takes part in anything)
+  }
   constexpr int N = C::N, SS = C::SS, L = C::L, n = C::n, KH = C::KH, KS = C::KS, CREF = C::CREF;
   extern __shared__ __align__(16) float2 lds2[];
-  float2 *SPEC = C::GSPEC ? (A.spec + (size_t)blockIdx.x * N * KS) : (lds2 + C::OFF_SPEC);
+  float2 *SPEC = C::GSPEC ? (A.spec + (size_t)e * N * KS) : (lds2 + C::OFF_SPEC);
   constexpr bool LITE = (PHASE == 2 || PHASE == 4 || PHASE == 6);  // (JointCfg::LDS_LITE)
   float2 *TW = lds2 + (LITE ? 0 : C::OFF_TW);
   float *RED = (float *)(lds2 + (LITE ? C::LITE_RED : C::OFF_RED));
-  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // spectrum scratch accessors: plain, except where the workgroups of an epoch meet inside one launch
+  bool same_xcd = false;  // cluster form: all workgroups of this epoch share an XCD (found out at the first sync)
+  auto SLD = [&](int idx) { return xwg_load<CL>(SPEC + idx); };
+  auto SST = [&](int idx, float2 v) { xwg_store<CL>(SPEC + idx, v, same_xcd); };
+  int *CLST = (int *)(RED + (C::NW + 1) * (4 + 3 * kMaxSources));  // (two words inside SZ_RED's padding)
+  unsigned int my_xcc = 0;
+  if constexpr (CL) my_xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 15u;
+  // end of a phase: workgroup barrier, or the sync over the epoch's workgroups (false: a wait was given up - leave);
+  // k = 0: the launch's first sync, at the end of the prologue (nothing handed over yet: it exchanges the XCC ids)
+  auto phase_end = [&](int k) -> bool {
+    if constexpr (CL) {
+      LC_JSTAMP(16 + k);
+      const bool ok = cluster_sync(A.cl_ctr + (size_t)e * kClStride, part, nparts, (A.cl_base + (unsigned int)(k + 1)) & 0x0fffffffu,
+                                   my_xcc, same_xcd, A.cl_abort, tid, CLST, k == 0);
+      if (k == 0) same_xcd = CLST[1] != 0;
+#ifdef LC_STAMPS
+      if (k == 0 && blockIdx.x == 0 && threadIdx.x == 0) g_jstamps[30] = same_xcd ? 1 : 0;
+#endif
+      return ok;
+    } else {
+      __syncthreads();
+      return true;
+    }
+  };
   const int pw = part * C::NW + wid, PWS = nparts * C::NW;  // this wave among the epoch's waves, their number
   const int M = A.M;
   const float c0 = (N - 1) * 0.5f;
@@ -243,7 +397,11 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     constexpr int NQ0 = 4 + 3 * kMaxSources;
     if (lane < NQ0) RED[wid * NQ0 + lane] = 0.f;
   }
-  __syncthreads();
+  if constexpr (CL) {
+    if (!phase_end(0)) return;
+  } else {
+    __syncthreads();
+  }
   const bool use_h = A.h_active && A.mode != 2;
 
   LC_JSTAMP(1);
@@ -365,8 +523,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       const int k = kbase + k2;
       if (active && k <= L / 2) {
         const int sk = slot_own(k2);
-        SPEC[u0 * KS + sk] = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-        SPEC[(u0 + 1) * KS + sk] = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+        SST(u0 * KS + sk, make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y)));
+        SST((u0 + 1) * KS + sk, make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x)));
       }
     }
   };
@@ -382,8 +540,12 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       const int sidx = lo ? slot_own(k2) : slot_neg(k2);
       const float sgn = lo ? -1.f : 1.f;
       float2 z = make_float2(0.f, 0.f);
-      if (active) {
-        const float2 x1 = SPEC[u0 * KS + sidx], x2 = SPEC[(u0 + 1) * KS + sidx];
+      if constexpr (CL) {  // (the cluster form's L1-bypassing loads are not speculated: unconditional, from a valid row, then selected)
+        const int uc = active ? u0 : 0;
+        const float2 x1 = SLD(uc * KS + sidx), x2 = SLD((uc + 1) * KS + sidx);
+        z = make_float2(active ? fmaf(sgn, x2.y, x1.x) : 0.f, active ? fmaf(-sgn, x1.y, x2.x) : 0.f);
+      } else if (active) {
+        const float2 x1 = SLD(u0 * KS + sidx), x2 = SLD((u0 + 1) * KS + sidx);
         z = make_float2(fmaf(sgn, x2.y, x1.x), fmaf(-sgn, x1.y, x2.x));
       }
       x[k2] = z;
@@ -401,13 +563,36 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   constexpr int RMASK_ADJ = C::FOLD ? ~1 : ~0;
   auto load_column = [&](float2 (&x)[N2], int kc, bool active, int row_off) {
     const int rmask = (row_off != 0) ? RMASK_ADJ : ~0;
+    if constexpr (CL) {
+      // cluster form: the loads bypass L1 and are not speculated by the compiler - with a test around each, every element was a
+      // branch (and the packed DC / Nyquist column a dependent round trip per element): all loads of the column unconditional,
+      // from a clamped row, the Nyquist column for the whole wave that holds the DC column (wave-uniform test)
+      const bool dcwave = (kc - qid) == 0;
+#pragma unroll
+      for (int n2 = 0; n2 < N2; ++n2) {
+        const int r = l16 + LPF * n2 - row_off;
+        const bool ok = active && r >= 0 && r < N;
+        const float2 v = SLD((ok ? (r & rmask) : 0) * KS + kc);
+        x[n2] = make_float2(ok ? v.x : 0.f, ok ? v.y : 0.f);
+      }
+      if (dcwave) {
+#pragma unroll
+        for (int n2 = 0; n2 < N2; ++n2) {
+          const int r = l16 + LPF * n2 - row_off;
+          const bool ok = active && r >= 0 && r < N;
+          const float2 w = SLD((ok ? (r & rmask) : 0) * KS + L / 2);
+          if (ok && kc == 0) x[n2].y = w.x;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int n2 = 0; n2 < N2; ++n2) {
       const int r = l16 + LPF * n2 - row_off;
       float2 v = make_float2(0.f, 0.f);
       if (active && r >= 0 && r < N) {
-        v = SPEC[(r & rmask) * KS + kc];
-        if (kc == 0) v.y = SPEC[(r & rmask) * KS + L / 2].x;
+        v = SLD((r & rmask) * KS + kc);
+        if (kc == 0) v.y = SLD((r & rmask) * KS + L / 2).x;
       }
       x[n2] = v;
     }
@@ -418,10 +603,10 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       const int r = l16 + LPF * n2 - row_off;
       if (active && r >= 0 && r < N) {
         if (kc == 0) {
-          SPEC[r * KS] = make_float2(x[n2].x, 0.f);
-          SPEC[r * KS + L / 2] = make_float2(x[n2].y, 0.f);
+          SST(r * KS, make_float2(x[n2].x, 0.f));
+          SST(r * KS + L / 2, make_float2(x[n2].y, 0.f));
         } else {
-          SPEC[r * KS + kc] = x[n2];
+          SST(r * KS + kc, x[n2]);
         }
       }
     }
@@ -637,7 +822,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   // KH float2 of spectrum row u), so the T^T gather below reads LDS, not global memory
   float *GSl = (float *)SPEC;
   constexpr int GST = 2 * KS;
-  if constexpr (PHASE == 0 || PHASE == 1) {
+  if constexpr (ALLPH || PHASE == 1) {
   if constexpr (!AUX && C::ROWPIPE) {
     if (use_h && translated) fetch_rows(2 * (pw * GPW + qid), pw * GPW + qid < N / 2, hpre);
   }
@@ -723,7 +908,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     unpack_rows(x, u0, active);
   }
   }  // phase A
-  __syncthreads();
+  if (!phase_end(1)) return;
   LC_JSTAMP(2);
   if constexpr (AUX) {
     if (A.mode == 4) {  // forward column transforms only: the spectrum of scene_in[e], transposed, divided by L^2
@@ -754,9 +939,9 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   }
   __builtin_amdgcn_s_setprio(0);
   // ---- phase B: columns: FFT, multiply by the PSF spectrum, inverse FFT, keep the 'same' window ----
-  if constexpr (PIPED && (PHASE == 0 || PHASE == 2)) {
+  if constexpr (PIPED && (ALLPH || PHASE == 2)) {
     column_sweeps(Ste, false, 0, CREF);
-  } else if constexpr (PHASE == 0 || PHASE == 2) {
+  } else if constexpr (ALLPH || PHASE == 2) {
   for (int kt = part * C::NW * GPW, sw = 0; kt < NCOL; kt += PWS * GPW, ++sw) {  // one sweep: NW * GPW consecutive columns
     const int kc0 = kt + wid * GPW;
     if (kc0 >= NCOL) break;
@@ -790,7 +975,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   }
   }  // phase B
   __builtin_amdgcn_s_setprio(0);
-  __syncthreads();
+  if (!phase_end(2)) return;
   LC_JSTAMP(3);
   if constexpr (AUX) {  // mode 3: inverse rows, 'same' window of the convolution at full resolution
     float *co = A.conv_out + (size_t)e * N * N;
@@ -812,7 +997,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     return;
   }
   // ---- phase C: inverse rows -> model, residuals; forward rows of the up-sampled weighted residual ----
-  if constexpr (PHASE == 0 || PHASE == 3) {
+  if constexpr (ALLPH || PHASE == 3) {
   if constexpr (C::FOLD) {
     // Binned rows.  Data row I is the sum of scene rows 2 I, 2 I + 1 (add their half spectra), shifted by CREF, added to
     // its right neighbour and decimated by two along x: in Fourier space a multiplication by phi and the fold
@@ -824,8 +1009,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     const int kbh = N2H * bitrev_n<LPF>(l16);
     auto folded = [&](int r0, int m) {  // D[m], 0 <= m <= KQ, of the data row made of scene rows r0, r0 + 1
       const int sa_ = slot_of(m), sb_ = slot_of(LH - m);
-      const float2 a0 = SPEC[r0 * KS + sa_], a1 = SPEC[(r0 + 1) * KS + sa_];
-      const float2 b0 = SPEC[r0 * KS + sb_], b1 = SPEC[(r0 + 1) * KS + sb_];
+      const float2 a0 = SLD(r0 * KS + sa_), a1 = SLD((r0 + 1) * KS + sa_);
+      const float2 b0 = SLD(r0 * KS + sb_), b1 = SLD((r0 + 1) * KS + sb_);
       const float2 ga = cmul(make_float2(a0.x + a1.x, a0.y + a1.y), PHI[m]);
       const float2 gb = cmul(make_float2(b0.x + b1.x, b0.y + b1.y), PHI[LH - m]);
       return make_float2(ga.x + gb.x, ga.y - gb.y);
@@ -839,13 +1024,15 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
       for (int k2 = 0; k2 < N2H; ++k2) {
         const int k = kbh + k2, m = (k <= KQ) ? k : LH - k;
         float2 z = make_float2(0.f, 0.f);
-        if (active) {
-          float2 d0 = folded(2 * I0, m), d1 = folded(2 * I1, m);
+        if (CL || active) {  // (cluster form: unconditional L1-bypassing loads from valid rows, the result selected)
+          const int J0 = (CL && !active) ? 0 : I0, J1 = (CL && !active) ? 1 : I1;
+          float2 d0 = folded(2 * J0, m), d1 = folded(2 * J1, m);
           if (k > KQ) {  // Hermitian extension
             d0.y = -d0.y;
             d1.y = -d1.y;
           }
           z = make_float2(d0.x - d1.y, d0.y + d1.x);  // row I0 + i row I1
+          if (CL && !active) z = make_float2(0.f, 0.f);
         }
         x[k2] = z;
       }
@@ -904,11 +1091,11 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
             const float2 u0b = cmul_conj(make_float2(R0.x, -R0.y), pb), u1b = cmul_conj(make_float2(R1.x, -R1.y), pb);
             const int ska = slot_of(k), skb = slot_of(LH - k);
             // (rows 2 I + 1 would hold the same values: the adjoint column loads read row r & ~1 instead)
-            SPEC[(2 * I0) * KS + ska] = u0a;
-            SPEC[(2 * I1) * KS + ska] = u1a;
+            SST((2 * I0) * KS + ska, u0a);
+            SST((2 * I1) * KS + ska, u1a);
             if (k != KQ) {
-              SPEC[(2 * I0) * KS + skb] = u0b;
-              SPEC[(2 * I1) * KS + skb] = u1b;
+              SST((2 * I0) * KS + skb, u0b);
+              SST((2 * I1) * KS + skb, u1b);
             }
           }
         }
@@ -1011,7 +1198,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   }
   }
   }  // phase C
-  if constexpr (PHASE == 3) {  // this workgroup's share of chi2 and of the sky-level gradient
+  if constexpr (PHASE == 3 || CL) {  // this workgroup's share of chi2 and of the sky-level gradient
     constexpr int NQP = 4 + 3 * kMaxSources;
     const float s0 = wave_sum(acc_chi), s1 = wave_sum(acc_mean);
     if (lane == 0) {
@@ -1022,7 +1209,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     if (tid < 2) {
       float acc = 0.f;
       for (int w = 0; w < C::NW; ++w) acc += RED[w * NQP + tid];
-      A.part[((size_t)e * nparts + part) * NQP + tid] = acc;
+      xwg_storef<CL>(&A.part[((size_t)e * nparts + part) * NQP + tid], acc, same_xcd);
     }
   }
   if (PHASE == 0 && A.mode != 0) {
@@ -1037,13 +1224,13 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     }
     return;
   }
-  __syncthreads();
+  if (!phase_end(3)) return;
   LC_JSTAMP(4);
   __builtin_amdgcn_s_setprio(0);
   // ---- phase B': adjoint columns (rows sit at offset CREF), multiply by conj(spectrum) ------------
-  if constexpr (PIPED && (PHASE == 0 || PHASE == 4)) {
+  if constexpr (PIPED && (ALLPH || PHASE == 4)) {
     column_sweeps(Ste, true, CREF, 0);
-  } else if constexpr (PHASE == 0 || PHASE == 4) {
+  } else if constexpr (ALLPH || PHASE == 4) {
   for (int kt = part * C::NW * GPW, sw = 0; kt < NCOL; kt += PWS * GPW, ++sw) {
     const int kc0 = kt + wid * GPW;
     if (kc0 >= NCOL) break;
@@ -1071,10 +1258,10 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   }
   }  // phase B'
   __builtin_amdgcn_s_setprio(0);
-  __syncthreads();
+  if (!phase_end(4)) return;
   LC_JSTAMP(5);
   // ---- phase C': adjoint inverse rows -> scene gradient rows; parameter gradients ------------------
-  if constexpr (PHASE == 0 || PHASE == 5) {
+  if constexpr (ALLPH || PHASE == 5) {
   for (int rp0 = pw * GPW, sw = 0; rp0 < N / 2; rp0 += PWS * GPW, ++sw) {
     progress_prio_end(sw, (N / 2 + PWS * GPW - 1) / (PWS * GPW));
     const int rp = rp0 + qid, u0 = 2 * rp;
@@ -1142,8 +1329,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
 #pragma unroll
           for (int n2 = 0; n2 < N / LPF; ++n2) {
             const int v = l16 + LPF * n2;
-            GSl[u0 * GST + v] = x[n2].x;
-            GSl[(u0 + 1) * GST + v] = x[n2].y;
+            xwg_storef<CL>(&GSl[u0 * GST + v], x[n2].x, same_xcd);
+            xwg_storef<CL>(&GSl[(u0 + 1) * GST + v], x[n2].y, same_xcd);
           }
         }
       }
@@ -1173,8 +1360,8 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         }
         if (use_h) {
           if (A.need_hgrad) {
-            GSl[u0 * GST + v] = g.x;
-            GSl[(u0 + 1) * GST + v] = g.y;
+            xwg_storef<CL>(&GSl[u0 * GST + v], g.x, same_xcd);
+            xwg_storef<CL>(&GSl[(u0 + 1) * GST + v], g.y, same_xcd);
           }
         }
       }
@@ -1186,7 +1373,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   LC_JSTAMP(6);
   acc_dx = fmaf(-(float)SS, acc_hx, acc_dx);
   acc_dy = fmaf(-(float)SS, acc_hy, acc_dy);
-  if constexpr (PHASE == 5) {  // this workgroup's share of the shift gradients and of the sums of the point sources
+  if constexpr (PHASE == 5 || CL) {  // this workgroup's share of the shift gradients and of the sums of the point sources
     constexpr int NQP = 4 + 3 * kMaxSources;
     const int nqp = 4 + 3 * M;
     const float s2 = wave_sum(acc_dx), s3 = wave_sum(acc_dy);
@@ -1198,8 +1385,14 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
     if (tid >= 2 && tid < nqp) {
       float acc = 0.f;
       for (int w = 0; w < C::NW; ++w) acc += RED[w * NQP + tid];
-      A.part[((size_t)e * nparts + part) * NQP + tid] = acc;
+      xwg_storef<CL>(&A.part[((size_t)e * nparts + part) * NQP + tid], acc, same_xcd);
     }
+  }
+  if constexpr (CL) {
+    // every workgroup's share of every sum is out, the scene gradient of the epoch complete: the first workgroup adds the
+    // shares in workgroup order (the phased launches' order: same bits), all of them take their pixels of phase D
+    if (!phase_end(5)) return;
+    if (part == 0) joint_epoch_totals<true>(A, e, tid, SS, nparts, RED);
   }
   // reductions: lanes by shuffles, the four waves in fixed order
   if constexpr (PHASE == 0) {
@@ -1242,7 +1435,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   }
   LC_JSTAMP(7);
   // ---- phase D: T_e^T of the scene gradient by an exact, ordered gather -----------------------------
-  if ((PHASE == 0 || PHASE == 6) && use_h && A.need_hgrad && !A.skip_D) {
+  if ((ALLPH || PHASE == 6) && use_h && A.need_hgrad && !A.skip_D) {
     if constexpr (PHASE == 6) {  // (launched with the workgroup count of the row phases, whose partial sums these are)
       if (part == 0) joint_epoch_totals(A, e, tid, SS, nparts, RED);
     }
@@ -1272,8 +1465,16 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
         for (int t = 0; t < 5; ++t) {
           const int qq = q0 - 1 + t;
           const bool qin = (qq >= 0 && qq < N);
-          ga[t] = (ra && qin) ? GSl[r0 * GST + qq] : 0.f;
-          gb[t] = (rb && qin) ? GSl[(r0 - 1) * GST + qq] : 0.f;
+          if constexpr (CL) {  // (unconditional loads from clamped positions, selected afterwards: see load_column)
+            const int qc = min(max(qq, 0), N - 1);
+            const float va = xwg_loadf<true>(&GSl[min(max(r0, 0), N - 1) * GST + qc]);
+            const float vb = xwg_loadf<true>(&GSl[min(max(r0 - 1, 0), N - 1) * GST + qc]);
+            ga[t] = (ra && qin) ? va : 0.f;
+            gb[t] = (rb && qin) ? vb : 0.f;
+          } else {
+            ga[t] = (ra && qin) ? GSl[r0 * GST + qq] : 0.f;
+            gb[t] = (rb && qin) ? GSl[(r0 - 1) * GST + qq] : 0.f;
+          }
         }
         float o[4];
 #pragma unroll
@@ -1340,7 +1541,7 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
           const int ya = min(max(y0, 0), N - 1), yb = min(max(y0 + 1, 0), N - 1);
           const float wx = ((xa == kx) ? (1.f - fx) : 0.f) + ((xb == kx) ? fx : 0.f);
           const float wy = ((ya == ky) ? (1.f - fy) : 0.f) + ((yb == ky) ? fy : 0.f);
-          acc = fmaf(wx * wy, GSl[u * GST + v], acc);
+          acc = fmaf(wx * wy, xwg_loadf<CL>(&GSl[u * GST + v]), acc);
         }
       }
       HGe[ky * N + kx] = acc;

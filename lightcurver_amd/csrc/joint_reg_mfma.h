@@ -534,6 +534,299 @@ __global__ void mreg_regs2_kernel(int J, int has_l1, int has_pts, int nblocks, i
   }
 }
 
+// ---- the second form of the chain as ONE launch --------------------------------------------------------------------------
+// The eight launches above take 5 - 7.5 us each for 1 - 2 us of work (a kernel boundary, the write-back of the XCD's L2 at
+// the end of every kernel, a cold start): ~60 us per iteration at N = 128, hidden behind a 53 us epoch kernel but the critical
+// path once the epoch kernel runs as a cluster launch (42 us; profiles/r04_*).  mreg_chain_kernel runs the same stages -
+// same arithmetic, same summation orders: bit-identical results - in one launch of kChainBlocks resident workgroups, the
+// stages separated by cluster_sync (joint_kernels.h) over all of them; what one workgroup hands to another goes through
+// write-through stores and L1-bypassing loads (xwg_*).  The element-wise stages walk the blocks of the launch form as
+// virtual blocks (same per-block partial sums).  Only where all its workgroups fit beside the epoch kernel's (the host
+// checks); every wait is bounded, and a chain that gave up never raises the completion flag, which the update's own bounded
+// wait reports.
+constexpr int kChainBlocks = 64;
+struct MregChainArgs {
+  MmBatch mm[4];               // f1, f2, a1, a2
+  int xa[4], xb[4];            // operand A / B of product q is an intermediate of this launch (L1-bypassing loads); xa = 2: only in
+                               // the last product of the batch (the point-source channel Pbar of stage 0)
+  MregSArgs G;                 // S planes
+  int sslots;
+  int with_pts, N, ss, E, M, J, has_l1;
+  const float *a, *cx, *cy;
+  float *pbar;
+  const float *S, *Z;
+  float *greg, *pts_part;
+  float *regs;
+  unsigned int *done_flag;
+  unsigned int done_seq;
+  unsigned int *flags;         // [kChainBlocks] sync words, then the abort word
+  unsigned int base;           // sequence number of the last sync before this launch
+};
+constexpr int kChainSyncs = 7;
+
+template <int N>
+__device__ __forceinline__ void chain_mm_tile(const MmBatch &G, int bz, int ty, int tx, bool xa, bool xb, float (*As)[64][kMmKT + 1],
+                                              float (*Bs)[kMmKT][64 + 4]) {
+  const int r0 = ty * 64, c0 = tx * 64;
+  const float *A = G.A[bz], *B = G.B[bz];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, h = lane >> 5;
+  const int wr = (wid >> 1) * 32, wc = (wid & 1) * 32;
+  float4 pa[2], pb[2];
+  auto ld4 = [&](const float *p, bool x) -> float4 {
+    if (x) {
+      const float2 lo = xwg_load<true>((const float2 *)p), hi = xwg_load<true>((const float2 *)p + 1);
+      return make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+    return *(const float4 *)p;
+  };
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + q * kMmThreads;
+      const int ar = e >> 3, ak = (e & 7) * 4;
+      pa[q] = ld4(A + (size_t)(r0 + ar) * N + k0 + ak, xa);
+      const int bk = e >> 4, bc = (e & 15) * 4;
+      pb[q] = ld4(B + (size_t)(k0 + bk) * N + c0 + bc, xb);
+    }
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + q * kMmThreads;
+      const int ar = e >> 3, ak = (e & 7) * 4;
+      As[buf][ar][ak] = pa[q].x; As[buf][ar][ak + 1] = pa[q].y; As[buf][ar][ak + 2] = pa[q].z; As[buf][ar][ak + 3] = pa[q].w;
+      const int bk = e >> 4, bc = (e & 15) * 4;
+      *(float4 *)&Bs[buf][bk][bc] = pb[q];
+    }
+  };
+  mr_acc acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  int kbeg = 0, kend = N;
+  if (G.band[bz]) {
+    const int lo = (G.band[bz] == 1) ? c0 : r0;
+    kbeg = max(lo - G.hw[bz], 0) / kMmKT * kMmKT;
+    kend = min((lo + 64 + G.hw[bz] + kMmKT - 1) / kMmKT * kMmKT, N);
+  }
+  fetch(kbeg);
+  put(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += kMmKT, buf ^= 1) {
+    if (k0 + kMmKT < kend) fetch(k0 + kMmKT);
+#pragma unroll
+    for (int s2 = 0; s2 < kMmKT / 2; ++s2) {
+      const int k = 2 * s2 + h;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][wr + i][k], Bs[buf][k][wc + i], acc, 0, 0, 0);
+    }
+    if (k0 + kMmKT < kend) put(buf ^ 1);
+    __syncthreads();
+  }
+  float *C = G.C[bz];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) xwg_storef<true>(&C[(size_t)(r0 + wr + mr_row(r, h)) * N + c0 + wc + i], acc[r]);
+}
+
+template <int N>
+__global__ __launch_bounds__(kMmThreads) void mreg_chain_kernel(MregChainArgs Q) {
+  static_assert(kMmThreads == kGmThreads, "one block shape for the products and the element-wise stages");
+  __shared__ float As[2][64][kMmKT + 1];
+  __shared__ float Bs[2][kMmKT][64 + 4];
+  __shared__ float red[kGmThreads / 64][kMaxSources * 3 + 2];
+  __shared__ float abar[kMaxSources];
+  __shared__ int st[2];
+  constexpr int NN = N * N, NVB = NN / kGmThreads, TPB = (N / 64) * (N / 64);
+  const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  unsigned int seq = Q.base;
+  auto sync = [&](bool first) -> bool {
+    seq = (seq + 1u) & 0x0fffffffu;
+    return cluster_sync(Q.flags, blk, kChainBlocks, seq, 0u, false, Q.flags + kChainBlocks, tid, st, first);
+  };
+  auto LDF = [&](const float *p) { return xwg_loadf<true>(p); };
+  const MregArgs &A = Q.G.B;
+  const int J = Q.J;
+  // ---- stage 0: Pbar ---------------------------------------------------------------------------------------------
+  if (Q.with_pts) {
+    for (int i = wid; i < Q.M; i += kGmThreads / 64) {
+      float acc = 0.f;
+      for (int e = lane; e < Q.E; e += 64) acc += Q.a[e * Q.M + i];
+      acc = wave_sum_shfl(acc);
+      if (lane == 0) abar[i] = acc / (float)Q.E;
+    }
+    __syncthreads();
+    const float c0 = (N - 1) * 0.5f, inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm2 = 0.15915494309189535f * inv_s2;
+    for (int vb = blk; vb < NVB; vb += kChainBlocks) {
+      const int k = vb * kGmThreads + tid, u = k / N, v = k % N;
+      float acc = 0.f;
+      for (int i = 0; i < Q.M; ++i) {
+        const float tx = (float)v - (c0 + Q.ss * Q.cx[i]), ty = (float)u - (c0 + Q.ss * Q.cy[i]);
+        acc = fmaf(abar[i] * nrm2, expf(-0.5f * (tx * tx + ty * ty) * inv_s2), acc);
+      }
+      xwg_storef<true>(&Q.pbar[k], acc);
+    }
+  }
+  if (!sync(true)) return;
+  // ---- stages 1, 2: forward products -----------------------------------------------------------------------------------
+  for (int q = 0; q < 2; ++q) {
+    for (int t = blk; t < TPB * Q.mm[q].nb; t += kChainBlocks) {
+      const int bz = t / TPB;
+      const bool xa = Q.xa[q] == 1 || (Q.xa[q] == 2 && bz == Q.mm[q].nb - 1);
+      chain_mm_tile<N>(Q.mm[q], bz, (t % TPB) / (N / 64), (t % TPB) % (N / 64), xa, Q.xb[q] != 0, As, Bs);
+    }
+    if (!sync(false)) return;
+  }
+  // ---- stage 3: S planes and values (mreg_splanes_kernel's blocks as virtual blocks) -------------------------------------------
+  {
+    const int nh = Q.G.has_l1 ? J + 1 : 1;
+    auto sgn = [](float d, float lw) { return (d > 0.f) ? lw : ((d < 0.f) ? -lw : 0.f); };
+    for (int vbs = blk; vbs < NVB * Q.sslots; vbs += kChainBlocks) {
+      const int vb = vbs % NVB, slot = vbs / NVB, k = vb * kGmThreads + tid;
+      const bool pts = slot >= nh;
+      const int j = pts ? 0 : slot;
+      auto lw_of = [&](int s, float lam) { return A.W ? lam * A.W[(size_t)s * NN + k] : lam * A.norms[s]; };
+      // (plane 0 is h itself, written before this launch; the others are products of this launch)
+      auto plane_at = [&](int s) { return s == 0 ? A.X[k] : LDF(A.C + (size_t)s * NN + k); };
+      float l1 = 0.f, pos = 0.f;
+      if (pts) {
+        const float d = LDF(A.P + k) - LDF(A.C + (size_t)(J + 1) * NN + k), lw = lw_of(0, A.lam_pts);
+        xwg_storef<true>(&Q.G.S[(size_t)(J + 1) * NN + k], sgn(d, lw));
+        l1 = lw * fabsf(d);
+      } else if (j == 0) {
+        const float hv = A.X[k];
+        float z = 0.f;
+        if (Q.G.has_l1) {
+          const float d = hv - LDF(A.C + (size_t)NN + k), lw = lw_of(0, A.lam_hf);
+          z = sgn(d, lw);
+          l1 = lw * fabsf(d);
+        }
+        if (Q.G.lam_pos != 0.f && hv < 0.f) {
+          pos = -Q.G.lam_pos * hv;
+          z -= Q.G.lam_pos;
+        }
+        xwg_storef<true>(&Q.G.S[k], z);
+      } else {
+        const float cm = plane_at(j - 1), cj = plane_at(j);
+        const float cn = LDF(A.C + (size_t)min(j + 1, J) * NN + k);   // (unconditional: see joint_kernels.h, load_column)
+        const float qm = sgn(cm - cj, lw_of(j - 1, j - 1 == 0 ? A.lam_hf : A.lam_sc));
+        float qj = 0.f;
+        if (j < J) {
+          const float d = cj - cn, lw = lw_of(j, A.lam_sc);
+          qj = sgn(d, lw);
+          l1 = lw * fabsf(d);
+        }
+        xwg_storef<true>(&Q.G.S[(size_t)j * NN + k], qj - qm);
+      }
+      l1 = wave_sum_shfl(l1);
+      pos = wave_sum_shfl(pos);
+      if (lane == 0) {
+        red[wid][0] = l1;
+        red[wid][1] = pos;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int w = 0; w < kGmThreads / 64; ++w) {
+          t0 += red[w][0];
+          t1 += red[w][1];
+        }
+        if (pts) xwg_storef<true>(&Q.G.l1b[(size_t)(J + 1) * NVB + vb], t0);
+        else if (j < J) xwg_storef<true>(&Q.G.l1b[(size_t)j * NVB + vb], t0);
+        if (!pts && j == 0) xwg_storef<true>(&Q.G.posb[vb], t1);
+      }
+      __syncthreads();
+    }
+  }
+  if (!sync(false)) return;
+  // ---- stages 4, 5: adjoint products -----------------------------------------------------------------------------------
+  for (int q = 2; q < 4; ++q) {
+    for (int t = blk; t < TPB * Q.mm[q].nb; t += kChainBlocks)
+      chain_mm_tile<N>(Q.mm[q], t / TPB, (t % TPB) / (N / 64), (t % TPB) % (N / 64), Q.xa[q] != 0, Q.xb[q] != 0, As, Bs);
+    if (!sync(false)) return;
+  }
+  // ---- stage 6: greg and the inner products of the point-source term (mreg_finish2_kernel's blocks) ---------------------------
+  {
+    const float c0 = (N - 1) * 0.5f, inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm2 = 0.15915494309189535f * inv_s2;
+    for (int vb = blk; vb < NVB; vb += kChainBlocks) {
+      const int k = vb * kGmThreads + tid;
+      {
+        constexpr int MAXJ = 8;
+        float zv[MAXJ];
+        float g = LDF(Q.S + k);
+#pragma unroll
+        for (int s = 1; s <= MAXJ; ++s) zv[s - 1] = LDF(Q.Z + (size_t)min(s, J) * NN + k);
+        if (Q.has_l1) {
+#pragma unroll
+          for (int s = 1; s <= MAXJ; ++s) g += (s <= J) ? zv[s - 1] : 0.f;
+        }
+        xwg_storef<true>(&Q.greg[k], g);   // (write-through: the update kernel reads it behind the completion flag, L1-bypassing)
+      }
+      if (Q.with_pts) {
+        const float z = LDF(Q.S + (size_t)(J + 1) * NN + k) - LDF(Q.Z + (size_t)(J + 1) * NN + k);
+        const int u = k / N, v = k % N;
+        for (int i = 0; i < Q.M; ++i) {
+          const float tx = (float)v - (c0 + Q.ss * Q.cx[i]), ty = (float)u - (c0 + Q.ss * Q.cy[i]);
+          const float gq = z * nrm2 * expf(-0.5f * (tx * tx + ty * ty) * inv_s2);
+          const float sa = wave_sum_shfl(gq), sx = wave_sum_shfl(gq * tx * inv_s2), sy = wave_sum_shfl(gq * ty * inv_s2);
+          if (lane == 0) {
+            red[wid][i * 3] = sa;
+            red[wid][i * 3 + 1] = sx;
+            red[wid][i * 3 + 2] = sy;
+          }
+        }
+        __syncthreads();
+        if (tid < 3 * Q.M) {
+          float acc = 0.f;
+          for (int w = 0; w < kGmThreads / 64; ++w) acc += red[w][tid];
+          xwg_storef<true>(&Q.pts_part[(size_t)vb * 3 * kMaxSources + tid], acc);
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (!sync(false)) return;
+  // ---- stage 7: the values and inner products (mreg_regs2_kernel, one wave), then the completion flag ---------------------------
+  if (blk == 0 && wid == 0) {
+    const float *l1b = Q.G.l1b, *posb = Q.G.posb;
+    float a = 0.f, b = 0.f, c = 0.f;
+    if (Q.has_l1) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      const int n = J * NVB;
+      int i = lane;
+      for (; i + 192 < n; i += 256) {
+        const float v0 = LDF(l1b + i), v1 = LDF(l1b + i + 64), v2 = LDF(l1b + i + 128), v3 = LDF(l1b + i + 192);
+        a0 += v0;
+        a1 += v1;
+        a2 += v2;
+        a3 += v3;
+      }
+      for (; i < n; i += 64) a0 += LDF(l1b + i);
+      a = (a0 + a1) + (a2 + a3);
+    }
+    for (int i = lane; i < NVB; i += 64) b += LDF(posb + i);
+    if (Q.with_pts)
+      for (int i = lane; i < NVB; i += 64) c += LDF(l1b + (size_t)(J + 1) * NVB + i);
+    a = wave_sum_shfl(a);
+    b = wave_sum_shfl(b);
+    c = wave_sum_shfl(c);
+    if (lane == 0) {
+      Q.regs[0] = a;
+      Q.regs[1] = b;
+      if (Q.with_pts) Q.regs[2] = c;
+    }
+    if (Q.with_pts)
+      for (int t = 0; t < 3 * Q.M; ++t) {
+        float acc = 0.f;
+        for (int vb = lane; vb < NVB; vb += 64) acc += LDF(Q.pts_part + (size_t)vb * 3 * kMaxSources + t);
+        acc = wave_sum_shfl(acc);
+        if (lane == 0) Q.regs[4 + t] = acc;
+      }
+    if (Q.done_flag) {
+      __threadfence();
+      if (lane == 0) __hip_atomic_store(Q.done_flag, Q.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // test hook (LCMI_REG_DELAY_US): holds the second stream back in front of the chain, so that the update kernel of the
 // iteration really has to wait for the chain's completion flag
 __global__ void mreg_delay_kernel(long long ticks) {  // ticks of the constant 100 MHz counter

@@ -184,6 +184,13 @@ class JointFit:
     def iterations_done(self):
         return self._l.lc_joint_iterations_done(self.h)
 
+    def cluster_info(self):
+        """(workgroups per epoch of the most recent epoch launch - 0 = the one-workgroup kernel -, runs in which a cluster
+        launch gave up and the library fell back): lc_joint_cluster_info."""
+        parts, fb = C.c_int(), C.c_int()
+        self._chk(self._l.lc_joint_cluster_info(self.h, C.byref(parts), C.byref(fb)), 'cluster_info')
+        return parts.value, fb.value
+
     def loss_history(self):
         T = self.iterations_done
         hist = np.empty(T + 1, np.float32)

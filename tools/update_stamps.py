@@ -17,8 +17,8 @@ j.set_loss(W=W, lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source
 j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
 j.run_adabelief(50, init_learning_rate=1e-4); ctx.synchronize()
 out = (C.c_longlong * 16)()
-_lib.lib().lc_debug_get_jstamps.argtypes = [C.POINTER(C.c_longlong)]
-assert _lib.lib().lc_debug_get_jstamps(out) == 0
+_lib.lib().lc_debug_get_ustamps.argtypes = [C.POINTER(C.c_longlong)]
+assert _lib.lib().lc_debug_get_ustamps(out) == 0
 s = np.array(out[:], dtype=np.int64)
 t0 = min(s[0], s[2])
 names = {0: 'image block 0 starts', 1: 'last image block done', 2: 'scalar block starts', 3: 'scalars reduced', 4: 'flag seen',
