@@ -133,6 +133,8 @@ def supervise_rank(argv, grace_s=600.0, script=None):
     if state['line'] is not None:
         line = state['line']
         if killed or child.returncode != 0:
+            print(f'bench.py: rank {os.environ.get("RANK")}: the worker ended before the sharded joint fits did (killed after the '
+                  f'grace period: {killed}, exit code {child.returncode}); the headline line is kept', file=sys.stderr)
             try:
                 d = json.loads(line)
                 d['config'].setdefault('sharded_joint_fit', {})
@@ -146,7 +148,9 @@ def supervise_rank(argv, grace_s=600.0, script=None):
         sys.stdout.write(line + '\n')
         sys.stdout.flush()
     if state['marker_at'] is not None:
-        return 0
+        return 0    # (the headline was measured: what happened afterwards is in the line's error field and on stderr)
+    print(f'bench.py: rank {os.environ.get("RANK")}: the worker ended before the headline measurement (exit code '
+          f'{child.returncode})', file=sys.stderr)
     return child.returncode if child.returncode is not None else 1
 
 
@@ -510,6 +514,58 @@ def c3_shard_workload(ctx, iters=200):
             'loss_finite': bool(np.all(np.isfinite(hist)))}
 
 
+def c3_sharded_fit(ctx, rank, world, dist, iters=200):
+    """BASELINE.json configs[2] as north_star splits it: C3's 500 frames x 8 stars x 64 x 64 sharded over the ranks,
+    ceil(500 / N) frames each (the last rank takes what is left), no data-path collective - the frames are independent fits
+    (reference: the serial loop over frames at lightcurver/processes/psf_modelling.py:92).  Strong scaling: the 500 frames
+    are fixed; the time is the slowest rank's."""
+    import torch
+    from lightcurver_amd.psf_batch import PsfBatch
+    from lightcurver_amd.synthetic import make_psf_dataset
+    Ftot, S, n, ss = 500, 8, 64, 2
+    per = (Ftot + world - 1) // world
+    lo, hi = min(rank * per, Ftot), min((rank + 1) * per, Ftot)
+    F = hi - lo
+    ms = 0.0
+    finite = True
+    if F > 0:
+        ds = make_psf_dataset(F=F, S=S, n=n, ss=ss, seed=103 + 1000 * rank)
+        weight = (ds['masks'] / ds['noisemap'].astype(np.float64) ** 2).astype(np.float32)
+        b = PsfBatch(ds['data'], weight, ss, ctx)
+        g = ds['fwhm_guess']
+        f0 = np.sqrt(np.maximum(g * g - (2.0 / ss) ** 2, 1.0))
+        b.set_moffat(np.stack([f0, f0, np.zeros(F), np.full(F, 2.5)], axis=-1))
+        stars = np.zeros((F, S, 4), np.float32)
+        stars[..., 0] = (ds['data'] * ds['masks']).sum(axis=(-1, -2))
+        b.set_stars(stars)
+        b.set_grid(None)
+        b.fit_moffat(30)
+        b.propagate_noise()
+        b.set_regularization(None, 1.0, 1.0)
+        ab = dict(init_learning_rate=1e-4, schedule_learning_rate=True)
+        b.run_adabelief(5, **ab)
+        ctx.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    if F > 0:
+        b.run_adabelief(iters, **ab)
+        ctx.synchronize()
+    dt = time.perf_counter() - t0
+    if F > 0:
+        finite = bool(np.all(np.isfinite(b.loss_history())))
+        b.close()
+    t = torch.tensor([dt, 0.0 if finite else 1.0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t[0])
+    bytes_per = psf_bytes_per_cutout_iteration(n, ss, S)
+    return {'workload': f'C3 sharded: {Ftot} frames x {S} stars, {n}x{n} stamps over {world} ranks ({per} frames per rank, no '
+                        f'collective), {iters} AdaBelief iterations, one launch per rank',
+            'value': Ftot * S * iters / dt, 'unit': 'cutouts/sec', 'us_per_iteration': dt * 1e6 / iters, 'scaling': 'strong',
+            'frames_per_rank': per, 'ranks': world,
+            'roofline_frac_per_gpu': Ftot * S * iters * bytes_per / dt / 1e9 / HBM_PEAK_GBS / world,
+            'loss_finite': float(t[1]) == 0.0}
+
+
 def star_photometry_workload(ctx, iters=2000, with_cpu=True):
     """The reference's star photometry (star_photometry.py:257-326: 30 reference stars, each a 2000-iteration joint fit of
     one point source over its epochs, background fixed at zero) as one batched device fit: 30 stars x 100 epochs x 32x32,
@@ -564,16 +620,36 @@ def star_photometry_workload(ctx, iters=2000, with_cpu=True):
     return out
 
 
-def sharded_joint_fit(ctx, rank, world, iters=500, transport='collective', config='C4'):
+def all_ranks_agree(step, fn, world):
+    """Runs fn on this rank, then lets the ranks agree (host-side default group): a failure anywhere raises everywhere, so
+    that no rank walks into a collective or a barrier the failed one never reaches (tests/test_bench_supervisor_cpu.py
+    rehearses it on eight gloo ranks)."""
+    import torch.distributed as dist
+    err, out = None, None
+    try:
+        out = fn()
+    except Exception as e:
+        err = repr(e)
+    errs = [None] * world
+    dist.all_gather_object(errs, err)
+    bad = [f'rank {r}: {e}' for r, e in enumerate(errs) if e]
+    if bad:
+        raise RuntimeError(f'{step}: ' + '; '.join(bad))
+    return out
+
+
+def sharded_joint_fit(ctx, rank, world, iters=500, transport='rccl', config='C4'):
     """C4's 200 epochs (or, config='C5', BASELINE.json configs[4]: 1000 epochs of 128 x 128 with 4 sources, the joint fit
     that needs the eight GPUs) sharded over the ranks; the shared block is all-reduced every iteration - in place by RCCL
-    (transport 'collective'; gloo staged through the host in the one-GPU rehearsal) or by the library's one-shot
-    peer-memory kernel over HIP IPC (transport 'peer', csrc/peer.hip); the loop runs in C++ (lc_joint_run_sharded).
+    through the library's own communicator (transport 'rccl': lc_rccl_allreduce is the callback of the C++ loop, no Python
+    per iteration; in the one-GPU rehearsal, where RCCL refuses two ranks on one device, gloo staged through the host), by
+    torch.distributed's nccl group called back from the loop ('torch-nccl', the cross-check) or by the library's one-shot
+    peer-memory kernel over HIP IPC ('peer', csrc/peer.hip); the loop runs in C++ (lc_joint_run_sharded).
     Strong scaling: the total work is fixed."""
     import datetime
     import torch
     import torch.distributed as dist
-    from lightcurver_amd.distributed import PeerGroup, ShardedJointOptimizer, shard_epochs
+    from lightcurver_amd.distributed import PeerGroup, RcclGroup, ShardedJointOptimizer, shard_epochs
     from lightcurver_amd.joint import JointFit
     from lightcurver_amd.synthetic import make_roi_dataset
     E, n, M, ss, seed = (1000, 128, 4, 2, 105) if config == 'C5' else (200, 64, 2, 2, 104)
@@ -581,19 +657,7 @@ def sharded_joint_fit(ctx, rank, world, iters=500, transport='collective', confi
     lo, hi = shard_epochs(E, world, rank)
 
     def all_ranks(step, fn):
-        """Runs fn on this rank, then lets the ranks agree (host-side group): a failure anywhere raises everywhere, so
-        that no rank walks into a collective or a barrier the failed one never reaches."""
-        err, out = None, None
-        try:
-            out = fn()
-        except Exception as e:
-            err = repr(e)
-        errs = [None] * world
-        dist.all_gather_object(errs, err)
-        bad = [f'rank {r}: {e}' for r, e in enumerate(errs) if e]
-        if bad:
-            raise RuntimeError(f'{step}: ' + '; '.join(bad))
-        return out
+        return all_ranks_agree(step, fn, world)
 
     def make_fit():
         j = JointFit(ds['data'][lo:hi], ds['noisemap'][lo:hi].astype(np.float64) ** 2, ds['psf'][lo:hi], ss, M, ctx)
@@ -607,18 +671,20 @@ def sharded_joint_fit(ctx, rank, world, iters=500, transport='collective', confi
         return j
 
     j = all_ranks('set-up of the local fit', make_fit)
-    peer = None
+    peer = rccl = None
+    group = None
     if transport == 'peer':
-        group = None
         peer = PeerGroup(j)                 # IPC handles travel over the default (gloo) group; fails on every rank or on none
     elif os.environ.get('LCMI_BENCH_DEVICE') is not None:
         # one-GPU rehearsal (every rank on the same device): RCCL refuses two ranks on one GPU, so the shared block
         # is staged through the host over the gloo group
-        group = None
-    else:
+        pass
+    elif transport == 'torch-nccl':
         torch.cuda.set_device(ctx.stream()[1])
         group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=180))
-    opt = ShardedJointOptimizer(j, group, peer=peer)
+    else:
+        rccl = RcclGroup(ctx)               # the unique id travels over the default (gloo) group; raises on every rank or on none
+    opt = ShardedJointOptimizer(j, group, peer=peer, rccl=rccl)
     ab = dict(init_learning_rate=1e-4, schedule_learning_rate=False)
 
     def run_synced(n):
@@ -634,18 +700,23 @@ def sharded_joint_fit(ctx, rank, world, iters=500, transport='collective', confi
     dt = float(t[0])
     hist = j.loss_history()
     kind = opt.transport
+    rccl_calls = rccl.calls if rccl is not None else 0
     if peer is not None:
         peer.close()
+    if rccl is not None:
+        rccl.close()
     j.close()
     transport = {'peer': 'one-shot peer-memory all-reduce (HIP IPC, every rank reads the others directly)',
-                 'rccl': 'RCCL all-reduce in place in device memory',
+                 'rccl-native': "RCCL all-reduce in place in device memory by the library's own communicator (no Python in the loop)",
+                 'rccl': 'RCCL all-reduce in place in device memory (torch.distributed nccl group called back from the loop)',
                  'gloo': 'gloo all-reduce staged through the host (one-GPU rehearsal)'}[kind]
     return {'workload': f'{config} sharded: {E} epochs x {n}x{n} ROI over {world} ranks, {transport} of the shared block '
                         f'({n * ss * n * ss + 4 * M + 2} floats) once per iteration, {iters} iterations',
             'value': E * iters / dt, 'unit': 'cutouts/sec', 'us_per_iteration': dt * 1e6 / iters, 'scaling': 'strong',
             # what RCCL saw: the size of the nccl group the block was reduced over, 0 when the collective was gloo's
-            'rccl_ranks': dist.get_world_size(group) if kind == 'rccl' else 0, 'collective': kind,
-            'device_collective': kind in ('rccl', 'peer'), 'ranks': world, 'loop': 'lc_joint_run_sharded (C++)',
+            'rccl_ranks': world if kind == 'rccl-native' else (dist.get_world_size(group) if kind == 'rccl' else 0),
+            'rccl_all_reduces': rccl_calls, 'collective': kind,
+            'device_collective': kind in ('rccl', 'rccl-native', 'peer'), 'ranks': world, 'loop': 'lc_joint_run_sharded (C++)',
             'loss_finite': bool(np.all(np.isfinite(hist)))}
 
 
@@ -821,8 +892,12 @@ def main():
             os.write(real_stdout, (json.dumps(out) + '\n').encode())
         os.write(real_stdout, b'HEADLINE_DONE\n')
 
-    sharded = sharded_peer = sharded_c5 = None
+    sharded = sharded_peer = sharded_c5 = sharded_c5_rccl = sharded_c3 = None
     if world > 1 and not args.no_sharded_joint:
+        try:   # C3 as north_star splits it: the 500 frames over the ranks, no collective
+            sharded_c3 = c3_sharded_fit(ctx, rank, world, dist)
+        except Exception as e:
+            sharded_c3 = {'error': repr(e)}
         try:
             sharded = sharded_joint_fit(ctx, rank, world)
         except Exception as e:
@@ -832,6 +907,10 @@ def main():
         except Exception as e:
             sharded_peer = {'error': repr(e)}
         try:   # C5, the configuration sharding is for: 1000 epochs of 128 x 128 (one GPU alone: ~1.54 ms per iteration)
+            sharded_c5_rccl = sharded_joint_fit(ctx, rank, world, iters=100, transport='rccl', config='C5')
+        except Exception as e:
+            sharded_c5_rccl = {'error': repr(e)}
+        try:
             sharded_c5 = sharded_joint_fit(ctx, rank, world, iters=100, transport='peer', config='C5')
         except Exception as e:
             sharded_c5 = {'error': repr(e)}
@@ -844,6 +923,10 @@ def main():
             out['config']['sharded_joint_fit_peer'] = sharded_peer
         if sharded_c5 is not None:
             out['config']['sharded_joint_fit_c5_peer'] = sharded_c5
+        if sharded_c5_rccl is not None:
+            out['config']['sharded_joint_fit_c5'] = sharded_c5_rccl
+        if sharded_c3 is not None:
+            out['config']['sharded_psf_fit_c3'] = sharded_c3
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist:
         dist.barrier()

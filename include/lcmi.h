@@ -303,6 +303,26 @@ int lc_peer_allreduce(void *group, void *dev_buf, int count, void *hip_stream);
 int lc_peer_group_status(lc_peer_group *g);
 void lc_peer_group_destroy(lc_peer_group *g);
 
+/* RCCL group: the same all-reduce by RCCL, from the library's own loop ("RCCL all-reduce over xGMI only for the
+ * shared-background gradient in the joint fit", BASELINE.json north_star; the reference keeps all epochs on one device,
+ * lightcurver/processes/roi_modelling.py:154-160,213, and has no counterpart).  The library loads librccl at run time (it
+ * does not link against it; a copy the process already carries - torch's - is shared) and owns the communicator:
+ *   lc_rccl_available   1 when librccl could be loaded
+ *   lc_rccl_unique_id   rank 0: a fresh ncclUniqueId (id_bytes >= 128), which the caller hands to every rank over any
+ *                       channel it has (a torch.distributed broadcast, MPI, a file)
+ *   lc_rccl_group_create  every rank, collectively: ncclCommInitRank on the context's device
+ *   lc_rccl_allreduce   has the signature of lc_allreduce_fn with user = the group: ncclAllReduce (float32, sum) in place
+ *                       on the given stream, enqueued, never synchronised - pass it to lc_joint_run_sharded and no host
+ *                       code runs inside the loop
+ *   lc_rccl_group_info  rank, size, all-reduces enqueued so far (each may be NULL) */
+typedef struct lc_rccl_group lc_rccl_group;
+int lc_rccl_available(void);
+int lc_rccl_unique_id(void *id_out, int id_bytes);
+int lc_rccl_group_create(lc_ctx *ctx, const void *unique_id, int id_bytes, int rank, int world, lc_rccl_group **out);
+int lc_rccl_allreduce(void *group, void *dev_buf, int count, void *hip_stream);
+int lc_rccl_group_info(lc_rccl_group *g, int *rank, int *world, long long *calls);
+void lc_rccl_group_destroy(lc_rccl_group *g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@ vp = C.c_void_p
 LBFGS_EVAL = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp, dp)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 IPC_HANDLE_BYTES = 64
+RCCL_ID_BYTES = 128
 
 
 class AdabeliefCfg(C.Structure):
@@ -121,6 +122,12 @@ SIGNATURES = {
     'lc_peer_allreduce': (C.c_int, [vp, vp, C.c_int, vp]),
     'lc_peer_group_status': (C.c_int, [vp]),
     'lc_peer_group_destroy': (None, [vp]),
+    'lc_rccl_available': (C.c_int, []),
+    'lc_rccl_unique_id': (C.c_int, [C.c_void_p, C.c_int]),
+    'lc_rccl_group_create': (C.c_int, [vp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    'lc_rccl_allreduce': (C.c_int, [vp, vp, C.c_int, vp]),
+    'lc_rccl_group_info': (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    'lc_rccl_group_destroy': (None, [vp]),
 }
 
 _lib = None

@@ -50,20 +50,29 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs A) {
     __hip_atomic_store(peer_flags(A.xch[A.rank], A.cpad) + par * A.nchunks + c, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // once a wait has run out, every later call of this rank gives up at once: a broken exchange costs one time-out, not one per call
     int good = (__hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) ? 1 : 0;
+    // exit condition every workgroup reaches: a peer that never shows up is reported, not waited for - bounded by the
+    // constant 100 MHz counter (s_memrealtime; 2 s), not by a spin count whose duration depends on the clock and on the
+    // latency of the xGMI hop
+    const long long t0 = wall_clock64();
     for (int r = 0; r < A.world && good; ++r) {
       if (r == A.rank) continue;
       const unsigned int *fl = peer_flags(A.xch[r], A.cpad) + par * A.nchunks + c;
       int spins = 0;
-      // exit condition every workgroup reaches: a peer that never shows up is reported, not waited for (~2 s)
       while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
         __builtin_amdgcn_s_sleep(16);
-        if (++spins > (1 << 22)) {
+        if ((++spins & 63) == 0 && wall_clock64() - t0 > 200000000ll) {
           good = 0;
           __hip_atomic_store(A.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
       }
     }
+    // One system-scope acquire by the polling lane, behind the last successful poll and in front of the workgroup barrier that
+    // releases the readers (the consumer side of the release the peers' flag stores carry).  The readers' loads are
+    // system-scope atomics - never served from a cache of this device - so the fence orders rather than invalidates for
+    // them; it is one buffer_inv per 4 KiB chunk, 16 - 64 of them per call (measured at world size 1: no change of the
+    // sharded loop's 90 us per iteration; an agent-scope acquire by every block of the 1 000-block update cost 33 us).
+    if (good && A.world > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     ok = good;
   }
   __syncthreads();

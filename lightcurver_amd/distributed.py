@@ -171,6 +171,77 @@ class PeerGroup:
             pass
 
 
+class RcclGroup:
+    """RCCL communicator owned by the library (include/lcmi.h "RCCL group", csrc/rccl.hip): librccl is loaded at run time,
+    the unique id of rank 0 travels over ``group`` (any torch.distributed group of the same ranks - gloo will do: the
+    communicator is the library's own, not torch's), and ``callback()`` hands lc_joint_run_sharded the C entry point
+    lc_rccl_allreduce - ncclAllReduce in place on the library's stream, no Python inside the loop.  One rank per GPU (RCCL
+    refuses two ranks on one device)."""
+
+    def __init__(self, ctx, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib
+        self._l = _lib.lib()
+        self.ctx = ctx
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.group = group = host_group(group)
+        self.h, err, raw = None, None, b''
+        if self.rank == 0:
+            try:
+                buf = C.create_string_buffer(_lib.RCCL_ID_BYTES)
+                rc = self._l.lc_rccl_unique_id(buf, _lib.RCCL_ID_BYTES)
+                if rc:
+                    raise RuntimeError(f'lc_rccl_unique_id failed ({rc}): librccl not loadable?')
+                raw = bytes(buf.raw)
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+        parts = [None] * self.world
+        dist.all_gather_object(parts, (err, raw), group=group)
+        if parts[0][0]:
+            raise RuntimeError(f'RCCL group (unique id): rank 0: {parts[0][0]}')
+        err = None
+        try:
+            h = C.c_void_p()
+            uid = C.create_string_buffer(parts[0][1], _lib.RCCL_ID_BYTES)
+            ctx.check(self._l.lc_rccl_group_create(ctx.h, uid, _lib.RCCL_ID_BYTES, self.rank, self.world, C.byref(h)),
+                      'lc_rccl_group_create')
+            self.h = h
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+        raise_together(err, 'RCCL group (ncclCommInitRank)', group)
+
+    def callback(self):
+        """(function pointer, user pointer) for lc_joint_run_sharded: the library's own lc_rccl_allreduce."""
+        import ctypes as C
+        return C.cast(self._l.lc_rccl_allreduce, C.c_void_p), self.h
+
+    def all_reduce(self, dev_ptr, count, stream_ptr):
+        """One all-reduce of ``count`` floats at ``dev_ptr``, enqueued on ``stream_ptr`` (what the loop calls per iteration)."""
+        import ctypes as C
+        self.ctx.check(self._l.lc_rccl_allreduce(self.h, C.c_void_p(dev_ptr), int(count), C.c_void_p(stream_ptr)), 'lc_rccl_allreduce')
+
+    @property
+    def calls(self):
+        import ctypes as C
+        n = C.c_longlong()
+        self._l.lc_rccl_group_info(self.h, None, None, C.byref(n))
+        return n.value
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self._l.lc_rccl_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            import sys
+            if not sys.is_finalizing():
+                self.close()
+        except Exception:
+            pass
+
+
 class ShardedJointOptimizer:
     """Drives ``n_iter`` AdaBelief iterations of a sharded joint fit.
 
@@ -179,12 +250,14 @@ class ShardedJointOptimizer:
     step_update(**adabelief_cfg).
     """
 
-    def __init__(self, local_fit, group=None, peer=None):
+    def __init__(self, local_fit, group=None, peer=None, rccl=None):
         """peer: a ``PeerGroup`` over the same ranks - the shared block is then reduced by the one-shot peer-memory kernel
-        instead of the process group's collective."""
+        instead of the process group's collective.  rccl: an ``RcclGroup`` over the same ranks - reduced by the library's own
+        RCCL communicator, called from the C++ loop (no Python per iteration); ``group`` then only carries host objects."""
         self.fit = local_fit
         self.group = group
         self.peer = peer
+        self.rccl = rccl
         self.host_group = host_group(group)   # (collective on first use: see host_group)
         self._dev = None  # (tensor view of the shared block, torch ExternalStream of the library's stream)
         self._ref_agreed = False
@@ -194,6 +267,8 @@ class ShardedJointOptimizer:
         """'peer' (one-shot peer-memory kernel), 'rccl' (in place in device memory) or 'gloo' (staged through the host)."""
         if self.peer is not None:
             return 'peer'
+        if self.rccl is not None:
+            return 'rccl-native'
         return 'rccl' if self._device_collective() else 'gloo'
 
     def _agree_flux_reference(self):
@@ -273,6 +348,11 @@ class ShardedJointOptimizer:
                 except Exception as e:  # noqa: BLE001
                     err = repr(e)
                 raise_together(err, 'sharded joint fit (peer all-reduce)', self.host_group)
+                return
+            if self.rccl is not None:
+                # the library's own communicator: lc_rccl_allreduce is the callback, the loop never leaves C++
+                fn, user = self.rccl.callback()
+                self.fit.run_sharded(int(n_iter), fn, user, **adabelief_cfg)
                 return
             failure = []
 
@@ -416,6 +496,9 @@ def sharded_lbfgs(optimizer, free, maxiter, lower=None, upper=None):
                 if rc:
                     raise RuntimeError(f'lc_peer_allreduce failed ({rc})')
                 optimizer.peer.check()       # (synchronises the stream, as the gradient read-back below would anyway)
+            elif getattr(optimizer, 'rccl', None) is not None:
+                ptr, count = fit.shared_buffer()
+                optimizer.rccl.all_reduce(ptr, count, fit.ctx.stream()[0])
             elif optimizer._device_collective():
                 optimizer.all_reduce_device()
             else:

@@ -55,6 +55,47 @@ def test_rccl_in_place_all_reduce_world_size_1(ctx):
     np.testing.assert_array_equal(fits[0].get_params()['h'], fits[1].get_params()['h'])
 
 
+def test_native_rccl_all_reduce_world_size_1(ctx):
+    """The library's OWN RCCL communicator (include/lcmi.h "RCCL group", csrc/rccl.hip: librccl loaded at run time, unique id
+    from rank 0, ncclCommInitRank on the context's device) as the all-reduce callback of lc_joint_run_sharded: no Python
+    inside the loop.  The torch process group is gloo and carries only the unique id.  One rank: the all-reduce is the
+    identity, so the sharded drive reproduces lc_joint_run_adabelief bit for bit - and RCCL really ran (call count)."""
+    import torch.distributed as dist
+    from lightcurver_amd import _lib
+    from lightcurver_amd.distributed import RcclGroup, ShardedJointOptimizer
+    from lightcurver_amd.joint import JointFit
+    assert _lib.lib().lc_rccl_available() == 1
+    E, M, n, ss, T = 6, 2, 32, 2, 12
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=4242)
+    p = dict(ds['truth'])
+    p['a'] = np.asarray(p['a']) * 0.9
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h']
+    fits = []
+    for _ in range(2):
+        j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
+        j.set_params(**p)
+        j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_flux_uniformity=0.5)
+        j.set_free(free)
+        fits.append(j)
+    fits[0].run_adabelief(T, init_learning_rate=1e-3)
+    ref_hist = fits[0].loss_history()
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1)
+    try:
+        rccl = RcclGroup(ctx)
+        opt = ShardedJointOptimizer(fits[1], rccl=rccl)
+        assert opt.transport == 'rccl-native'
+        opt.run(T, init_learning_rate=1e-3)
+        ctx.synchronize()
+        assert rccl.calls == T
+        np.testing.assert_array_equal(fits[1].loss_history(), ref_hist)
+        np.testing.assert_array_equal(fits[0].get_params()['h'], fits[1].get_params()['h'])
+        hist, res = opt.run_lbfgs(['a', 'dx', 'dy'], 3)       # the L-BFGS-B stage reduces through the same communicator
+        assert rccl.calls > T and np.all(np.isfinite(hist))
+        rccl.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_two_hip_ranks_equal_the_unsharded_fit(ctx, tmp_path):
     """Two processes, each with its own JointFit over half of the epochs (both on the one GPU of the box, the shared
     block all-reduced over gloo), driven by ShardedJointOptimizer: the replicas of h / c and the gathered per-epoch
