@@ -395,6 +395,49 @@ def joint_workload(ctx, E, n, M, seed, iters, label):
             'loss_finite': bool(np.all(np.isfinite(hist))), 'loss_first_last': [float(hist[0]), float(hist[-1])]}
 
 
+def joint_cpu_port(n, M, seed, epochs=32, seconds_target=8.0):
+    """CPU figure beside a joint-fit entry (north_star: "next to the STARRED-CPU path timed on the same box's host cores"):
+    oracle/joint_cpu.c - the joint fit WITH the background as plain C + OpenMP over the epochs (radix-2 FFT convolution, hand-derived
+    adjoints, the same loss terms and AdaBelief as the HIP path; fp32 build; its fp64 build is pinned to oracle/model.py at 1e-9
+    in tests/test_joint_cpu_port_cpu.py) - on `epochs` epochs of the same synthetic workload, full AdaBelief iterations, all the
+    cores the job may use, then one.  The loop it stands for: lightcurver/processes/roi_modelling.py:308-334."""
+    import tempfile as _tf
+    from oracle import joint_cpu
+    from lightcurver_amd.synthetic import make_roi_dataset
+    try:  # compiled for the CPU this runs on; the portable build shipped with the repo is the fall-back
+        path = joint_cpu.build(native=True, out=os.path.join(_tf.mkdtemp(prefix='lcmi_cpuj_', dir='/tmp'), 'libjointcpu.so'))
+    except Exception:
+        path = None
+    ss = 2
+    cores = effective_cpus()
+    epochs = max(epochs, cores)
+    ds = make_roi_dataset(E=epochs, M=M, n=n, ss=ss, seed=seed)
+    out = {}
+    for label, thr, budget in (('all', cores, 0.7 * seconds_target), ('one', 1, 0.3 * seconds_target)):
+        c = joint_cpu.JointCpu(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, double=False, threads=thr,
+                               lib_path=path)
+        p = dict(ds['truth'])
+        p['a'] = np.asarray(p['a']) * 0.9
+        c.set_params(**p)
+        c.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
+        c.run(1, threads=thr)                      # thread pool, first touch of the work space
+        k, t0 = 0, time.perf_counter()
+        while True:
+            hist = c.run(2, threads=thr)
+            k += 3                                 # (a run of 2 iterations evaluates the model three times)
+            dt = time.perf_counter() - t0
+            if dt > budget or k >= 600:
+                break
+        c.close()
+        out[label] = dict(rate=epochs * k / dt, k=k, dt=dt, finite=bool(np.all(np.isfinite(hist))))
+    return dict(value=out['all']['rate'], unit='cutouts/sec', cores=cores, host_logical_cpus=os.cpu_count(), kind='port',
+                sample=f"{out['all']['k']} forward + backward evaluations with AdaBelief updates on {epochs} epochs x {n}x{n} of the same "
+                       f"synthetic workload ({out['all']['dt']:.1f} s), oracle/joint_cpu.c fp32 + OpenMP over the epochs",
+                value_one_thread=out['one']['rate'],
+                sample_one_thread=f"{out['one']['k']} evaluations on the same epochs ({out['one']['dt']:.1f} s)",
+                loss_finite=out['all']['finite'] and out['one']['finite'])
+
+
 def joint_cpu_oracle(n, M, seed, epochs=4, seconds_target=6.0):
     """CPU figure beside a joint-fit entry: loss + full gradient of the same model by the float64 torch oracle (oracle/model.py,
     autograd - the checker of the parity tests, kind 'oracle': not a tuned port) on `epochs` epochs of the same synthetic
@@ -418,7 +461,7 @@ def joint_cpu_oracle(n, M, seed, epochs=4, seconds_target=6.0):
         dt = time.perf_counter() - t0
         if dt > seconds_target or k >= 200:
             break
-    return dict(value=epochs * k / dt, unit='cutouts/sec', cores=torch.get_num_threads(), kind='oracle',
+    return dict(value=epochs * k / dt, unit='cutouts/sec', cores=min(torch.get_num_threads(), effective_cpus()), kind='oracle',
                 sample=f'{k} evaluations of loss + full gradient on {epochs} epochs x {n}x{n} of the same synthetic workload '
                        f'({dt:.1f} s), oracle/model.py in torch float64 with autograd (the parity checker, not a tuned port)')
 
@@ -871,11 +914,12 @@ def main():
                         if 'roofline' in w and not (key == 'C4' and 'shard' in w['workload'][:10]):
                             w['roofline']['traffic'] = tr
                             w['roofline']['traffic_source'] = src
-            if not args.no_cpu_baseline:   # the CPU path timed beside the joint fit too (north_star): attached to the C4 entry
-                try:
-                    extra[0]['cpu_baseline'] = joint_cpu_oracle(n=64, M=2, seed=104)
-                except Exception as e:
-                    extra[0]['cpu_baseline'] = {'value': None, 'error': repr(e)}
+            if not args.no_cpu_baseline:   # the CPU path timed beside the joint fits too (north_star): C4 and the C5 shard
+                for idx, kw in ((0, dict(n=64, M=2, seed=104, seconds_target=8.0)), (2, dict(n=128, M=4, seed=105, seconds_target=6.0))):
+                    try:
+                        extra[idx]['cpu_baseline'] = joint_cpu_port(**kw)
+                    except Exception as e:
+                        extra[idx]['cpu_baseline'] = {'value': None, 'error': repr(e)}
             out['config']['other_workloads'] = extra
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -16,7 +16,8 @@ pinned only by library known-answer checks (scipy ``fftconvolve``/
 ``map_coordinates``, starlet exact reconstruction, finite differences).
 
 Contents: ``model.py`` / ``optim.py`` (torch float64 + autograd: the oracle), ``prep.py`` (stamp pre-processing),
-``psf_cpu.c`` and ``joint_ps_cpu.c`` (plain-C restatements of the PSF pixel-grid stage and of the point-source-only joint
-fit in the direct separable form; their float64 builds are second, algorithmically independent checkers, their float32
+``psf_cpu.c``, ``joint_ps_cpu.c`` and ``joint_cpu.c`` (plain-C restatements of the PSF pixel-grid stage, of the
+point-source-only joint fit in the direct separable form, and of the joint fit with the pixelated background - radix-2 FFT
+convolution, hand-derived adjoints; their float64 builds are further, algorithmically independent checkers, their float32
 builds the ``cpu_baseline`` "port" figures of ``bench.py``).
 """
