@@ -232,3 +232,28 @@ def test_flux_uniformity_with_small_scatter(ctx, sigma_rel):
     assert H.rel_err(out[10.0][3], out[10.0][1]) < 1e-4
     # the chi2 gradient (~1e2..1e4) dwarfs the term's (lam / (E std) * (a - mean) ~ lam / E): isolate it with its own bound
     assert np.abs(g_d - g_o).max() < 2e-3 * np.abs(g_o).max() + 2e-6 * np.abs(out[0.0][1]).max()
+
+
+@pytest.mark.parametrize('E,M,n,alpha', [(6, 2, 32, 0.0), (4, 2, 64, 0.0), (3, 3, 32, 2.0)])
+def test_loss_and_gradients_against_the_c_port(ctx, E, M, n, alpha):
+    """A third implementation beside the HIP path and the torch oracle: oracle/joint_cpu.c in float64 (its own radix-2 FFTs,
+    hand-derived adjoints; pinned to oracle/model.py at 1e-9 in tests/test_joint_cpu_port_cpu.py) at sizes the torch
+    autograd oracle is slow at - every loss term on, 64 x 64 stamps (the kernel C4 runs) included."""
+    from oracle.joint_cpu import JointCpu
+    ss = 2
+    ds, j, po, data, sig2, psf = _setup(ctx, E, M, n, ss, 300 + n + E, alpha_sigma=alpha)
+    lam = dict(lam_scales=1.0, lam_hf=1.0, lam_positivity=50.0, lam_positivity_ps=5.0, lam_pts_source=0.05, lam_flux_uniformity=2.0)
+    W = j.propagate_noise()
+    j.set_loss(W=W, **lam)
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean']
+    j.set_free(free)
+    loss, g = j.loss_grad(free)
+    c = JointCpu(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, double=True)
+    c.set_params(**{k: v.numpy() for k, v in po.items()})
+    c.set_loss(W=W, **lam)
+    Lc, gc = c.eval()
+    c.close()
+    assert abs(loss - Lc) / abs(Lc) < 3e-5, (loss, Lc)
+    for k in free:
+        assert H.rel_err(g[k], gc[k]) < (3e-4 if k in ('c_x', 'c_y') else 1e-4), k
+    j.close()
