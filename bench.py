@@ -55,6 +55,17 @@ def joint_flops_per_cutout_iteration(n, ss):
     return 10.0 * (2 * N) ** 2 * math.log2((2 * N) ** 2) + 40.0 * N * N  # SURVEY.md 8(d), FFT route
 
 
+def joint_flops_executed_per_cutout_iteration(n, ss):
+    """What the epoch kernel executes (csrc/joint_kernels.h) instead of SURVEY's (2 N)^2 transforms: length L = 3 N / 2 (the
+    smallest alias-free 'same' window), two real rows per complex transform, half spectra, binned rows - per epoch N / 2
+    complex row transforms of length L in phase A and N / 2 in phase C', L / 2 forward + L / 2 inverse column transforms in
+    each of B and B', and n / 2 + n / 2 transforms of length L / 2 in phase C; 5 L log2 L flop per complex transform, plus
+    ~40 N^2 for the spectrum products, scene, residual and gradient arithmetic."""
+    N = n * ss
+    L = 3 * N // 2
+    return 5.0 * ((N + 2 * L) * L * math.log2(L) + n * (L / 2) * math.log2(L / 2)) + 40.0 * N * N
+
+
 def hbm_roofline(bytes_per_launch, launch_s, kernel, extra=None):
     achieved = bytes_per_launch / launch_s / 1e9
     r = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -194,68 +205,126 @@ def measure_traffic(timeout_s=150):
                      f'WRITE_SIZE {out["WRITE_SIZE"]:.0f} KiB per {ITERS_PER_STEP}-iteration launch')
 
 
-JOINT_PMC_ITERS = 30   # iterations of a --pmc-child-joint run (10 untimed + 20)
+PMC_ITERS = 20   # iterations inside a marked section of the --pmc-child-sections run
+# the sections of that run: key -> (what is iterated, rows of the section are divided by this many units)
+PMC_SECTIONS = ('C4', 'C4 shard', 'C5 shard', 'C3 shard', 'star photometry')
 
 
-def measure_joint_traffic(E, n, M, timeout_s=150):
-    """HBM traffic of ONE joint-fit iteration (every kernel of it: epoch kernel or phases, reduction + update, regulariser
-    chain) from the same two rocprofv3 --pmc passes as measure_traffic, on a child that runs JOINT_PMC_ITERS iterations.
-    LCMI_EVENT_SYNC=1: counter collection serialises the two streams, the update must wait for the chain by an event."""
+def measure_section_traffic(timeout_s=240):
+    """HBM traffic of ONE iteration of every secondary workload from the same two rocprofv3 --pmc passes as measure_traffic,
+    on ONE child per counter that runs the workloads one after the other.  The measured iterations of a workload are bracketed
+    explicitly: the child launches a marker dispatch (lc_ctx_marker, kernel lc_marker_kernel) before and after them, and only
+    the rows between the two markers are summed - every kernel of the iteration (epoch kernel or phases, reduction + update,
+    regulariser chain), nothing of the set-up, whatever the launch counts are.  LCMI_EVENT_SYNC=1: counter collection
+    serialises the two streams, the update must wait for the chain by an event.
+    Returns {key: (bytes per iteration or None, source text)}."""
     exe = shutil.which('rocprofv3')
     if not exe:
-        return None, 'rocprofv3 not found'
+        return {k: (None, 'rocprofv3 not found') for k in PMC_SECTIONS}
     tot = {}
-    tmp = tempfile.mkdtemp(prefix='lcmi_pmcj_', dir='/tmp')
+    tmp = tempfile.mkdtemp(prefix='lcmi_pmcs_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp', LCMI_EVENT_SYNC='1')
     try:
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             d = os.path.join(tmp, counter)
             cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable,
-                   os.path.abspath(__file__), '--pmc-child-joint', f'{E},{n},{M}']
+                   os.path.abspath(__file__), '--pmc-child-sections']
             try:
                 subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                timeout=timeout_s, check=True)
             except Exception as e:
-                return None, f'{counter} pass failed: {e!r}'
-            per_kernel = {}
+                return {k: (None, f'{counter} pass failed: {e!r}') for k in PMC_SECTIONS}
+            rows = []
             for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r.get('Counter_Name') != counter:
-                        continue
-                    k = r.get('Kernel_Name', '')
-                    c = per_kernel.setdefault(k, [0, 0.0])
-                    c[0] += 1
-                    c[1] += float(r['Counter_Value'])
-            # the kernels of the iterations (launched at least once per iteration), not those of the set-up
-            vals = [v for k, (c, v) in per_kernel.items() if c >= JOINT_PMC_ITERS and c % JOINT_PMC_ITERS == 0]
-            if not vals:
-                return None, f'no {counter} rows for the iteration kernels'
-            tot[counter] = sum(vals) / JOINT_PMC_ITERS
+                    if r.get('Counter_Name') == counter:
+                        rows.append((int(r['Dispatch_Id']), r.get('Kernel_Name', ''), float(r['Counter_Value'])))
+            rows.sort()
+            sums, n_markers, open_section = {}, 0, None
+            for _, name, val in rows:
+                if 'lc_marker_kernel' in name:
+                    n_markers += 1
+                    open_section = (n_markers - 1) // 2 if n_markers % 2 == 1 else None
+                elif open_section is not None and open_section < len(PMC_SECTIONS):
+                    sums[open_section] = sums.get(open_section, 0.0) + val
+            if n_markers != 2 * len(PMC_SECTIONS):
+                return {k: (None, f'{counter}: {n_markers} markers in the counter rows, expected {2 * len(PMC_SECTIONS)}') for k in PMC_SECTIONS}
+            tot[counter] = sums
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    traffic = (2.0 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0
-    return traffic, (f'rocprofv3 --pmc passes inside this run, all kernels of one iteration: FETCH_SIZE {tot["FETCH_SIZE"]:.0f} KiB '
-                     f'(x2 on gfx950) + WRITE_SIZE {tot["WRITE_SIZE"]:.0f} KiB')
+    out = {}
+    for i, key in enumerate(PMC_SECTIONS):
+        fs, ws = tot['FETCH_SIZE'].get(i, 0.0) / PMC_ITERS, tot['WRITE_SIZE'].get(i, 0.0) / PMC_ITERS
+        out[key] = ((2.0 * fs + ws) * 1024.0,
+                    f'rocprofv3 --pmc passes inside this run, every kernel between the markers around {PMC_ITERS} iterations: '
+                    f'FETCH_SIZE {fs:.0f} KiB (x2 on gfx950) + WRITE_SIZE {ws:.0f} KiB per iteration')
+    return out
 
 
-def joint_pmc_child(spec):
-    """under rocprofv3 --pmc: JOINT_PMC_ITERS iterations of the joint workload, nothing timed"""
+def pmc_sections_child():
+    """under rocprofv3 --pmc: the secondary workloads, PMC_ITERS iterations of each between two marker dispatches; nothing timed"""
     from lightcurver_amd import _lib
-    from lightcurver_amd.joint import JointFit
-    from lightcurver_amd.synthetic import make_roi_dataset
-    E, n, M = [int(v) for v in spec.split(',')]
-    ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=104 if n == 64 else 105)
+    from lightcurver_amd.joint import JointFit, StarPhotometryBatch
+    from lightcurver_amd.psf_batch import PsfBatch
+    from lightcurver_amd.synthetic import make_psf_dataset, make_roi_dataset
     ctx = _lib.Context(0)
-    j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], 2, M, ctx)
-    p = dict(ds['truth'])
-    p['a'] = p['a'] * 0.9
-    j.set_params(**p)
-    W = j.propagate_noise()
-    j.set_loss(W=W, lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
-    j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
-    j.run_adabelief(JOINT_PMC_ITERS, init_learning_rate=1e-4, schedule_learning_rate=False)
+    tag = [0]
+
+    def marked(fn):
+        tag[0] += 1
+        ctx.marker(tag[0])
+        fn()
+        ctx.synchronize()
+        tag[0] += 1
+        ctx.marker(tag[0])
+
+    for E, n, M in ((200, 64, 2), (25, 64, 2), (125, 128, 4)):
+        ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=104 if n == 64 else 105)
+        j = JointFit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], 2, M, ctx)
+        p = dict(ds['truth'])
+        p['a'] = p['a'] * 0.9
+        j.set_params(**p)
+        W = j.propagate_noise()
+        j.set_loss(W=W, lam_scales=1.0, lam_hf=1.0, lam_positivity=100.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
+        j.set_free(['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'])
+        ab = dict(init_learning_rate=1e-4, schedule_learning_rate=False)
+        j.run_adabelief(5, **ab)
+        marked(lambda: j.run_adabelief(PMC_ITERS, **ab))
+        j.close()
+    # C3 shard: the iterations of the pixel-grid stage are inside one launch
+    F, S, n, ss = 63, 8, 64, 2
+    ds = make_psf_dataset(F=F, S=S, n=n, ss=ss, seed=103)
+    weight = (ds['masks'] / ds['noisemap'].astype(np.float64) ** 2).astype(np.float32)
+    b = PsfBatch(ds['data'], weight, ss, ctx)
+    g = ds['fwhm_guess']
+    f0 = np.sqrt(np.maximum(g * g - (2.0 / ss) ** 2, 1.0))
+    b.set_moffat(np.stack([f0, f0, np.zeros(F), np.full(F, 2.5)], axis=-1))
+    stars = np.zeros((F, S, 4), np.float32)
+    stars[..., 0] = (ds['data'] * ds['masks']).sum(axis=(-1, -2))
+    b.set_stars(stars)
+    b.set_grid(None)
+    b.fit_moffat(30)
+    b.propagate_noise()
+    b.set_regularization(None, 1.0, 1.0)
+    ab = dict(init_learning_rate=1e-4, schedule_learning_rate=True)
+    b.run_adabelief(5, **ab)
+    marked(lambda: b.run_adabelief(PMC_ITERS, **ab))
+    b.close()
+    # star photometry batch
+    G, E, n = 30, 100, 32
+    base = make_roi_dataset(E=E, M=1, n=n, ss=2, seed=106, with_background=False)
+    sig2 = base['noisemap'].astype(np.float64) ** 2
+    sb = StarPhotometryBatch([(base['data'], sig2, base['psf'])] * G, 2, 1, ctx)
+    a0 = np.asarray(base['truth']['a'], np.float64) * 0.9
+    sb.set_params(a=np.tile(a0, G), c_x=np.zeros(G), c_y=np.zeros(G), dx=np.zeros(G * E), dy=np.zeros(G * E),
+                  alpha=np.zeros(G * E), mean=np.zeros(G * E))
+    sb.set_loss()
+    sb.set_free(['a', 'c_x', 'c_y', 'dx', 'dy'])
+    ab = dict(init_learning_rate=1e-3, schedule_learning_rate=True)
+    sb.run_adabelief(5, **ab)
+    marked(lambda: sb.run_adabelief(PMC_ITERS, **ab))
+    sb.close()
     ctx.synchronize()
-    j.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -391,7 +460,11 @@ def joint_workload(ctx, E, n, M, seed, iters, label):
             'roofline': hbm_roofline(E * bytes_per, it_s, 'one joint iteration: joint_epoch_kernel + reduction + update',
                                      {'algorithmic_bytes_per_cutout_iteration': bytes_per,
                                       'fp32_valu_tflops': E * flops_per / it_s / 1e12,
-                                      'fp32_valu_frac_of_157': E * flops_per / it_s / 1e12 / FP32_PEAK_TFLOPS}),
+                                      'fp32_valu_frac_of_157': E * flops_per / it_s / 1e12 / FP32_PEAK_TFLOPS,
+                                      # the executed-flop figure beside SURVEY's algorithmic one (the kernel transforms at
+                                      # L = 1.5 N with binned rows: joint_flops_executed_per_cutout_iteration)
+                                      'fp32_valu_tflops_executed': E * joint_flops_executed_per_cutout_iteration(n, ss) / it_s / 1e12,
+                                      'fp32_valu_frac_of_157_executed': E * joint_flops_executed_per_cutout_iteration(n, ss) / it_s / 1e12 / FP32_PEAK_TFLOPS}),
             'loss_finite': bool(np.all(np.isfinite(hist))), 'loss_first_last': [float(hist[0]), float(hist[-1])]}
 
 
@@ -552,7 +625,7 @@ def c3_shard_workload(ctx, iters=200):
     return {'workload': f'C3 shard: {F} frames x {S} stars, {n}x{n} stamps (1/8 of C3), {iters} AdaBelief iterations, one launch',
             'value': F * S * iters / (ms * 1e-3), 'unit': 'cutouts/sec', 'us_per_iteration': ms * 1e3 / iters,
             'roofline': hbm_roofline(F * S * iters * bytes_per, ms * 1e-3, 'psf_fit_kernel (N = 128)',
-                                     {'algorithmic_bytes_per_cutout_iteration': bytes_per,
+                                     {'algorithmic_bytes_per_cutout_iteration': bytes_per, 'iterations_per_figure': iters,
                                       'fp32_valu_frac_of_157': F * S * iters * 58.5 * N * N / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}),
             'loss_finite': bool(np.all(np.isfinite(hist)))}
 
@@ -639,7 +712,7 @@ def star_photometry_workload(ctx, iters=2000, with_cpu=True):
                        f'{iters} AdaBelief iterations',
            'value': G * E * iters / (ms * 1e-3), 'unit': 'cutouts/sec', 'us_per_iteration': ms * 1e3 / iters,
            'roofline': hbm_roofline(G * E * iters * bytes_per, ms * 1e-3, 'joint_ps_kernel + joint_update_groups_kernel',
-                                    {'algorithmic_bytes_per_cutout_iteration': bytes_per}),
+                                    {'algorithmic_bytes_per_cutout_iteration': bytes_per, 'iterations_per_figure': iters}),
            'loss_finite': bool(np.all(np.isfinite(hist)))}
     if with_cpu:
         try:
@@ -775,10 +848,10 @@ def main():
     ap.add_argument('--no-traffic', action='store_true', help='skip the rocprofv3 --pmc passes (roofline.traffic = null)')
     ap.add_argument('--no-sharded-joint', action='store_true', help='N > 1: skip the epoch-sharded C4 fit with RCCL')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--pmc-child-joint', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--pmc-child-sections', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
-    if args.pmc_child_joint:
-        joint_pmc_child(args.pmc_child_joint)
+    if args.pmc_child_sections:
+        pmc_sections_child()
         return
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -804,8 +877,7 @@ def main():
     if world == 1 and not args.no_traffic and not args.pmc_child and args.config == 'C2':
         traffic, traffic_source = measure_traffic()   # before this process touches the GPU
         if not args.no_extra:
-            for key, spec in (('C4', (200, 64, 2)), ('C5 shard', (125, 128, 4))):
-                joint_traffic[key] = measure_joint_traffic(*spec)
+            joint_traffic = measure_section_traffic()
 
     dist = None
     if world > 1:
@@ -908,12 +980,16 @@ def main():
                     extra.append(fn(ctx, **kw))
                 except Exception as e:
                     extra.append({'workload': kw.get('label', fn.__name__), 'error': repr(e)})
-            for w in extra:   # counter traffic of one iteration, measured before this process touched the GPU
-                for key, (tr, src) in joint_traffic.items():
-                    if w.get('workload', '').startswith(key + ':') or w.get('workload', '').startswith(key + ' ('):
-                        if 'roofline' in w and not (key == 'C4' and 'shard' in w['workload'][:10]):
-                            w['roofline']['traffic'] = tr
-                            w['roofline']['traffic_source'] = src
+            # counter traffic of one iteration (one launch-iteration of the C3 shard), measured before this process touched the GPU;
+            # per launch like `achieved`: the C3-shard and star-photometry entries time `iters` iterations in their figure
+            for w in extra:
+                label = w.get('workload', '')
+                key = next((k for k in sorted(joint_traffic, key=len, reverse=True) if label.startswith(k + ':') or label.startswith(k + ' (')), None)
+                if key is not None and 'roofline' in w:
+                    tr, src = joint_traffic[key]
+                    per_launch = w['roofline'].pop('iterations_per_figure', 1)
+                    w['roofline']['traffic'] = None if tr is None else tr * per_launch
+                    w['roofline']['traffic_source'] = src + (f' (x {per_launch} iterations of the timed figure)' if per_launch != 1 else '')
             if not args.no_cpu_baseline:   # the CPU path timed beside the joint fits too (north_star): C4 and the C5 shard
                 for idx, kw in ((0, dict(n=64, M=2, seed=104, seconds_target=8.0)), (2, dict(n=128, M=4, seed=105, seconds_target=6.0))):
                     try:

@@ -54,6 +54,10 @@ int lc_device_info(lc_ctx *ctx, char *name, int name_len, int *n_cu, int64_t *hb
 /* measured device copy bandwidth (read + write bytes / s) of a float4 grid-stride copy of `bytes` bytes, `reps`
  * launches: the box's own HBM figure that bench.py reports beside the 8 TB/s specification */
 int lc_copy_bandwidth(lc_ctx *ctx, int64_t bytes, int reps, float *gb_per_s);
+/* Measurement aid: synchronises the context's stream, launches `lc_marker_kernel` on a grid of `tag` (1 .. 65535) one-wave
+ * workgroups and synchronises again - a dispatch whose grid size identifies it in a rocprofv3 trace or counter CSV, so that
+ * the rows of a section (the iterations of one workload) can be cut out between two markers (bench.py, roofline.traffic). */
+int lc_ctx_marker(lc_ctx *ctx, int tag);
 
 /* ---- stamp pre-processing --------------------------------------------
  * One fused pass over K stamps of npix pixels, replacing the host-side NumPy of the reference:
@@ -251,8 +255,9 @@ int lc_joint_param_history_end(lc_joint *j);
  * G * M entries, star-major; a, dx, dy, mean follow the epochs), and every AdaBelief iteration is one kernel pair for all
  * stars (grid over (star, epoch), then one block per star for its reduction and update).  Each star's trajectory is bit
  * for bit that of lc_joint_create + lc_joint_run_adabelief on that star alone.  h and alpha stay fixed; no weight cube,
- * prior or point-source starlet term.  set/get_param, set_free, set_loss, run_adabelief, model, fisher_flux_sigma and
- * iterations_done work as on a plain object; the loss history is per star. */
+ * prior or point-source starlet term.  set/get_param, set_free, set_loss, run_adabelief, model, fisher_flux_sigma,
+ * deconvolved (epoch counted over the epochs of all stars; the positions of its star) and iterations_done work as on a
+ * plain object; the loss history is per star. */
 int lc_joint_create_groups(lc_ctx *ctx, int G, const int32_t *epochs_per_group, int M, int n, int ss, const float *data,
                            const float *sigma2, const float *psf, lc_joint **out);
 int lc_joint_get_group_loss_history(lc_joint *j, float *history /* [G][count_per_group] */, int count_per_group);

@@ -47,6 +47,7 @@ SIGNATURES = {
     'lc_ctx_destroy': (None, [vp]),
     'lc_last_error': (C.c_char_p, [vp]),
     'lc_copy_bandwidth': (C.c_int, [vp, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
+    'lc_ctx_marker': (C.c_int, [vp, C.c_int]),
     'lc_prepare_stamps': (C.c_int, [vp, C.c_int, C.c_int, fp, fp, fp, fp, fp, C.POINTER(C.c_uint8), C.c_float, C.c_float,
                                     C.c_int, fp, fp, fp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     'lc_ctx_stream': (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
@@ -207,6 +208,10 @@ class Context:
 
     def synchronize(self):
         self.check(self._l.lc_ctx_synchronize(self.h), 'lc_ctx_synchronize')
+
+    def marker(self, tag):
+        """A dispatch with grid size ``tag`` * 64 threads between two synchronisations: cuts a profiler trace into sections."""
+        self.check(self._l.lc_ctx_marker(self.h, int(tag)), 'lc_ctx_marker')
 
     def stream(self):
         """(hipStream_t as int, device ordinal) of this context."""

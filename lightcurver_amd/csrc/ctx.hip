@@ -110,6 +110,18 @@ int lc_batched_lbfgs(int nb, int D, double *x, const double *lo, const double *h
   return LC_OK;
 }
 
+// a dispatch a profiler trace can be cut at: `tag` workgroups of one wave that do nothing (the tag is the grid size of the row)
+__global__ void lc_marker_kernel(int tag) { (void)tag; }
+int lc_ctx_marker(lc_ctx *ctx, int tag) {
+  if (!ctx || tag < 1 || tag > 65535) return LC_ERR_INVALID;
+  LC_ENTER(ctx);
+  LC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipLaunchKernelGGL(lc_marker_kernel, dim3(tag), dim3(64), 0, ctx->stream, tag);
+  LC_HIP(ctx, hipGetLastError());
+  LC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LC_OK;
+}
+
 int lc_device_info(lc_ctx *ctx, char *name, int name_len, int *n_cu, int64_t *hbm_bytes) {
   if (!ctx) return LC_ERR_INVALID;
   hipDeviceProp_t prop;

@@ -1030,7 +1030,7 @@ static int joint_create_impl(lc_ctx *ctx, int E, int M, int n, int ss, const flo
   LC_HIP(ctx, hipEventCreateWithFlags(&j->evReg, hipEventDisableTiming));
   LC_HIP(ctx, hipEventCreateWithFlags(&j->evUpd, hipEventDisableTiming));
   LC_HIP(ctx, hipEventRecord(j->evUpd, ctx->stream));
-  TRY(dmalloc(j, &j->scene2, lean ? 1 : 2 * NN));
+  TRY(dmalloc(j, &j->scene2, 2 * NN));
   TRY(dmalloc(j, &j->prior, 4 * std::max(M, 1)));
   TRY(dmalloc(j, &j->a_ref, kMaxSources));
   TRY(ensure_hist(j, 64));
@@ -1529,10 +1529,16 @@ int lc_joint_model(lc_joint *j, float *model, float *chi2_per_epoch) {
 int lc_joint_deconvolved(lc_joint *j, int epoch, float *scene, float *background) {
   if (!j || epoch < 0 || epoch >= j->E) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
-  if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_deconvolved: not available on a batched star-photometry object");
   const size_t NN = (size_t)j->N * j->N;
+  // (a batched star-photometry object: `epoch` counts over the epochs of all stars; the positions are those of its star)
+  size_t coff = 0;
+  if (j->G > 0) {
+    int g = 0;
+    while (g + 1 < j->G && epoch >= j->gstart[g + 1]) ++g;
+    coff = (size_t)g * j->M;
+  }
   hipLaunchKernelGGL(joint_scene_kernel, dim3(64), dim3(256), 0, j->ctx->stream, j->N, j->ss, j->M, epoch, j->par[LC_P_A],
-                     j->par[LC_P_CX], j->par[LC_P_CY], j->par[LC_P_DX], j->par[LC_P_DY], j->par[LC_P_ALPHA],
+                     j->par[LC_P_CX] + coff, j->par[LC_P_CY] + coff, j->par[LC_P_DX], j->par[LC_P_DY], j->par[LC_P_ALPHA],
                      j->par[LC_P_H], j->scene2, j->scene2 + NN);
   LC_HIP(j->ctx, hipGetLastError());
   int rc;

@@ -100,23 +100,45 @@ def do_one_star_forward_modelling(data, noisemap, psf, subsampling_factor, n_ite
     }
 
 
-def do_many_stars_forward_modelling(stacks, subsampling_factor, n_iter=2000):
+def do_many_stars_forward_modelling(stacks, subsampling_factor, n_iter=2000, uniform_background_per_epoch=False,
+                                    starlet_global_background=False):
     """The reference's loop over its reference stars (star_photometry.py:257-326: ``do_one_star_forward_modelling`` once per
     star, each a 2000-iteration fit) as ONE batched device fit (``lightcurver_amd.joint.StarPhotometryBatch``,
     lc_joint_create_groups): every AdaBelief iteration advances all stars with one kernel pair instead of one pair per star.
 
     stacks: list of (data, noisemap, psf) per star - (E_g, n, n), (E_g, n, n), (E_g, N, N); the epoch counts may differ
-    (each star keeps its own frame selection).  data and noisemap are rescaled IN PLACE by nanmax(data), as the one-star
-    function does.  The configuration is the reference's default (``star_photometry_starlet_global_background: false``,
-    ``star_photometry_uniform_background_per_epoch: false``, config.yaml:254-258): fluxes, the star's position and the
-    per-epoch shifts free, no background.  Returns one dictionary per star with the keys of
-    ``do_one_star_forward_modelling``; each star's numbers are bit for bit those of its own one-star fit."""
+    (each star keeps its own frame selection), the stamp size may not.  data and noisemap are rescaled IN PLACE by
+    nanmax(data), as the one-star function does.  The two switches are the one-star function's (config.yaml:254-258
+    ``star_photometry_uniform_background_per_epoch`` / ``star_photometry_starlet_global_background``; NOTE the defaults here are
+    the pipeline's configuration, both off, whereas the one-star function's own default is ``starlet_global_background=True``):
+
+    * both off (the pipeline's default): fluxes, the star's position and the per-epoch shifts free, no background - batched;
+    * ``uniform_background_per_epoch=True``: the sky level of every epoch free as well - batched (one more per-epoch
+      parameter of the same update);
+    * ``starlet_global_background=True``: every star its own background grid with the starlet regulariser.  The batched object
+      carries no background work space (no spectra, no slabs: lc_joint_create_groups), so these fits run one star after the
+      other through ``do_one_star_forward_modelling`` - same numbers, no batching gain.
+
+    Returns one dictionary per star with ALL keys of ``do_one_star_forward_modelling`` (``deconvolved_image``: the scene of the
+    star's first epoch, ``starlet_background``: zeros when no background is fitted - what the reference's caller reads at
+    star_photometry.py:139-150); each star's numbers are bit for bit those of its own one-star fit."""
     from ..joint import StarPhotometryBatch, EmbeddedJointFit, joint_fit_size
     from ..starred.deconvolution.deconvolution import nest_kwargs
     ss = int(subsampling_factor)
+    if not stacks:
+        return []
+    shapes = {np.asarray(d).shape[1:] for d, _, _ in stacks}
+    n_user = int(np.asarray(stacks[0][0]).shape[-1])
+    if shapes != {(n_user, n_user)}:
+        raise ValueError(f'every star of a batch needs square stamps of ONE size, got {sorted(shapes)}')
+    for d, nm, p in stacks:
+        if np.asarray(nm).shape != np.asarray(d).shape or np.asarray(p).shape != (len(d), n_user * ss, n_user * ss):
+            raise ValueError('every star needs data, noisemap (E_g, n, n) and psf (E_g, n ss, n ss)')
+    if starlet_global_background:
+        return [do_one_star_forward_modelling(d, nm, p, ss, n_iter=n_iter, uniform_background_per_epoch=uniform_background_per_epoch,
+                                              starlet_global_background=True) for d, nm, p in stacks]
     # a stamp size without a kernel of its own: the stamps in the centre of the next instantiated size, no weight on the ring
     # (what joint.EmbeddedJointFit does for the one-star fit; no background here, so only the model has to be cut back)
-    n_user = int(np.asarray(stacks[0][0]).shape[-1])
     n_fit = joint_fit_size(n_user, ss)
     pad = (n_fit - n_user) // 2
 
@@ -142,13 +164,15 @@ def do_many_stars_forward_modelling(stacks, subsampling_factor, n_iter=2000):
         batch.set_params(a=np.concatenate(guesses), c_x=np.zeros(G), c_y=np.zeros(G), dx=np.zeros(E), dy=np.zeros(E),
                          alpha=np.zeros(E), h=np.zeros(N * N), mean=np.zeros(E))
         batch.set_loss(lam_scales=3.0, lam_hf=3.0)          # (constants with the background fixed at zero)
-        batch.set_free(['a', 'c_x', 'c_y', 'dx', 'dy'])
+        batch.set_free(['a', 'c_x', 'c_y', 'dx', 'dy'] + (['mean'] if uniform_background_per_epoch else []))
         batch.run_adabelief(int(n_iter), init_learning_rate=1e-3, schedule_learning_rate=True)
         final = batch.get_params()
         hist = batch.loss_history()
         model, _ = batch.model()
         model = model[:, pad:pad + n_user, pad:pad + n_user]
         sigma_a = batch.fisher_flux_sigma()
+        P, Nu = pad * ss, n_user * ss
+        scenes = [batch.deconvolved(int(batch.starts[g]))[0][P:P + Nu, P:P + Nu] for g in range(G)]
     finally:
         batch.close()
     out = []
@@ -169,5 +193,7 @@ def do_many_stars_forward_modelling(stacks, subsampling_factor, n_iter=2000):
             'chi2_per_frame': np.array(chi2_per_frame),
             'loss_curve': np.asarray(hist[g, 1:], dtype=np.float64).tolist(),
             'residuals': scale * residuals,
+            'deconvolved_image': scale * np.ascontiguousarray(scenes[g]),
+            'starlet_background': scale * np.zeros((n_user * ss, n_user * ss), np.float32),
         })
     return out
