@@ -11,6 +11,7 @@
 #include "joint_kernels.h"
 #include "joint_gm.h"
 #include "joint_reg_mfma.h"
+#include "joint_reg_rows.h"
 #include "joint_ps.h"
 #include "joint_noise.h"
 #include "joint_lbfgs.h"
@@ -52,6 +53,8 @@ struct MregKernels {
   int lds_fwd, lds_adj, nthr;
   mreg_mm_fn mm;  // batched tiled products of the second form of the chain (joint_reg_mfma.h)
   mreg_chain_fn chain;  // the whole second form as one launch (null: not built for this N)
+  void (*rows)(MregRowsArgs) = nullptr;  // third form: row blocks, two stages (joint_reg_rows.h; null: not built for this N)
+  int rows_lds = 0;
 };
 
 struct lc_joint {
@@ -88,6 +91,7 @@ struct lc_joint {
   float *mr_A = nullptr, *mr_AT = nullptr, *mr_C = nullptr, *mr_Z = nullptr, *mr_l1 = nullptr, *mr_pos = nullptr,
         *mr_part = nullptr, *mr_pbar = nullptr;
   float *mr_l1b = nullptr, *mr_posb = nullptr, *mr_S = nullptr, *mr_T = nullptr;  // second form of the chain: per-block values, S planes, product scratch
+  float *rr_Zp = nullptr;  // third form (row blocks): partial sub-gradient planes [N / 16 * kRrMaxParts][N^2]
   hipStream_t streamB = nullptr;      // the h regulariser runs here, concurrently with the epoch kernel
   hipEvent_t evReg = nullptr, evUpd = nullptr;
   const void *ps_attr_fn = nullptr;   // point-source kernel whose dynamic-LDS attribute has been set
@@ -536,6 +540,8 @@ template <int N>
 MregKernels make_mreg_chain() {
   MregKernels k = make_mreg<N>();
   k.chain = mreg_chain_kernel<N>;
+  k.rows = mreg_rows_kernel<N>;
+  k.rows_lds = RrCfg<N>::LDS_BYTES;
   return k;
 }
 const MregKernels *find_mreg(int N) {
@@ -603,8 +609,62 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
       hipLaunchKernelGGL(mreg_pbar_kernel, dim3(nb), dim3(kGmThreads), 0, stream, N, j->ss, j->E, j->M, j->par[LC_P_A],
                          j->par[LC_P_CX], j->par[LC_P_CY], j->mr_pbar);
   };
+  // Third form (LCMI_REG_ROWS=1; N = 128): the regulariser cut by ROWS - one launch does forward products, S rows and adjoint
+  // products of a row block for a group of scales, a second adds the partial planes and the values; the point-source term as
+  // tiles in a launch of its own in front.  Three launches for the eight of the batched-product form (joint_reg_rows.h).
+  // Correct (tests/test_joint_paths_gpu.py: against the cascade and the second form) and NOT the default: measured on MI355X
+  // (profiles/r04_rows_*) its row kernel takes 45 us (35 us with a rolled product loop), the chain 57 - 63 us against ~60 us
+  // for the eight launches - a workgroup's 18 dependent 16-row products cost ~5 k cycles each, of which ~2.5 k remain with the
+  // operand loads and the matrix products switched off (LCMI_REG_ROWS_DBG=7): a few hundred instructions per product issued
+  // by two waves per SIMD, not memory and not the matrix pipe.  C4 83.9 against 71.1 us per iteration, its 25-epoch shard 76.8
+  // against 65.0.
+  // (its completion signal is a counter - every block of the last launch adds one - so only the flag-reading update of the
+  //  device loop and the event-waiting forms can follow it: both read reg_flag / wait for the stream)
+  {
+    const char *rr_env = std::getenv("LCMI_REG_ROWS");
+    if (k->rows && j->rr_Zp && l1_on && J == 7 && rr_env && std::atoi(rr_env) != 0 && !std::getenv("LCMI_REG_MFMA_V1")) {
+      // scale groups per row block, of about equal cost (the products of a scale cover its band: the first scales are cheap);
+      // at most kRrBatch scales each: three groups {1 .. 4}, {5, 6}, {7} (default) or two {1 .. 4}, {5 .. 7}
+      int nparts = 3;
+      if (const char *pe = std::getenv("LCMI_REG_ROWS_PARTS")) nparts = std::min(std::max(2, std::atoi(pe)), kRrMaxParts);
+      MregRowsArgs Q;
+      std::memset(&Q, 0, sizeof(Q));
+      Q.J = J;
+      Q.nparts = nparts;
+      const int lo3[3] = {1, 5, 7}, hi3[3] = {4, 6, 7}, lo2[2] = {1, 5}, hi2[2] = {4, 7};
+      for (int p = 0; p < nparts; ++p) {
+        Q.s_lo[p] = (nparts == 3) ? lo3[p] : lo2[p];
+        Q.s_hi[p] = (nparts == 3) ? hi3[p] : hi2[p];
+      }
+      Q.A = j->mr_A;
+      Q.AT = j->mr_AT;
+      Q.X = j->par[LC_P_H];
+      Q.W = j->have_W ? j->W : nullptr;
+      Q.norms = j->norms;
+      Q.lam_sc = j->cfg.lam_scales;
+      Q.lam_hf = j->cfg.lam_hf;
+      Q.lam_pos = j->cfg.lam_positivity;
+      Q.Zp = j->rr_Zp;
+      Q.S0 = j->mr_S;
+      Q.vals = j->mr_l1b;
+      if (const char *dg = std::getenv("LCMI_REG_ROWS_DBG")) Q.dbg = std::atoi(dg);
+      const int tiles = (N / kPtT) * (N / kPtT), nwg = (N / kRrRows) * nparts;
+      if (with_pts)
+        hipLaunchKernelGGL(gm_pts_direct_kernel, dim3(tiles), dim3(kGmThreads), 0, stream, N, j->ss, j->M, j->a_ref, (const float *)nullptr,
+                           j->par[LC_P_CX], j->par[LC_P_CY], Q.W, j->norms, j->cfg.lam_pts_source, j->mr_part, j->mr_posb,
+                           (const float *)j->par[LC_P_A], j->E);
+      LC_HIP(j->ctx, hipFuncSetAttribute((const void *)k->rows, hipFuncAttributeMaxDynamicSharedMemorySize, k->rows_lds));
+      hipLaunchKernelGGL(k->rows, dim3(nwg), dim3(kRrThreads), k->rows_lds, stream, Q);
+      const int nfin = NN / kGmThreads + 1;
+      j->reg_seq += (unsigned int)nfin;
+      hipLaunchKernelGGL(mreg_rows_finish_kernel, dim3(nfin), dim3(kGmThreads), 0, stream, NN, nwg, j->rr_Zp, j->mr_S, j->greg,
+                         j->mr_l1b, with_pts ? 1 : 0, tiles, j->M, j->mr_part, j->mr_posb, j->regs, j->reg_flag);
+      LC_HIP(j->ctx, hipGetLastError());
+      return LC_OK;
+    }
+  }
   if (!std::getenv("LCMI_REG_MFMA_V1")) {
-    // second form (default): batched tiled products over the scales, telescoped adjoint
+    // second form: batched tiled products over the scales, telescoped adjoint
     const size_t NNs = (size_t)NN;
     auto At = [&](int s) { return j->mr_AT + (size_t)s * NNs; };
     auto Ap = [&](int s) { return j->mr_A + (size_t)s * NNs; };
@@ -1021,6 +1081,7 @@ static int joint_create_impl(lc_ctx *ctx, int E, int M, int n, int ss, const flo
     TRY(dmalloc(j, &j->mr_pos, nb));
     TRY(dmalloc(j, &j->mr_part, nb * 3 * kMaxSources));
     TRY(dmalloc(j, &j->mr_pbar, NN));
+    if (j->mreg->rows) TRY(dmalloc(j, &j->rr_Zp, (size_t)(N / kRrRows) * kRrMaxParts * NN));
     TRY(dmalloc(j, &j->reg_flag, 4));  // [0] completion flag, [1] a wait ran out, [2] ticket of the finishing launch
     LC_HIP(ctx, hipFuncSetAttribute((const void *)j->mreg->fwd, hipFuncAttributeMaxDynamicSharedMemorySize, j->mreg->lds_fwd));
     LC_HIP(ctx, hipFuncSetAttribute((const void *)j->mreg->adj, hipFuncAttributeMaxDynamicSharedMemorySize, j->mreg->lds_adj));
@@ -2121,6 +2182,9 @@ int lc_joint_fisher_flux_sigma(lc_joint *j, float *sigma_a) {
 #ifdef LC_STAMPS
 int lc_debug_get_jstamps(long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::g_jstamps), 32 * sizeof(long long)) == hipSuccess ? 0 : -2;
+}
+int lc_debug_get_rstamps(long long *out) {  // (the row-block regulariser kernel: tools/rows_stamps.py)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::g_rstamps), 16 * sizeof(long long)) == hipSuccess ? 0 : -2;
 }
 int lc_debug_get_ustamps(long long *out) {  // (the fused reduction + update launch: tools/update_stamps.py)
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(lc::g_ustamps), 16 * sizeof(long long)) == hipSuccess ? 0 : -2;

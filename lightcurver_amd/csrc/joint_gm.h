@@ -201,9 +201,12 @@ __global__ void gm_pts_inner_kernel(int N, int ss, int M, const float *q, const 
 // 0..2 / N-3..N-1 of q are inside the halo of the tiles that need them) and the inner products of gm_pts_inner_kernel.
 // part / l1_part per tile in the layout gm_pts_final_kernel sums ((N / 16)^2 tiles = N^2 / 256 blocks).
 constexpr int kPtT = 16;
+// (shared == null: the mean fluxes are taken from the fluxes themselves, a [E][M] - one GPU, all epochs local; summed as
+//  mreg_pbar_kernel sums them)
 __global__ __launch_bounds__(kGmThreads) void gm_pts_direct_kernel(int N, int ss, int M, const float *a_ref, const float *shared,
                                                                     const float *cx, const float *cy, const float *W0,
-                                                                    const float *norm, float lam, float *part, float *l1_part) {
+                                                                    const float *norm, float lam, float *part, float *l1_part,
+                                                                    const float *a = nullptr, int E = 0) {
   constexpr int T = kPtT, H4 = T + 8, H2 = T + 4;
   __shared__ float P[H4][H4 + 1], R1[H4][H2 + 1], Q[H2][H2 + 1], TA[T][H2 + 1];
   __shared__ float AB[kMaxSources], CX[kMaxSources], CY[kMaxSources];
@@ -211,8 +214,17 @@ __global__ __launch_bounds__(kGmThreads) void gm_pts_direct_kernel(int N, int ss
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, NN = N * N;
   const int tiles = N / T, tu0 = (blockIdx.x / tiles) * T, tv0 = (blockIdx.x % tiles) * T;
   const float c0 = (N - 1) * 0.5f, inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm2 = 0.15915494309189535f * inv_s2;
+  if (shared) {
+    if (tid < M) AB[tid] = a_ref[tid] + shared[NN + 2 * M + tid] / shared[NN + 4 * M + 1];
+  } else {
+    for (int i = wid; i < M; i += kGmThreads / 64) {
+      float acc = 0.f;
+      for (int e = lane; e < E; e += 64) acc += a[e * M + i];
+      acc = wave_sum_shfl(acc);
+      if (lane == 0) AB[i] = acc / (float)E;
+    }
+  }
   if (tid < M) {
-    AB[tid] = a_ref[tid] + shared[NN + 2 * M + tid] / shared[NN + 4 * M + 1];
     CX[tid] = c0 + ss * cx[tid];
     CY[tid] = c0 + ss * cy[tid];
   }

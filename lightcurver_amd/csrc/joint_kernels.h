@@ -19,6 +19,7 @@ constexpr int kMaxSources = 8;
 #ifdef LC_STAMPS
 __device__ long long g_jstamps[32];
 __device__ long long g_ustamps[16];
+__device__ long long g_rstamps[16];
 #define LC_JSTAMP(k)                                                \
   do {                                                              \
     if (blockIdx.x == 0 && threadIdx.x == 0) g_jstamps[k] = clock64(); \

@@ -172,6 +172,21 @@ def test_stencil_in_the_reduction_equals_the_slab_form(ctx, E, parts):
     _compare(a, b, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 12, 1e-4)
 
 
+@pytest.mark.parametrize('parts', ['2', '3'])
+def test_row_block_regulariser_equals_the_batched_products(ctx, parts):
+    """The regulariser of the 128 x 128 grid cut by rows (csrc/joint_reg_rows.h, LCMI_REG_ROWS=1: forward products, S rows and
+    adjoint products of a row block in ONE workgroup, 16 x 16 x 4 fp32 MFMA tiles with a permuted k order; the point-source
+    term as tiles) against the batched-product chain (the default) and against the cascade: same mathematics, other
+    summation orders."""
+    ds = make_roi_dataset(E=8, M=2, n=64, ss=2, seed=104)
+    a = _fit(ctx, ds, 2, 25)
+    b = _fit(ctx, ds, 2, 25, env={'LCMI_REG_ROWS': '1', 'LCMI_REG_ROWS_PARTS': parts})
+    c = _fit(ctx, ds, 2, 25, env={'LCMI_REG_CASCADE': '1'})
+    _compare(b, a, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 25, 1e-4)
+    _compare(b, c, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 25, 1e-4)
+    assert b[0][-1] < b[0][0]
+
+
 @pytest.mark.parametrize('parts', ['2', '4'])
 def test_epoch_spread_over_workgroups_equals_the_one_workgroup_kernel(ctx, parts):
     """128 x 128 ROIs with fewer epochs than CUs: the six phases of an epoch become six launches on a grid
