@@ -602,17 +602,49 @@ __device__ __forceinline__ void starlet_l1_grad_dpp(const float img[PX], const f
   }
   // transposes: row-major -> column-major through bufA, back through bufB (one barrier each: a buffer is rewritten
   // only after a barrier that every reader of its previous contents has passed)
+  // Bank swizzle (64 x 64, 8 samples per thread): a row-major access puts lanes t % 8 = a at columns 8 a + p - banks 8 a + row,
+  // so a and a + 4 collide - and a column-major one lanes a at rows 8 a + p - 65 * 8 a = 8 a (mod 32): the same collision.
+  // Every LDS access of the 24 transposes of an iteration was a 2-way conflict (SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS
+  // = 0.97, profiles/r03_psf_sq_wave_time.txt).  Element (r, c) therefore sits at column c ^ 4 ((c >> 5) ^ (r >> 5)): the
+  // upper half of the columns and the lower half of the rows shift by four banks - conflict-free in both directions (the
+  // flip stays inside a thread's eight samples: same values in the same registers, only their LDS addresses differ).
+  // The flip is the same for all eight samples of a thread (its columns share c >> 5, its rows r >> 5), so it costs no
+  // per-element address arithmetic: a row-major thread swaps the two halves of its eight columns - two base addresses,
+  // immediate offsets as before - and a column-major thread moves its one column by four.  (Computed per element, the flip
+  // took the immediate offsets away: 20.0 against 14.8 us per iteration.)
+  // MEASURED AND NOT KEPT (built with -DLC_STARLET_SWZ only): A / B on one MI355X, same run - 100 frames in the two-workgroup
+  // form 14.9 us per iteration with the swizzle against 15.0 without (the convolution role is the longer of the two: a faster
+  // starlet does not show), 256 frames in the one-workgroup form 28.0 - 28.2 against 26.4 - 26.6, 100 frames one workgroup each
+  // 26.1 against 25.0: the 2-way conflicts of the transposes are NOT what the starlet waits for (its 16 LDS instructions per
+  // transpose sit between register passes of ~300 vector instructions), and the second base address costs registers.
+#ifdef LC_STARLET_SWZ   // (A / B build: make alt ALTFLAGS=-DLC_STARLET_SWZ)
+  constexpr bool SWZ = (N == 64 && PX == 8);
+#else
+  constexpr bool SWZ = false;
+#endif
+  auto row_bases = [&](int pu, int pv, int &lo, int &hi) {   // samples p < 4 at lo + p, samples p >= 4 at hi + p
+    const int k4 = SWZ ? ((((pv >> 5) ^ (pu >> 5)) & 1) << 2) : 0;
+    lo = pu * TS + pv + k4;
+    hi = pu * TS + pv - k4;
+  };
+  auto col_base = [&](int cu0, int cv) {                      // sample p at base + p * TS
+    const int k4 = SWZ ? ((((cv >> 5) ^ (cu0 >> 5)) & 1) << 2) : 0;
+    return cu0 * TS + (cv ^ k4);
+  };
   auto to_columns = [&](const float (&v)[PX], float (&o)[PX]) {
     int pu = pu_, pv = pv_, cu0 = cu0_, cv = cv_;
     LC_LAUNDER(pu);
     LC_LAUNDER(pv);
     LC_LAUNDER(cu0);
     LC_LAUNDER(cv);
+    int lo, hi;
+    row_bases(pu, pv, lo, hi);
+    const int cb = col_base(cu0, cv);
 #pragma unroll
-    for (int p = 0; p < PX; ++p) bufA[pu * TS + pv + p] = v[p];
+    for (int p = 0; p < PX; ++p) bufA[((SWZ && p >= 4) ? hi : lo) + p] = v[p];
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < PX; ++p) o[p] = bufA[(cu0 + p) * TS + cv];
+    for (int p = 0; p < PX; ++p) o[p] = bufA[cb + p * TS];
   };
   auto to_rows = [&](const float (&v)[PX], float (&o)[PX]) {
     int pu = pu_, pv = pv_, cu0 = cu0_, cv = cv_;
@@ -620,11 +652,14 @@ __device__ __forceinline__ void starlet_l1_grad_dpp(const float img[PX], const f
     LC_LAUNDER(pv);
     LC_LAUNDER(cu0);
     LC_LAUNDER(cv);
+    int lo, hi;
+    row_bases(pu, pv, lo, hi);
+    const int cb = col_base(cu0, cv);
 #pragma unroll
-    for (int p = 0; p < PX; ++p) bufB[(cu0 + p) * TS + cv] = v[p];
+    for (int p = 0; p < PX; ++p) bufB[cb + p * TS] = v[p];
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < PX; ++p) o[p] = bufB[pu * TS + pv + p];
+    for (int p = 0; p < PX; ++p) o[p] = bufB[((SWZ && p >= 4) ? hi : lo) + p];
   };
   static_for(std::make_integer_sequence<int, J>{}, [&](auto jc) {
     constexpr int j = decltype(jc)::value, d = 1 << j;
