@@ -93,6 +93,8 @@ struct lc_joint {
   float *mr_l1b = nullptr, *mr_posb = nullptr, *mr_S = nullptr, *mr_T = nullptr;  // second form of the chain: per-block values, S planes, product scratch
   float *rr_Zp = nullptr;  // third form (row blocks): partial sub-gradient planes [N / 16 * kRrMaxParts][N^2]
   hipStream_t streamB = nullptr;      // the h regulariser runs here, concurrently with the epoch kernel
+  hipStream_t streamC = nullptr;      // ... and the point-source starlet term here, beside the regulariser chain (created on first use)
+  hipEvent_t evPts = nullptr;
   hipEvent_t evReg = nullptr, evUpd = nullptr;
   const void *ps_attr_fn = nullptr;   // point-source kernel whose dynamic-LDS attribute has been set
   std::vector<hipStream_t> gstreams;  // batched star photometry: the parts of the batch beyond the first run on these
@@ -668,6 +670,28 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
     const size_t NNs = (size_t)NN;
     auto At = [&](int s) { return j->mr_AT + (size_t)s * NNs; };
     auto Ap = [&](int s) { return j->mr_A + (size_t)s * NNs; };
+    // LCMI_PTS_SIDE=1: the point-source starlet term (scale 0 only) beside the chain instead of inside it - as tiles in ONE
+    // launch (gm_pts_direct_kernel, joint_gm.h; mean fluxes from the fluxes themselves) on a third stream, joined in front of
+    // the sums; inside the chain it is a launch of its own for Pbar plus one more product in each of the four batches.  Equal
+    // to the batched form to fp32 rounding (tests/test_joint_paths_gpu.py).  Built to take the Pbar launch off a chain that
+    // ends just after the epoch kernel; measured SLOWER and not the default: C4 81.0 against 70.9 us per iteration, its
+    // 25-epoch shard 66.4 / 64.4, the C5 shard 235.5 / 230.7 - the third stream's fork and join (two more cross-stream event
+    // waits per iteration, a third hardware queue) cost more than the launch they remove.
+    const char *ps_env = std::getenv("LCMI_PTS_SIDE");
+    const bool pts_side = with_pts && stream == j->streamB && N % kPtT == 0 && ps_env && std::atoi(ps_env) != 0 && !std::getenv("LCMI_REG_CHAIN");
+    if (pts_side) {
+      if (!j->streamC) {
+        LC_HIP(j->ctx, hipStreamCreate(&j->streamC));
+        LC_HIP(j->ctx, hipEventCreateWithFlags(&j->evPts, hipEventDisableTiming));
+      }
+      LC_HIP(j->ctx, hipStreamWaitEvent(j->streamC, j->evUpd, 0));   // (what the chain's own stream waited for)
+      const int tiles = (N / kPtT) * (N / kPtT);
+      hipLaunchKernelGGL(gm_pts_direct_kernel, dim3(tiles), dim3(kGmThreads), 0, j->streamC, N, j->ss, j->M, j->a_ref, (const float *)nullptr,
+                         j->par[LC_P_CX], j->par[LC_P_CY], j->have_W ? j->W : nullptr, j->norms, j->cfg.lam_pts_source, j->mr_part,
+                         j->mr_l1b + (size_t)(J + 1) * nb, (const float *)j->par[LC_P_A], j->E);
+      LC_HIP(j->ctx, hipEventRecord(j->evPts, j->streamC));
+    }
+    const bool pts_batch = with_pts && !pts_side;
     MmBatch f1, f2, a1, a2;
     std::memset(&f1, 0, sizeof(f1));
     f2 = a1 = a2 = f1;
@@ -688,7 +712,7 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
     };
     if (l1_on)
       for (int s = 1; s <= J; ++s) add(s, j->par[LC_P_H], j->mr_C + (size_t)s * NNs, j->mr_S + (size_t)s * NNs, j->mr_Z + (size_t)s * NNs);
-    if (with_pts) add(1, j->mr_pbar, j->mr_C + (size_t)(J + 1) * NNs, j->mr_S + (size_t)(J + 1) * NNs, j->mr_Z + (size_t)(J + 1) * NNs);
+    if (pts_batch) add(1, j->mr_pbar, j->mr_C + (size_t)(J + 1) * NNs, j->mr_S + (size_t)(J + 1) * NNs, j->mr_Z + (size_t)(J + 1) * NNs);
     f1.nb = f2.nb = a1.nb = a2.nb = nbch;
     // The whole chain as ONE launch (mreg_chain_kernel; LCMI_REG_CHAIN=1) where its kChainBlocks workgroups are resident beside
     // the epoch kernel's.  Same stages, same bits (tests/test_joint_cluster_gpu.py).  Built on the premise that the eight
@@ -731,7 +755,7 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
       return LC_OK;
     }
     const dim3 mgrid(N / 64, N / 64, nbch), mblock(kMmThreads);
-    launch_pbar();
+    if (pts_batch) launch_pbar();
     if (nbch > 0) {
       hipLaunchKernelGGL(k->mm, mgrid, mblock, 0, stream, f1);
       hipLaunchKernelGGL(k->mm, mgrid, mblock, 0, stream, f2);
@@ -744,13 +768,16 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
     G.S = j->mr_S;
     G.l1b = j->mr_l1b;
     G.posb = j->mr_posb;
-    const int sslots = (l1_on ? J + 1 : 1) + (with_pts ? 1 : 0);  // slot 0 always: it carries the positivity term
+    G.B.has_pts = pts_batch ? 1 : 0;
+    const int sslots = (l1_on ? J + 1 : 1) + (pts_batch ? 1 : 0);  // slot 0 always: it carries the positivity term
     hipLaunchKernelGGL(mreg_splanes_kernel, dim3(nb, sslots), dim3(kGmThreads), 0, stream, G, NN);
     if (nbch > 0) {
       hipLaunchKernelGGL(k->mm, mgrid, mblock, 0, stream, a1);
       hipLaunchKernelGGL(k->mm, mgrid, mblock, 0, stream, a2);
     }
-    hipLaunchKernelGGL(mreg_finish2_kernel, dim3(nb), dim3(kGmThreads), 0, stream, N, J, l1_on ? 1 : 0, with_pts ? 1 : 0, j->ss, j->M,
+    // (the tiles of the point-source term, on the third stream, are joined here: the sums below read their partials)
+    if (pts_side) LC_HIP(j->ctx, hipStreamWaitEvent(stream, j->evPts, 0));
+    hipLaunchKernelGGL(mreg_finish2_kernel, dim3(nb), dim3(kGmThreads), 0, stream, N, J, l1_on ? 1 : 0, pts_batch ? 1 : 0, j->ss, j->M,
                        j->mr_S, j->mr_Z, j->par[LC_P_CX], j->par[LC_P_CY], j->greg, j->mr_part);
     j->reg_seq += 1;
     hipLaunchKernelGGL(mreg_regs2_kernel, dim3(1), dim3(64), 0, stream, J, l1_on ? 1 : 0, with_pts ? 1 : 0, nb, j->M, j->mr_l1b,
@@ -1173,6 +1200,11 @@ void lc_joint_destroy(lc_joint *j) {
     hipStreamSynchronize(j->streamB);
     hipStreamDestroy(j->streamB);
   }
+  if (j->streamC) {
+    hipStreamSynchronize(j->streamC);
+    hipStreamDestroy(j->streamC);
+  }
+  if (j->evPts) hipEventDestroy(j->evPts);
   for (hipStream_t st : j->gstreams) {
     hipStreamSynchronize(st);
     hipStreamDestroy(st);

@@ -172,6 +172,17 @@ def test_stencil_in_the_reduction_equals_the_slab_form(ctx, E, parts):
     _compare(a, b, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 12, 1e-4)
 
 
+@pytest.mark.parametrize('E,n,M', [(8, 64, 2), (3, 128, 4)])
+def test_point_source_term_beside_the_chain_equals_the_batched_form(ctx, E, n, M):
+    """The point-source starlet term as tiles in one launch on a third stream beside the regulariser chain (LCMI_PTS_SIDE=1;
+    measured slower, opt-in) against the same term as one more product in each batch of the chain (default): other summation
+    order of the scale-0 stencil, same numbers to fp32 rounding."""
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=104)
+    a = _fit(ctx, ds, M, 25, env={'LCMI_PTS_SIDE': '1'})
+    b = _fit(ctx, ds, M, 25)
+    _compare(a, b, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 25, 1e-4)
+
+
 @pytest.mark.parametrize('parts', ['2', '3'])
 def test_row_block_regulariser_equals_the_batched_products(ctx, parts):
     """The regulariser of the 128 x 128 grid cut by rows (csrc/joint_reg_rows.h, LCMI_REG_ROWS=1: forward products, S rows and
