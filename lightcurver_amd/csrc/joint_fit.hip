@@ -11,6 +11,7 @@
 #include "joint_kernels.h"
 #include "joint_gm.h"
 #include "joint_reg_mfma.h"
+#include "joint_reg_fused.h"
 #include "joint_reg_rows.h"
 #include "joint_ps.h"
 #include "joint_noise.h"
@@ -55,6 +56,7 @@ struct MregKernels {
   mreg_chain_fn chain;  // the whole second form as one launch (null: not built for this N)
   void (*rows)(MregRowsArgs) = nullptr;  // third form: row blocks, two stages (joint_reg_rows.h; null: not built for this N)
   int rows_lds = 0;
+  void (*mmx[4])(MmxArgs) = {nullptr, nullptr, nullptr, nullptr};  // fourth form (default): f1', a1', a2' and the plain product of joint_reg_fused.h
 };
 
 struct lc_joint {
@@ -105,6 +107,12 @@ struct lc_joint {
   unsigned int *reg_flag = nullptr;  // [0] sequence number of the last finished regulariser chain, [1] a flag wait ran out
   unsigned int reg_seq = 0;
   bool flag_sync = false;            // this iteration's update checks reg_flag itself instead of waiting for evReg
+  // four-launch chain (joint_reg_fused.h): planes_pred = the consumer of this iteration's chain will be the fused reduction +
+  // update, which adds the planes itself (set by lc_joint_step_local before the chain is enqueued); reg_planes = this
+  // iteration's chain left planes and per-tile values only (no greg / regs yet); reg_noflag = it wrote greg / regs but raises
+  // no completion flag (its consumer waits for the event)
+  bool planes_pred = false, reg_planes = false, reg_noflag = false;
+  RegPlanes planes;
   bool fuse_full = false;  // lc_joint_run_adabelief, background free: reduction over the epochs and update in one launch
   bool fuse_stencil = false;  // ... and the T_e^T step too: no phase D, no slabs (global-spectrum kernels, translated epochs)
   bool any_rotation = false;  // some alpha != 0
@@ -535,8 +543,13 @@ int launch_reg_gm(lc_joint *j, hipStream_t stream, bool with_pts, bool abar_from
 
 template <int N>
 MregKernels make_mreg() {
-  return MregKernels{N, mreg_forward_kernel<N>, mreg_adjoint_kernel<N>, MregCfg<N>::LDS_FWD, MregCfg<N>::LDS_ADJ, MregCfg<N>::NTHR,
-                     mreg_mm_kernel<N>, nullptr};
+  MregKernels k{N, mreg_forward_kernel<N>, mreg_adjoint_kernel<N>, MregCfg<N>::LDS_FWD, MregCfg<N>::LDS_ADJ, MregCfg<N>::NTHR,
+                mreg_mm_kernel<N>, nullptr};
+  k.mmx[0] = mreg_mmx_kernel<N, 0>;
+  k.mmx[1] = mreg_mmx_kernel<N, 1>;
+  k.mmx[2] = mreg_mmx_kernel<N, 2>;
+  k.mmx[3] = mreg_mmx_kernel<N, 3>;
+  return k;
 }
 template <int N>
 MregKernels make_mreg_chain() {
@@ -720,8 +733,54 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
     // are not: the one launch takes 59.4 us per iteration (profiles/r04_cluster_*) - every stage boundary is a hand-off
     // between CUs (write-through stores, drain, flag, L1-bypassing loads from the memory side), 5 - 7 us whether a launch
     // boundary or an in-kernel sync delivers it.  NOT the default; what shortens the chain is fewer stages, not cheaper ones.
-    const int epoch_wgs = j->E * std::max(1, cluster_parts(j));
     const char *rc_env = std::getenv("LCMI_REG_CHAIN");
+    // Fourth form (default; LCMI_REG_FUSED=0: the eight launches below): the element-wise launches folded into the products
+    // (joint_reg_fused.h) - f1' (Pbar in the operand fetch), f2, a1' (S planes in the operand fetch, values per tile),
+    // a2' (point-source inner products in the epilogue, completion counter); the fused reduction + update adds the planes, any
+    // other consumer gets greg / regs from one more launch.
+    {
+      const char *fu_env = std::getenv("LCMI_REG_FUSED");
+      const bool chain_one = rc_env && std::atoi(rc_env) != 0;
+      if (k->mmx[0] && l1_on && nbch > 0 && J <= kPlanesMaxJ && J + 1 <= 12 && !pts_side && !chain_one && !(fu_env && std::atoi(fu_env) == 0)) {
+        MmxArgs Q;
+        std::memset(&Q, 0, sizeof(Q));
+        for (int b = 0; b < nbch; ++b) Q.scale[b] = (pts_batch && b == nbch - 1) ? -1 : b + 1;
+        Q.J = J;
+        Q.ntile = (N / 64) * (N / 64);
+        Q.E = j->E; Q.M = j->M; Q.ss = j->ss;
+        Q.a = j->par[LC_P_A]; Q.cx = j->par[LC_P_CX]; Q.cy = j->par[LC_P_CY];
+        Q.pbar = j->mr_pbar;
+        Q.X = j->par[LC_P_H]; Q.C = j->mr_C; Q.W = j->have_W ? j->W : nullptr; Q.norms = j->norms;
+        Q.lam_sc = j->cfg.lam_scales; Q.lam_hf = j->cfg.lam_hf; Q.lam_pts = j->cfg.lam_pts_source; Q.lam_pos = j->cfg.lam_positivity;
+        Q.S = j->mr_S;
+        Q.vals = j->mr_l1b;
+        Q.pts_part = j->mr_part;
+        const dim3 mgrid(N / 64, N / 64, nbch), mblock(kMmThreads);
+        Q.mm = f1;
+        hipLaunchKernelGGL(k->mmx[0], mgrid, mblock, 0, stream, Q);
+        Q.mm = f2;
+        hipLaunchKernelGGL(k->mmx[3], mgrid, mblock, 0, stream, Q);   // (the plain product, without mreg_mm_kernel's 48 bytes of scratch per lane)
+        Q.mm = a1;
+        hipLaunchKernelGGL(k->mmx[1], mgrid, mblock, 0, stream, Q);
+        Q.mm = a2;
+        const bool planes = j->planes_pred && j->reg_flag;
+        Q.done = planes ? j->reg_flag : nullptr;
+        hipLaunchKernelGGL(k->mmx[2], mgrid, mblock, 0, stream, Q);
+        RegPlanes &P = j->planes;
+        P.on = 1; P.J = J; P.ntile = Q.ntile; P.has_pts = pts_batch ? 1 : 0;
+        P.S0 = j->mr_S; P.Z = j->mr_Z; P.vals = j->mr_l1b; P.pts_part = j->mr_part;
+        if (planes) {
+          j->reg_seq += (unsigned int)(mgrid.x * mgrid.y * mgrid.z);
+          j->reg_planes = true;
+        } else {
+          hipLaunchKernelGGL(mreg_finish3_kernel, dim3(nb + 1), dim3(kGmThreads), 0, stream, NN, nb, j->M, P, j->greg, j->regs);
+          j->reg_noflag = true;
+        }
+        LC_HIP(j->ctx, hipGetLastError());
+        return LC_OK;
+      }
+    }
+    const int epoch_wgs = j->E * std::max(1, cluster_parts(j));
     if (k->chain && j->chain_flags && j->reg_flag && !j->chain_off && epoch_wgs + kChainBlocks <= j->ctx->n_cu && rc_env && std::atoi(rc_env) != 0) {
       MregChainArgs Q;
       std::memset(&Q, 0, sizeof(Q));
@@ -890,6 +949,7 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
         A.wait_seq = j->reg_seq;
         A.wait_err = j->reg_flag + 1;
       }
+      if (j->reg_planes && reg_mode == 2 && !j->fuse_stencil) A.planes = j->planes;
       A.g_cx_e = j->g_cx_e;
       A.g_cy_e = j->g_cy_e;
       A.chi2_e = j->chi2_e;
@@ -1430,6 +1490,16 @@ int lc_joint_step_local(lc_joint *j) {
   // inside lc_joint_run_adabelief (one GPU: the mean fluxes are all local) the point-source starlet term, which depends
   // on the current a, c_x, c_y only, is evaluated with the background regulariser on the second stream
   j->pts_pending = j->in_device_loop && j->cfg.lam_pts_source != 0.f && j->M > 0;
+  j->reg_planes = j->reg_noflag = false;
+  {
+    // will the fused reduction + update consume this iteration's chain (the conditions of fuse_full / fuse_stencil below, as far
+    // as they are known before the epoch launch)?  Then the chain leaves its planes for that kernel to add; a wrong guess is
+    // repaired in lc_joint_step_update (one more launch), never wrong numbers
+    const bool gm_upd = !j->v->uk || (j->cfg.lam_pts_source == 0.f || j->pts_pending);
+    const bool stencil = j->v->gspec && j->spec && j->tshift && !j->any_rotation && (j->N * j->N) % kStPix == 0 && j->N % 4 == 0 &&
+                         std::getenv("LCMI_STENCIL_REDUCE");
+    j->planes_pred = j->in_device_loop && j->free_mask[LC_P_H] && gm_upd && !std::getenv("LCMI_SPLIT_UPDATE") && !stencil;
+  }
   if (reg_h_on(j) || j->pts_pending) {
     // starlet l1 + positivity of h depend on h alone: evaluate them on a second stream while the epoch
     // kernel (which leaves CUs idle whenever E < 256) runs; the update kernel joins the two
@@ -1477,6 +1547,18 @@ int lc_joint_shared_set(lc_joint *j, const float *host, int count) {
   LC_ENTER(j->ctx);
   return h2d(j, j->shared, host, (size_t)count * sizeof(float));
 }
+// The chain of this iteration left planes for the fused reduction + update (planes_pred) and another consumer turned up: wait
+// for the chain and let one more launch write greg / regs on the consumer's stream.
+static int planes_repair(lc_joint *j, bool consumer_adds_planes) {
+  if (!j->reg_planes || consumer_adds_planes) return LC_OK;
+  const int NN = j->N * j->N, nb = (NN + kGmThreads - 1) / kGmThreads;
+  LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
+  hipLaunchKernelGGL(mreg_finish3_kernel, dim3(nb + 1), dim3(kGmThreads), 0, j->ctx->stream, NN, nb, j->M, j->planes, j->greg, j->regs);
+  LC_HIP(j->ctx, hipGetLastError());
+  j->reg_planes = false;
+  j->reg_noflag = true;
+  return LC_OK;
+}
 int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   if (!j) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
@@ -1490,7 +1572,8 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   // two 16-pixel tiles per block: at most two resident 256-thread blocks per CU (8 of 32 wave slots, 192 of 512 registers
   // per lane and SIMD), next to which every kernel of the chain fits
   const bool few_blocks = ((j->N * j->N) / kRedPix) % 2 == 0 && (j->N * j->N) / kRedPix / 2 <= 2 * j->ctx->n_cu;
-  j->flag_sync = j->reg_pending && j->fuse_full && j->mreg && j->reg_flag && few_blocks && !std::getenv("LCMI_EVENT_SYNC");
+  if ((rc = planes_repair(j, j->fuse_full && !j->fuse_stencil))) return rc;
+  j->flag_sync = j->reg_pending && j->fuse_full && j->mreg && j->reg_flag && few_blocks && !j->reg_noflag && !std::getenv("LCMI_EVENT_SYNC");
   if (j->reg_pending && !j->flag_sync) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
   rc = launch_update(j, 1, j->iters_done, cfg, true, false, j->reg_pending ? 2 : 0);
   if (rc) return rc;
@@ -1509,8 +1592,10 @@ int lc_joint_step_grad(lc_joint *j, float *loss, float *const grads[LC_P_COUNT])
   if (!j) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
   if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_step_grad: not available on a batched star-photometry object");
+  int rc = planes_repair(j, false);
+  if (rc) return rc;
   if (j->reg_pending) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
-  int rc = launch_update(j, 0, 0, nullptr, false, true, j->reg_pending ? 2 : 0);
+  rc = launch_update(j, 0, 0, nullptr, false, true, j->reg_pending ? 2 : 0);
   if (rc) return rc;
   LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));  // (the next lc_joint_step_local's chain waits for this one)
   j->reg_pending = false;
@@ -1972,7 +2057,11 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
     if (err) {
       const unsigned int zero = 0;
       h2d(j, j->reg_flag + 1, &zero, sizeof(zero));
-      j->ctx->err = "joint fit: the regulariser of an iteration did not complete in time on the second stream (set LCMI_EVENT_SYNC=1)";
+      unsigned int seen = 0;
+      (void)d2h(j, &seen, j->reg_flag, sizeof(seen));
+      static thread_local char msg[256];
+      std::snprintf(msg, sizeof(msg), "joint fit: the regulariser of an iteration did not complete in time on the second stream (set LCMI_EVENT_SYNC=1); completion word %u, expected %u", seen, j->reg_seq);
+      j->ctx->err = msg;
       return LC_ERR_DEVICE;
     }
   }

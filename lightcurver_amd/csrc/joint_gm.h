@@ -534,6 +534,9 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_groups_kernel(const J
 // nimg + 1 updates the per-epoch shifts and sky levels.
 // `tiles` 16-pixel tiles per image block (2 where the regulariser flag is checked in the kernel: at most two 256-thread
 // blocks per CU are then resident, so a chain that runs late always finds the wave slots and registers to finish).
+// Registers: 197 per lane (the scalar block's side-by-side double-precision sums set the figure, whatever the tile count): two
+// resident blocks per CU leave 112 of the 512 registers per lane and SIMD, which is what a wave of every kernel of the
+// regulariser chain must fit in (joint_reg_fused.h) - a late chain must be schedulable while this kernel waits for it.
 constexpr int kUpdMaxTiles = 4;  // tiles per block the kernel below holds side by side (the host never asks for more)
 __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointUpdArgs A, int N, const float *HG, int tiles) {
   static_assert(kRedThreads == kGmThreads, "one block size");
@@ -580,8 +583,10 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointU
     if (tid < kRedPix) {
 #pragma unroll
       for (int tl = 0; tl < kUpdMaxTiles; ++tl)
-        if (tl < tiles && A.reg_mode == 2)
-          gr[tl] = ld_coherent(A.greg + (bid * tiles + tl) * kRedPix + tid, A.wait_flag != nullptr);
+        if (tl < tiles && A.reg_mode == 2) {
+          const int px = (bid * tiles + tl) * kRedPix + tid;
+          gr[tl] = A.planes.on ? planes_greg(A.planes, px, NN, A.wait_flag != nullptr) : ld_coherent(A.greg + px, A.wait_flag != nullptr);
+        }
 #pragma unroll
       for (int tl = 0; tl < kUpdMaxTiles; ++tl) {
         if (tl < tiles) {
@@ -615,7 +620,9 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointU
   // what the chain left in regs (values of its terms, inner products of the point-source term): one round trip for the block
   const bool have_regs = (A.regs != nullptr) && (A.reg_mode == 2 || (A.lam_pts != 0.f && A.pts_early == 2));
   if (have_regs) {
-    if (tid < 4 + 3 * M) regl[tid] = ld_coherent(A.regs + tid, A.wait_flag != nullptr);
+    if (tid < 4 + 3 * M)
+      regl[tid] = A.planes.on ? (tid == 3 ? 0.f : planes_reg_value(A.planes, tid, A.wait_flag != nullptr))
+                              : ld_coherent(A.regs + tid, A.wait_flag != nullptr);
     __syncthreads();
   }
   LC_USTAMP(4);

@@ -1696,6 +1696,15 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_kernel(int E, int M,
 }
 
 // ---- kernel 3: regularisers, loss, AdaBelief -------------------------------------------------------
+// What the four-launch regulariser chain (joint_reg_fused.h) leaves for its consumer to add up: the sub-gradient as planes
+// S_0 + sum_{s = 1 .. J} Z_s, the values of the terms and the inner products of the point-source term per 64 x 64 tile.
+struct RegPlanes {
+  int on, J, ntile, has_pts;
+  const float *S0;        // [NN]
+  const float *Z;         // [J + 2][NN]: planes 1 .. J in use
+  const float *vals;      // [J + 2][ntile]: rows 0 .. J - 1 l1 per scale, row J positivity, row J + 1 the point-source term
+  const float *pts_part;  // [ntile][3 kMaxSources]
+};
 struct JointUpdArgs {
   int E, M, mode, t, hist_stride, ss;  // mode 1 = update, 0 = gradients only
   int reg_mode;                        // 0 = background regulariser inline, 1 = compute it only (-> greg, regs), 2 = use greg / regs
@@ -1731,6 +1740,7 @@ struct JointUpdArgs {
   const unsigned int *wait_flag;
   unsigned int wait_seq;
   unsigned int *wait_err;
+  RegPlanes planes;   // planes.on: greg / regs are not materialised, the kernel adds the chain's planes and per-tile values itself
   // return_param_history (reference call sites star_photometry.py:115-122, roi_modelling.py:326-334): the row of the
   // device-resident history [iterations][P] this update fills - every free block at its offset poff[which] (-1: fixed),
   // written where the parameter itself is stored, so the loop stays on the device
@@ -1768,6 +1778,39 @@ __device__ __forceinline__ void wait_for_flag(const unsigned int *flag, unsigned
 }
 __device__ __forceinline__ float ld_coherent(const float *p, bool coherent) {
   return coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+// greg of pixel k from the planes (mreg_finish2_kernel's order: S_0, then Z_1 .. Z_J); all loads requested before the first sum
+constexpr int kPlanesMaxJ = 8;
+__device__ __forceinline__ float planes_greg(const RegPlanes &P, int k, int NN, bool coherent) {
+  float zv[kPlanesMaxJ];
+  float g = ld_coherent(P.S0 + k, coherent);
+#pragma unroll
+  for (int s = 1; s <= kPlanesMaxJ; ++s) zv[s - 1] = ld_coherent(P.Z + (size_t)min(s, P.J) * NN + k, coherent);
+#pragma unroll
+  for (int s = 1; s <= kPlanesMaxJ; ++s) g += (s <= P.J) ? zv[s - 1] : 0.f;
+  return g;
+}
+// regs[t] from the per-tile values: t = 0 l1, 1 positivity, 2 the point-source term, 4 + q its inner products (one thread
+// each; four running sums so that the loads do not wait for each other's additions; fixed order)
+__device__ __forceinline__ float planes_reg_value(const RegPlanes &P, int t, bool coherent) {
+  const float *base;
+  int n, stride = 1;
+  if (t == 0) { base = P.vals; n = P.J * P.ntile; }
+  else if (t == 1) { base = P.vals + (size_t)P.J * P.ntile; n = P.ntile; }
+  else if (t == 2) { base = P.vals + (size_t)(P.J + 1) * P.ntile; n = P.has_pts ? P.ntile : 0; }
+  else { base = P.pts_part + (t - 4); n = P.has_pts ? P.ntile : 0; stride = 3 * kMaxSources; }
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int i = 0;
+  for (; i + 3 < n; i += 4) {
+    const float v0 = ld_coherent(base + (size_t)i * stride, coherent), v1 = ld_coherent(base + (size_t)(i + 1) * stride, coherent);
+    const float v2 = ld_coherent(base + (size_t)(i + 2) * stride, coherent), v3 = ld_coherent(base + (size_t)(i + 3) * stride, coherent);
+    a0 += v0;
+    a1 += v1;
+    a2 += v2;
+    a3 += v3;
+  }
+  for (; i < n; ++i) a0 += ld_coherent(base + (size_t)i * stride, coherent);
+  return (a0 + a1) + (a2 + a3);
 }
 
 // (no contraction into fused multiply-adds here: several kernels apply this step - fused and split update, single-workgroup

@@ -91,6 +91,27 @@ def test_regulariser_chain_forms_agree(ctx, E, n, M):
     _compare(a, c, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 20, 1e-4)
 
 
+@pytest.mark.parametrize('E,n,M', [(8, 64, 2), (3, 128, 4), (6, 64, 1)])
+def test_four_launch_chain_equals_the_eight_launch_one(ctx, E, n, M):
+    """Default since round 4 (csrc/joint_reg_fused.h): the element-wise launches of the batched-product chain folded into the
+    products' operand fetches and epilogues, the sums left to the fused reduction + update.  Element by element the same
+    arithmetic as the eight launches (LCMI_REG_FUSED=0); the values of the terms and the inner products of the point-source
+    term are added per 64 x 64 tile instead of per 256-pixel block: fp32 rounding of those sums only.  With the split update
+    (LCMI_SPLIT_UPDATE=1) the same chain hands greg / regs over through one more launch: the same bits as the fused form."""
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=104)
+    a = _fit(ctx, ds, M, 25)
+    b = _fit(ctx, ds, M, 25, env={'LCMI_REG_FUSED': '0'})
+    _compare(a, b, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 25, 1e-4)
+    assert a[0][-1] < a[0][0]
+    c = _fit(ctx, ds, M, 25, env={'LCMI_SPLIT_UPDATE': '1'})
+    np.testing.assert_array_equal(a[0], c[0])
+    np.testing.assert_array_equal(a[1]['h'], c[1]['h'])
+    # one iteration: identical h gradient (same products, same order of the planes' sum), so identical h after one step
+    a1 = _fit(ctx, ds, M, 1)
+    b1 = _fit(ctx, ds, M, 1, env={'LCMI_REG_FUSED': '0'})
+    np.testing.assert_array_equal(a1[1]['h'], b1[1]['h'])
+
+
 @pytest.mark.parametrize('E,n,M', [(8, 64, 2), (5, 32, 2), (3, 128, 4)])
 def test_fused_reduction_and_update_equals_the_two_kernels(ctx, E, n, M):
     ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=104)
