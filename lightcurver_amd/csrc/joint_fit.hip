@@ -111,6 +111,9 @@ struct lc_joint {
   // update, which adds the planes itself (set by lc_joint_step_local before the chain is enqueued); reg_planes = this
   // iteration's chain left planes and per-tile values only (no greg / regs yet); reg_noflag = it wrote greg / regs but raises
   // no completion flag (its consumer waits for the event)
+  unsigned int *pts_ctr = nullptr;   // [0] arrival counter of the point-source blocks inside the update launch, [1] a wait ran out
+  unsigned int pts_seq = 0;
+  bool pts_tail_used = false;
   bool planes_pred = false, reg_planes = false, reg_noflag = false;
   RegPlanes planes;
   bool fuse_full = false;  // lc_joint_run_adabelief, background free: reduction over the epochs and update in one launch
@@ -324,19 +327,26 @@ void find_ps_kernel(int N, int ss, ps_fn *fn, int *lds, bool persist = false) {
 // Workgroups per epoch of the cluster form for the next forward + backward launch of this object (0: the one-workgroup
 // kernel).  Inside the library's own loops only, and all workgroups of the launch resident together, one per CU.  P
 // four-wave workgroups per epoch: six turn every phase into one sweep (24 waves x 4 transforms = the 96 column transforms).
-// OPT-IN (LCMI_CLUSTER=<P>; "auto": as many as fit, up to six), not the default.  Measured on MI355X at 25 epochs of 64 x 64 (a
-// rank's share of a sharded C4; profiles/r04_cluster_*): the epoch kernel itself takes 42.2 us as a cluster of six against
-// 53.5 us with one workgroup per epoch, and an iteration WITHOUT the starlet regulariser 47.0 against 61.1 us - but with the
-// regulariser on (the reference's ROI fit) the iteration is bound by the regulariser chain on the second stream (~60 us for
-// its eight stages, as launches or as one launch: each stage is a cross-CU hand-off of 5 - 7 us), which the 53 us kernel
-// hides and the 42 us kernel does not: 66.8 against 65.0 us per iteration.  The form pays once the chain is shorter than it.
+// Measured on MI355X at 64 x 64 (profiles/r04_cluster_*): the epoch kernel itself takes 42 us as a cluster of six against 53.5
+// us with one workgroup per epoch.  With the eight-launch regulariser chain (~60 us on the second stream) that gained nothing:
+// the chain was the iteration (66.8 against 65.0 us at 25 epochs).  With the four-launch chain (joint_reg_fused.h, ~32 us) it
+// does: 8 / 16 / 25 / 32 epochs 55.3 / 55.9 / 56.2 / 56.7 us per iteration against 64.8 / 65.1 / 65.0 / 65.3.
+// DEFAULT ("auto", also when LCMI_CLUSTER is unset) since then: six workgroups per epoch whenever they leave kChainBlocks CUs
+// to the chain (6 E + 64 <= CUs: up to 32 epochs - a rank's share of a sharded C4).  Not beyond: clusters that fill the
+// machine starve the chain (42 epochs x 6: 87.5 us, 50 x 5: 101.9, 85 x 3: 122.5), and fewer workgroups per epoch gain
+// little or lose (36 x 5: 64.1, 40 x 4: 64.0, 56 x 3: 72.8, 80 x 2: 85.9 against 65 - 67 us).  LCMI_CLUSTER=0 switches the
+// form off, LCMI_CLUSTER=<P> forces P workgroups per epoch (as many as fit one per CU).
 int cluster_parts(const lc_joint *j) {
   const JointVariant *v = j->v;
   if (!(v->ek_cluster && j->cl_ctr && !j->cluster_off && (j->in_device_loop || j->in_sharded_loop) && !j->fuse_stencil)) return 0;
   const char *cl = std::getenv("LCMI_CLUSTER");
-  if (!cl) return 0;
   const int per_wg = v->cl_thr / v->cl_lpf, full = (j->L / 2 + per_wg - 1) / per_wg;
-  const int want = (std::strcmp(cl, "auto") == 0) ? full : std::max(0, std::atoi(cl));
+  if (!cl || std::strcmp(cl, "auto") == 0) {
+    if (full > kMaxParts || full < 2 || j->E * full + kChainBlocks > j->ctx->n_cu) return 0;
+    // (the chain must be the short one for the form to pay: the background regulariser on the matrix cores)
+    return (j->mreg || !reg_h_on(j)) ? full : 0;
+  }
+  const int want = std::max(0, std::atoi(cl));
   const int P = std::min({kMaxParts, want, j->ctx->n_cu / std::max(j->E, 1)});
   return P >= 2 ? P : 0;
 }
@@ -704,7 +714,15 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
                          j->mr_l1b + (size_t)(J + 1) * nb, (const float *)j->par[LC_P_A], j->E);
       LC_HIP(j->ctx, hipEventRecord(j->evPts, j->streamC));
     }
-    const bool pts_batch = with_pts && !pts_side;
+    // Fourth form (default; LCMI_REG_FUSED=0: the eight launches below): the element-wise launches folded into the products and
+    // the point-source term evaluated from separable tables instead of a ninth product (joint_reg_fused.h) - f1 (+ the
+    // point-source blocks), f2, a1' (S planes in the operand fetch, values per tile), a2' (completion counter); the fused
+    // reduction + update adds the planes, any other consumer gets greg / regs from one more launch.
+    const char *rc_env = std::getenv("LCMI_REG_CHAIN");
+    const char *fu_env = std::getenv("LCMI_REG_FUSED");
+    const bool fused = k->mmx[0] && l1_on && J <= kPlanesMaxJ && J <= 12 && !pts_side && !(rc_env && std::atoi(rc_env) != 0) &&
+                       !(fu_env && std::atoi(fu_env) == 0) && NN % (kPtsBlocks * kMmThreads) == 0;
+    const bool pts_batch = with_pts && !pts_side && !fused;
     MmBatch f1, f2, a1, a2;
     std::memset(&f1, 0, sizeof(f1));
     f2 = a1 = a2 = f1;
@@ -733,52 +751,53 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
     // are not: the one launch takes 59.4 us per iteration (profiles/r04_cluster_*) - every stage boundary is a hand-off
     // between CUs (write-through stores, drain, flag, L1-bypassing loads from the memory side), 5 - 7 us whether a launch
     // boundary or an in-kernel sync delivers it.  NOT the default; what shortens the chain is fewer stages, not cheaper ones.
-    const char *rc_env = std::getenv("LCMI_REG_CHAIN");
-    // Fourth form (default; LCMI_REG_FUSED=0: the eight launches below): the element-wise launches folded into the products
-    // (joint_reg_fused.h) - f1' (Pbar in the operand fetch), f2, a1' (S planes in the operand fetch, values per tile),
-    // a2' (point-source inner products in the epilogue, completion counter); the fused reduction + update adds the planes, any
-    // other consumer gets greg / regs from one more launch.
-    {
-      const char *fu_env = std::getenv("LCMI_REG_FUSED");
-      const bool chain_one = rc_env && std::atoi(rc_env) != 0;
-      if (k->mmx[0] && l1_on && nbch > 0 && J <= kPlanesMaxJ && J + 1 <= 12 && !pts_side && !chain_one && !(fu_env && std::atoi(fu_env) == 0)) {
-        MmxArgs Q;
-        std::memset(&Q, 0, sizeof(Q));
-        for (int b = 0; b < nbch; ++b) Q.scale[b] = (pts_batch && b == nbch - 1) ? -1 : b + 1;
-        Q.J = J;
-        Q.ntile = (N / 64) * (N / 64);
-        Q.E = j->E; Q.M = j->M; Q.ss = j->ss;
-        Q.a = j->par[LC_P_A]; Q.cx = j->par[LC_P_CX]; Q.cy = j->par[LC_P_CY];
-        Q.pbar = j->mr_pbar;
-        Q.X = j->par[LC_P_H]; Q.C = j->mr_C; Q.W = j->have_W ? j->W : nullptr; Q.norms = j->norms;
-        Q.lam_sc = j->cfg.lam_scales; Q.lam_hf = j->cfg.lam_hf; Q.lam_pts = j->cfg.lam_pts_source; Q.lam_pos = j->cfg.lam_positivity;
-        Q.S = j->mr_S;
-        Q.vals = j->mr_l1b;
-        Q.pts_part = j->mr_part;
-        const dim3 mgrid(N / 64, N / 64, nbch), mblock(kMmThreads);
-        Q.mm = f1;
-        hipLaunchKernelGGL(k->mmx[0], mgrid, mblock, 0, stream, Q);
-        Q.mm = f2;
-        hipLaunchKernelGGL(k->mmx[3], mgrid, mblock, 0, stream, Q);   // (the plain product, without mreg_mm_kernel's 48 bytes of scratch per lane)
-        Q.mm = a1;
-        hipLaunchKernelGGL(k->mmx[1], mgrid, mblock, 0, stream, Q);
-        Q.mm = a2;
-        const bool planes = j->planes_pred && j->reg_flag;
-        Q.done = planes ? j->reg_flag : nullptr;
-        hipLaunchKernelGGL(k->mmx[2], mgrid, mblock, 0, stream, Q);
-        RegPlanes &P = j->planes;
-        P.on = 1; P.J = J; P.ntile = Q.ntile; P.has_pts = pts_batch ? 1 : 0;
-        P.S0 = j->mr_S; P.Z = j->mr_Z; P.vals = j->mr_l1b; P.pts_part = j->mr_part;
-        if (planes) {
-          j->reg_seq += (unsigned int)(mgrid.x * mgrid.y * mgrid.z);
-          j->reg_planes = true;
-        } else {
-          hipLaunchKernelGGL(mreg_finish3_kernel, dim3(nb + 1), dim3(kGmThreads), 0, stream, NN, nb, j->M, P, j->greg, j->regs);
-          j->reg_noflag = true;
-        }
-        LC_HIP(j->ctx, hipGetLastError());
-        return LC_OK;
+    if (fused) {
+      MmxArgs Q;
+      std::memset(&Q, 0, sizeof(Q));
+      for (int b = 0; b < nbch; ++b) Q.scale[b] = b + 1;
+      Q.J = J;
+      Q.ntile = (N / 64) * (N / 64);
+      Q.X = j->par[LC_P_H]; Q.C = j->mr_C; Q.W = j->have_W ? j->W : nullptr; Q.norms = j->norms;
+      Q.lam_sc = j->cfg.lam_scales; Q.lam_hf = j->cfg.lam_hf; Q.lam_pos = j->cfg.lam_positivity;
+      Q.S = j->mr_S;
+      Q.vals = j->mr_l1b;
+      const dim3 mgrid(N / 64, N / 64, nbch), mblock(kMmThreads);
+      dim3 g1 = mgrid;
+      if (with_pts) {   // the point-source blocks ride in the first launch (they depend on nothing the chain computes)
+        PtsSepArgs &P = Q.pts;
+        P.N = N; P.ss = j->ss; P.E = j->E; P.M = j->M;
+        P.a = j->par[LC_P_A]; P.cx = j->par[LC_P_CX]; P.cy = j->par[LC_P_CY];
+        P.W0 = j->have_W ? j->W : nullptr; P.norms = j->norms; P.lam_pts = j->cfg.lam_pts_source;
+        P.part = j->mr_part;
+        g1.z += (kPtsBlocks + Q.ntile - 1) / Q.ntile;
       }
+      Q.mm = f1;
+      hipLaunchKernelGGL(k->mmx[0], g1, mblock, 0, stream, Q);
+      Q.mm = f2;
+      hipLaunchKernelGGL(k->mmx[3], mgrid, mblock, 0, stream, Q);   // (the plain product, without mreg_mm_kernel's 48 bytes of scratch per lane)
+      Q.mm = a1;
+      hipLaunchKernelGGL(k->mmx[1], mgrid, mblock, 0, stream, Q);
+      Q.mm = a2;
+      // who adds the planes up: the fused update itself when the chain is the longer path of the iteration (beside the cluster
+      // form of the epoch kernel: one stage less on the chain, ~1.3 us more in the update), otherwise a fifth launch of the
+      // chain, which then has the time (it ends ~15 us before a one-workgroup epoch kernel does)
+      const bool planes = j->planes_pred && j->reg_flag && cluster_parts(j) >= 2;
+      Q.done = planes ? j->reg_flag : nullptr;
+      hipLaunchKernelGGL(k->mmx[2], mgrid, mblock, 0, stream, Q);
+      RegPlanes &P = j->planes;
+      P.on = 1; P.J = J; P.ntile = Q.ntile; P.npts = with_pts ? kPtsBlocks : 0;
+      P.S0 = j->mr_S; P.Z = j->mr_Z; P.vals = j->mr_l1b; P.pts_part = j->mr_part;
+      if (planes) {
+        j->reg_seq += (unsigned int)(mgrid.x * mgrid.y * mgrid.z);
+        j->reg_planes = true;
+      } else {
+        unsigned int *done = (j->planes_pred && j->reg_flag) ? j->reg_flag : nullptr;
+        hipLaunchKernelGGL(mreg_finish3_kernel, dim3(nb + 1), dim3(kGmThreads), 0, stream, NN, nb, j->M, P, j->greg, j->regs, done);
+        if (done) j->reg_seq += (unsigned int)(nb + 1);
+        else j->reg_noflag = true;
+      }
+      LC_HIP(j->ctx, hipGetLastError());
+      return LC_OK;
     }
     const int epoch_wgs = j->E * std::max(1, cluster_parts(j));
     if (k->chain && j->chain_flags && j->reg_flag && !j->chain_off && epoch_wgs + kChainBlocks <= j->ctx->n_cu && rc_env && std::atoi(rc_env) != 0) {
@@ -866,7 +885,20 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   const JointVariant *v = j->v;
   bool gm_pts_done = false;
   if (reg_mode == 1 && j->mreg) return launch_reg_mfma(j, stream, j->pts_pending);
-  if (!v->uk) {
+  // Behind the chain of a sharded / step-by-step iteration (reg_mode 2) the point-source starlet term is still to do - it needs
+  // the all-reduced mean fluxes.  Where the separable form applies (N >= 128) it rides INSIDE the multi-block update launch
+  // (PtsTail, joint_gm.h): no launch of its own on the tail behind the all-reduce (two before: gm_pts_direct_kernel and its
+  // final sums; LCMI_PTS_TAIL=0 brings them back, the cross-check).
+  bool pts_tail = false;
+  {
+    const char *pt = std::getenv("LCMI_PTS_TAIL");
+    const bool want_pts = j->cfg.lam_pts_source != 0.f && j->M > 0;
+    pts_tail = reg_mode == 2 && want_pts && !j->pts_pending && j->pts_ctr && (j->N * j->N) % (kPtsBlocks * kGmThreads) == 0 &&
+               (mode == 1 || !v->uk) && !(pt && std::atoi(pt) == 0) && !std::getenv("LCMI_PTS_CHAIN") && (size_t)4 * j->M * j->N * sizeof(float) <= 48 * 1024;
+    if (pts_tail) gm_pts_done = true;
+  }
+  if (pts_tail) {
+  } else if (!v->uk) {
     const bool want_pts = j->cfg.lam_pts_source != 0.f && j->M > 0;
     if (reg_mode == 1) return launch_reg_gm(j, stream, j->pts_pending, false);
     if (reg_mode == 2) gm_pts_done = j->pts_pending;  // evaluated by the stream-B chain of this iteration
@@ -984,7 +1016,24 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
       A.shared_w = j->shared;
       nblk = 1;
     }
-    hipLaunchKernelGGL(joint_update_gm_kernel, dim3(nblk), dim3(kGmThreads), 0, stream, A, j->N);
+    PtsTail T;
+    std::memset(&T, 0, sizeof(T));
+    size_t dyn = 0;
+    if (pts_tail) {
+      T.on = 1;
+      PtsSepArgs &P = T.P;
+      P.N = j->N; P.ss = j->ss; P.E = j->E; P.M = j->M;
+      P.a = j->par[LC_P_A]; P.cx = j->par[LC_P_CX]; P.cy = j->par[LC_P_CY];
+      P.abar_sum = j->shared + NN + 2 * j->M; P.a_ref = j->a_ref; P.n_total = j->shared + NN + 4 * j->M + 1;
+      P.W0 = j->have_W ? j->W : nullptr; P.norms = j->norms; P.lam_pts = j->cfg.lam_pts_source;
+      P.part = j->mr_part;
+      P.write_through = 1;
+      j->pts_seq += (unsigned int)kPtsBlocks;
+      T.ctr = j->pts_ctr; T.seq = j->pts_seq; T.err = j->pts_ctr + 1;
+      dyn = (size_t)4 * j->M * j->N * sizeof(float);
+      j->pts_tail_used = true;
+    }
+    hipLaunchKernelGGL(joint_update_gm_kernel, dim3(nblk + (pts_tail ? kPtsBlocks : 0)), dim3(kGmThreads), dyn, stream, A, j->N, T);
     LC_HIP(j->ctx, hipGetLastError());
     return LC_OK;
   }
@@ -1166,9 +1215,10 @@ static int joint_create_impl(lc_ctx *ctx, int E, int M, int n, int ss, const flo
     TRY(dmalloc(j, &j->mr_T, (size_t)(j->J + 1) * NN));
     TRY(dmalloc(j, &j->mr_l1, j->J + 1));
     TRY(dmalloc(j, &j->mr_pos, nb));
-    TRY(dmalloc(j, &j->mr_part, nb * 3 * kMaxSources));
+    TRY(dmalloc(j, &j->mr_part, std::max<size_t>((size_t)nb * 3 * kMaxSources, (size_t)kPtsBlocks * kPtsStride)));
     TRY(dmalloc(j, &j->mr_pbar, NN));
     if (j->mreg->rows) TRY(dmalloc(j, &j->rr_Zp, (size_t)(N / kRrRows) * kRrMaxParts * NN));
+    TRY(dmalloc(j, &j->pts_ctr, 4));
     TRY(dmalloc(j, &j->reg_flag, 4));  // [0] completion flag, [1] a wait ran out, [2] ticket of the finishing launch
     LC_HIP(ctx, hipFuncSetAttribute((const void *)j->mreg->fwd, hipFuncAttributeMaxDynamicSharedMemorySize, j->mreg->lds_fwd));
     LC_HIP(ctx, hipFuncSetAttribute((const void *)j->mreg->adj, hipFuncAttributeMaxDynamicSharedMemorySize, j->mreg->lds_adj));
@@ -1553,7 +1603,8 @@ static int planes_repair(lc_joint *j, bool consumer_adds_planes) {
   if (!j->reg_planes || consumer_adds_planes) return LC_OK;
   const int NN = j->N * j->N, nb = (NN + kGmThreads - 1) / kGmThreads;
   LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
-  hipLaunchKernelGGL(mreg_finish3_kernel, dim3(nb + 1), dim3(kGmThreads), 0, j->ctx->stream, NN, nb, j->M, j->planes, j->greg, j->regs);
+  hipLaunchKernelGGL(mreg_finish3_kernel, dim3(nb + 1), dim3(kGmThreads), 0, j->ctx->stream, NN, nb, j->M, j->planes, j->greg, j->regs,
+                     (unsigned int *)nullptr);
   LC_HIP(j->ctx, hipGetLastError());
   j->reg_planes = false;
   j->reg_noflag = true;
@@ -1646,6 +1697,18 @@ static int chain_check(lc_joint *j) {
   LC_FAIL(j->ctx, LC_ERR_DEVICE, "joint fit: the one-launch regulariser chain gave up (its workgroups were not resident together); this run's numbers are invalid - the object has switched to the launch form, run again (LCMI_REG_CHAIN=0 selects it from the start)");
 }
 
+// Update launches that carried the point-source blocks since the last check: did block 0 give up waiting for them?
+static int pts_tail_check(lc_joint *j) {
+  if (!j->pts_ctr || !j->pts_tail_used) return LC_OK;
+  j->pts_tail_used = false;
+  unsigned int err = 0;
+  int rc = d2h(j, &err, j->pts_ctr + 1, sizeof(err));
+  if (rc || !err) return rc;
+  const unsigned int zero = 0;
+  (void)h2d(j, j->pts_ctr + 1, &zero, sizeof(zero));
+  LC_FAIL(j->ctx, LC_ERR_DEVICE, "joint fit: the point-source blocks of an update launch did not arrive in time; this run's numbers are invalid (LCMI_PTS_TAIL=0 selects the separate launches)");
+}
+
 int lc_joint_run_sharded(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg, lc_allreduce_fn allreduce, void *user) {
   if (!j || n_iter < 0 || !allreduce) return LC_ERR_INVALID;
   LC_ENTER(j->ctx);
@@ -1664,6 +1727,7 @@ int lc_joint_run_sharded(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg, l
   }
   j->in_sharded_loop = false;
   if (!rc) rc = chain_check(j);
+  if (!rc) rc = pts_tail_check(j);
   if (!rc && may_cluster && j->cl_parts_last > 0) {
     // a sharded run cannot be redone by one rank alone (the others have moved on through the same all-reduces): report it;
     // the object runs the one-workgroup kernel from here on

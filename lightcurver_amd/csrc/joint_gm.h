@@ -341,6 +341,138 @@ __global__ void gm_pts_final_kernel(int nblocks, int M, const float *part, const
   }
 }
 
+struct PtsSepArgs {
+  int N, ss, E, M;
+  const float *a, *cx, *cy;   // fluxes [E][M] (mean over the epochs taken here) and positions
+  const float *abar_sum;      // or: sums over ALL epochs of (a - a_ref) per source (the all-reduced block of a sharded fit) ...
+  const float *a_ref;         // ... with the references they are centred on, and
+  const float *n_total;       // ... the total epoch count (one float)
+  const float *W0;            // [NN] weights of scale 0, or null (then norms[0])
+  const float *norms;
+  float lam_pts;
+  float *part;                // [kPtsBlocks][kPtsStride]
+  int write_through;          // the consumer reads behind a completion counter, not behind a kernel boundary
+};
+
+
+// The point-source starlet term from separable tables (derivation: joint_reg_fused.h).  One block of it: pixels
+// [pb NN / kPtsBlocks, (pb + 1) NN / kPtsBlocks).  tab: 4 M N floats of LDS.
+// (N^2 a multiple of kPtsBlocks kGmThreads: N >= 128; all kGmThreads threads of the block call)
+__device__ __forceinline__ void pts_sep_block(const PtsSepArgs &P, int pb, float *tab, float (*red)[kPtsStride], float *abar) {
+  constexpr int NT = kGmThreads;
+  const int N = P.N, NN = N * N, PX = NN / kPtsBlocks;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, M = P.M;
+  const float cen = (N - 1) * 0.5f, inv_s2 = 1.0f / (kSigmaG * kSigmaG), nrm2 = 0.15915494309189535f * inv_s2;
+  if (P.abar_sum) {
+    if (tid < M) abar[tid] = P.a_ref[tid] + P.abar_sum[tid] / P.n_total[0];
+  } else {
+    for (int q = wid; q < M; q += NT / 64) {  // mean fluxes, as mreg_pbar_kernel sums them
+      float acc = 0.f;
+      for (int e = lane; e < P.E; e += 64) acc += P.a[e * M + q];
+      acc = wave_sum_shfl(acc);
+      if (lane == 0) abar[q] = acc / (float)P.E;
+    }
+  }
+  float *gx = tab, *sgx = tab + M * N, *dgx = tab + 2 * M * N, *sdgx = tab + 3 * M * N;
+  for (int t = tid; t < M * N; t += NT) {
+    const int i = t / N, v = t % N;
+    const float tx = (float)v - (cen + P.ss * P.cx[i]);
+    const float g = expf(-0.5f * tx * tx * inv_s2);
+    gx[t] = g;
+    dgx[t] = g * tx * inv_s2;
+  }
+  __syncthreads();
+  const float b0 = 0.0625f, b1 = 0.25f, b2 = 0.375f;
+  for (int t = tid; t < M * N; t += NT) {
+    const int i = t / N, v = t % N;
+    const int m2 = max(v - 2, 0), m1 = max(v - 1, 0), p1 = min(v + 1, N - 1), p2 = min(v + 2, N - 1);
+    const float *g = gx + i * N, *d = dgx + i * N;
+    sgx[t] = b0 * g[m2] + b1 * g[m1] + b2 * g[v] + b1 * g[p1] + b0 * g[p2];
+    sdgx[t] = b0 * d[m2] + b1 * d[m1] + b2 * d[v] + b1 * d[p1] + b0 * d[p2];
+  }
+  __syncthreads();
+  float sums[kPtsStride];
+#pragma unroll
+  for (int q = 0; q < kPtsStride; ++q) sums[q] = 0.f;
+  for (int q = 0; q < PX / NT; ++q) {
+    const int k = pb * PX + q * NT + tid, u = k / N, v = k % N;
+    float gy[kMaxSources], sgy[kMaxSources], dgy[kMaxSources], sdgy[kMaxSources];
+    float Pv = 0.f, Cv = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxSources; ++i) {
+      gy[i] = sgy[i] = dgy[i] = sdgy[i] = 0.f;
+      if (i < M) {
+        const float yc = cen + P.ss * P.cy[i];
+        float g5[5], d5[5];
+#pragma unroll
+        for (int t = -2; t <= 2; ++t) {
+          const float ty = (float)min(max(u + t, 0), N - 1) - yc;
+          g5[t + 2] = expf(-0.5f * ty * ty * inv_s2);
+          d5[t + 2] = g5[t + 2] * ty * inv_s2;
+        }
+        gy[i] = g5[2];
+        dgy[i] = d5[2];
+        sgy[i] = b0 * g5[0] + b1 * g5[1] + b2 * g5[2] + b1 * g5[3] + b0 * g5[4];
+        sdgy[i] = b0 * d5[0] + b1 * d5[1] + b2 * d5[2] + b1 * d5[3] + b0 * d5[4];
+        const float ab = abar[i] * nrm2;
+        Pv = fmaf(ab, gy[i] * gx[i * N + v], Pv);
+        Cv = fmaf(ab, sgy[i] * sgx[i * N + v], Cv);
+      }
+    }
+    const float d = Pv - Cv;
+    const float lw = P.W0 ? P.lam_pts * P.W0[k] : P.lam_pts * P.norms[0];
+    const float sp = (d > 0.f) ? lw : ((d < 0.f) ? -lw : 0.f);
+    sums[3 * kMaxSources] += lw * fabsf(d);
+#pragma unroll
+    for (int i = 0; i < kMaxSources; ++i) {
+      if (i < M) {
+        const float x0 = gx[i * N + v], x1 = sgx[i * N + v], x2 = dgx[i * N + v], x3 = sdgx[i * N + v];
+        sums[3 * i] += sp * nrm2 * (gy[i] * x0 - sgy[i] * x1);
+        sums[3 * i + 1] += sp * nrm2 * (gy[i] * x2 - sgy[i] * x3);
+        sums[3 * i + 2] += sp * nrm2 * (dgy[i] * x0 - sdgy[i] * x1);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kPtsStride; ++q) {
+    if (q < 3 * M || q == 3 * kMaxSources) {
+      const float t = wave_sum_shfl(sums[q]);
+      if (lane == 0) red[wid][q] = t;
+    }
+  }
+  __syncthreads();
+  if (tid < 3 * M || tid == 3 * kMaxSources) {
+    float t = 0.f;
+    for (int w = 0; w < NT / 64; ++w) t += red[w][tid];
+    float *dst = P.part + (size_t)pb * kPtsStride + tid;
+    if (P.write_through) xwg_storef<true>(dst, t);
+    else *dst = t;
+  }
+}
+
+
+// regs[t] from what the four-launch chain left (joint_reg_fused.h): t = 0 l1 (per-tile values of every scale), 1 positivity,
+// 2 the point-source term, 4 + q its inner products (per-block partials of pts_sep_block).  All threads of the block call: the
+// waves take the quantities in turn, the lanes of a wave stride over the partials (independent loads), one shuffle tree per
+// quantity - fixed order.  Without the point-source term (npts == 0) its slots are left alone: the sharded drive fills them
+// behind the all-reduce.
+__device__ __forceinline__ void planes_regs_block(const RegPlanes &P, int M, float *out, bool coherent, int t_first = 0) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+  for (int t = t_first + wid; t < 4 + 3 * M; t += nw) {
+    if (t == 3 || (t >= 2 && P.npts == 0)) continue;
+    const float *base;
+    int n, stride = 1;
+    if (t == 0) { base = P.vals; n = P.J * P.ntile; }
+    else if (t == 1) { base = P.vals + (size_t)P.J * P.ntile; n = P.ntile; }
+    else if (t == 2) { base = P.pts_part + 3 * kMaxSources; n = P.npts; stride = kPtsStride; }
+    else { base = P.pts_part + (t - 4); n = P.npts; stride = kPtsStride; }
+    float acc = 0.f;
+    for (int i = lane; i < n; i += 64) acc += ld_coherent(base + (size_t)i * stride, coherent);
+    acc = wave_sum_shfl(acc);
+    if (lane == 0) out[t] = acc;
+  }
+}
+
 // AdaBelief on the small parameter blocks and the loss of the iteration (one block of kGmThreads threads; same rules as
 // joint_update_kernel).  A.greg / A.regs hold the h regulariser when A.reg_mode == 2.
 // sc: the scalar part of the reduced block (A.shared + N * N, or a copy in LDS); parts: bit 0 = fluxes, positions and the
@@ -470,11 +602,38 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
   }
 }
 
+// The point-source starlet term INSIDE the update launch (sharded / step-by-step drive, where the term needs the all-reduced
+// mean fluxes and used to be two launches of its own between the all-reduce and the update): the first kPtsBlocks blocks of
+// the grid evaluate it (pts_sep_block) and count themselves in; only the scalar part of block 0 - fluxes, positions, loss -
+// needs the result and waits for the count (bounded; all blocks of this small grid are resident together), the pixel blocks
+// do not.  ctr grows by kPtsBlocks per launch (seq: its value once this launch's blocks are in).
+struct PtsTail {
+  int on;
+  PtsSepArgs P;
+  unsigned int *ctr;
+  unsigned int seq;
+  unsigned int *err;
+};
 // AdaBelief on h (every block) and on the small blocks + loss (block 0).  A.greg / A.regs hold the h regulariser.
-__global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArgs A, int N) {
+__global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArgs A, int N, PtsTail T) {
+  extern __shared__ __align__(16) float gm_dyn[];   // T.on: 4 M N floats for the tables of the point-source blocks
   __shared__ double lanes[kGmThreads];
+  __shared__ float pred[kGmThreads / 64][kPtsStride];
+  __shared__ float pabar[kMaxSources];
+  __shared__ float regl[4 + 3 * kMaxSources];
   const int tid = threadIdx.x;
   const int E = A.E, M = A.M, NN = N * N;
+  int bx = blockIdx.x;
+  if (T.on) {
+    if (bx < kPtsBlocks) {
+      pts_sep_block(T.P, bx, gm_dyn, pred, pabar);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(T.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    bx -= kPtsBlocks;
+  }
   if (A.fuse_scalar_reduce) {  // grid of one block (the background is not updated)
     reduce_scalars(E, M, NN, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.a_ref, A.shared_w, lanes, tid);
     __threadfence_block();
@@ -482,7 +641,7 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
   }
   const bool use_reg = (A.reg_mode == 2);
   const float lr = A.lr, bc1 = A.bc1, bc2 = A.bc2;
-  const int k = blockIdx.x * blockDim.x + tid;
+  const int k = bx * blockDim.x + tid;
   if (k < NN) {
     const float g = A.shared[k] + (use_reg ? A.greg[k] : 0.f);
     if (A.mode == 0 && A.gout[LC_P_H]) A.gout[LC_P_H][k] = g;
@@ -495,7 +654,21 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
       phist_put(A, LC_P_H, k, hv);
     }
   }
-  if (blockIdx.x != 0) return;
+  if (bx != 0) return;
+  if (T.on) {
+    // values of the background terms from the chain (regs[0 .. 1], behind the stream's event), the point-source term from the
+    // blocks of this launch
+    wait_for_flag(T.ctr, T.seq, T.err);
+    RegPlanes R;
+    R.on = 1; R.J = 0; R.ntile = 0; R.npts = kPtsBlocks;
+    R.S0 = R.Z = R.vals = nullptr;
+    R.pts_part = T.P.part;
+    if (tid < 2) regl[tid] = use_reg ? A.regs[tid] : 0.f;
+    planes_regs_block(R, M, regl, true, 2);
+    __syncthreads();
+    gm_small_blocks(A, N, lr, bc1, bc2, A.shared + NN, 3, nullptr, regl);
+    return;
+  }
   gm_small_blocks(A, N, lr, bc1, bc2, A.shared + NN, 3);
 }
 
@@ -620,9 +793,13 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_update_kernel(JointU
   // what the chain left in regs (values of its terms, inner products of the point-source term): one round trip for the block
   const bool have_regs = (A.regs != nullptr) && (A.reg_mode == 2 || (A.lam_pts != 0.f && A.pts_early == 2));
   if (have_regs) {
-    if (tid < 4 + 3 * M)
-      regl[tid] = A.planes.on ? (tid == 3 ? 0.f : planes_reg_value(A.planes, tid, A.wait_flag != nullptr))
-                              : ld_coherent(A.regs + tid, A.wait_flag != nullptr);
+    if (A.planes.on) {
+      planes_regs_block(A.planes, M, regl, A.wait_flag != nullptr);
+      // (a point-source term that was not part of the chain - none in the device loop - would sit in regs)
+      if (A.planes.npts == 0 && tid >= 2 && tid < 4 + 3 * M) regl[tid] = ld_coherent(A.regs + tid, A.wait_flag != nullptr);
+    } else if (tid < 4 + 3 * M) {
+      regl[tid] = ld_coherent(A.regs + tid, A.wait_flag != nullptr);
+    }
     __syncthreads();
   }
   LC_USTAMP(4);

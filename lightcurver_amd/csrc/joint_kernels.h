@@ -1698,12 +1698,14 @@ __global__ __launch_bounds__(kRedThreads) void joint_reduce_kernel(int E, int M,
 // ---- kernel 3: regularisers, loss, AdaBelief -------------------------------------------------------
 // What the four-launch regulariser chain (joint_reg_fused.h) leaves for its consumer to add up: the sub-gradient as planes
 // S_0 + sum_{s = 1 .. J} Z_s, the values of the terms and the inner products of the point-source term per 64 x 64 tile.
+constexpr int kPtsBlocks = 64;                       // blocks of the separable point-source term (N^2 / 64 pixels each)
+constexpr int kPtsStride = 3 * kMaxSources + 1;      // per block: 3 M inner products, [3 kMaxSources] the value of the term
 struct RegPlanes {
-  int on, J, ntile, has_pts;
+  int on, J, ntile, npts;  // npts: kPtsBlocks when pts_part holds this iteration's point-source term, else 0
   const float *S0;        // [NN]
   const float *Z;         // [J + 2][NN]: planes 1 .. J in use
-  const float *vals;      // [J + 2][ntile]: rows 0 .. J - 1 l1 per scale, row J positivity, row J + 1 the point-source term
-  const float *pts_part;  // [ntile][3 kMaxSources]
+  const float *vals;      // [J + 1][ntile]: rows 0 .. J - 1 l1 per scale, row J positivity
+  const float *pts_part;  // [kPtsBlocks][kPtsStride]
 };
 struct JointUpdArgs {
   int E, M, mode, t, hist_stride, ss;  // mode 1 = update, 0 = gradients only
@@ -1790,29 +1792,6 @@ __device__ __forceinline__ float planes_greg(const RegPlanes &P, int k, int NN, 
   for (int s = 1; s <= kPlanesMaxJ; ++s) g += (s <= P.J) ? zv[s - 1] : 0.f;
   return g;
 }
-// regs[t] from the per-tile values: t = 0 l1, 1 positivity, 2 the point-source term, 4 + q its inner products (one thread
-// each; four running sums so that the loads do not wait for each other's additions; fixed order)
-__device__ __forceinline__ float planes_reg_value(const RegPlanes &P, int t, bool coherent) {
-  const float *base;
-  int n, stride = 1;
-  if (t == 0) { base = P.vals; n = P.J * P.ntile; }
-  else if (t == 1) { base = P.vals + (size_t)P.J * P.ntile; n = P.ntile; }
-  else if (t == 2) { base = P.vals + (size_t)(P.J + 1) * P.ntile; n = P.has_pts ? P.ntile : 0; }
-  else { base = P.pts_part + (t - 4); n = P.has_pts ? P.ntile : 0; stride = 3 * kMaxSources; }
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int i = 0;
-  for (; i + 3 < n; i += 4) {
-    const float v0 = ld_coherent(base + (size_t)i * stride, coherent), v1 = ld_coherent(base + (size_t)(i + 1) * stride, coherent);
-    const float v2 = ld_coherent(base + (size_t)(i + 2) * stride, coherent), v3 = ld_coherent(base + (size_t)(i + 3) * stride, coherent);
-    a0 += v0;
-    a1 += v1;
-    a2 += v2;
-    a3 += v3;
-  }
-  for (; i < n; ++i) a0 += ld_coherent(base + (size_t)i * stride, coherent);
-  return (a0 + a1) + (a2 + a3);
-}
-
 // (no contraction into fused multiply-adds here: several kernels apply this step - fused and split update, single-workgroup
 //  and multi-block form - and their results are required to agree bit for bit, whatever the surrounding code looks like)
 __device__ __forceinline__ float adabelief_step(float &p, float &m, float &s, float g, float lr, float bc1, float bc2,

@@ -353,11 +353,18 @@ def test_point_source_term_behind_the_all_reduce_in_one_launch(ctx, E, M, n):
             for k in (env or {}):
                 os.environ.pop(k, None)
 
-    h_direct, p_direct = run(True)
+    # default since round 4 at N >= 128: the term from separable tables INSIDE the update launch (PtsTail, csrc/joint_gm.h);
+    # LCMI_PTS_TAIL=0: the one-launch tile kernel in front of the update
+    h_tail, p_tail = run(True)
+    h_direct, p_direct = run(True, {'LCMI_PTS_TAIL': '0'})
     h_chain, p_chain = run(True, {'LCMI_PTS_CHAIN': '1'})
     h_loop, p_loop = run(False)
     scale = np.abs(h_loop).max()
     assert np.abs(h_direct - h_chain).max() <= 2e-6 * scale
+    assert np.abs(h_tail - h_direct).max() <= 5e-6 * scale
+    for k in ('a', 'c_x', 'c_y', 'dx', 'dy'):
+        ref = max(np.abs(p_loop[k]).max(), 1e-3)
+        assert np.abs(p_tail[k] - p_direct[k]).max() <= 2e-5 * ref, k
     assert np.abs(h_direct - h_loop).max() <= 2e-5 * scale
     for k in ('a', 'c_x', 'c_y', 'dx', 'dy'):
         ref = max(np.abs(p_loop[k]).max(), 1e-3)
