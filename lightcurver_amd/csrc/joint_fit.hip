@@ -245,6 +245,9 @@ const JointVariant *find_jv(int n, int ss, int E = 0, int n_cu = 0) {
       make_jv_cl<128, 2, 192, 16, 8, 16, 4, 16>(),
       // n = 128 (C5): transforms over 32 lanes (12 registers per lane like the n = 64 kernel; at 16 lanes the 24-register
       // transforms spilled 200+ registers, and 4 waves with 436 registers each measured 1.23 x slower than that)
+      // (the cluster form at this size - two to eight 8-wave workgroups per epoch in one launch - was built in round 4 and measured
+      //  slower than the phased launches: 125 epochs x 2: 292.9 against 228.7 us per iteration, 64 x 4: 208.4 / 153.3, 32 x 8:
+      //  168.8 / 116.4; 256 registers with 39 spilled, and every hand-off goes to the memory side; not instantiated)
       make_jv_gm<256, 2, 384, 8, 32>(),
   };
   for (const auto &v : table)

@@ -391,53 +391,68 @@ __device__ __forceinline__ void pts_sep_block(const PtsSepArgs &P, int pb, float
     sdgx[t] = b0 * d[m2] + b1 * d[m1] + b2 * d[v] + b1 * d[p1] + b0 * d[p2];
   }
   __syncthreads();
-  float sums[kPtsStride];
+  // Two passes over the sources, few registers (this block rides in the first launch of the regulariser chain, whose kernels
+  // must fit beside two waiting update blocks per CU: joint_reg_fused.h): first the sign pattern of the thread's pixels -
+  // it needs all sources - then source by source the three inner products, the y-direction terms evaluated again.
+  constexpr int MAXQ = 4;   // pixels per thread: N <= 256
+  const int nq = PX / NT;
+  auto yterms = [&](int u, int i, float &gy, float &sgy, float &dgy, float &sdgy) {
+    const float yc = cen + P.ss * P.cy[i];
+    float g5[5], d5[5];
 #pragma unroll
-  for (int q = 0; q < kPtsStride; ++q) sums[q] = 0.f;
-  for (int q = 0; q < PX / NT; ++q) {
-    const int k = pb * PX + q * NT + tid, u = k / N, v = k % N;
-    float gy[kMaxSources], sgy[kMaxSources], dgy[kMaxSources], sdgy[kMaxSources];
-    float Pv = 0.f, Cv = 0.f;
-#pragma unroll
-    for (int i = 0; i < kMaxSources; ++i) {
-      gy[i] = sgy[i] = dgy[i] = sdgy[i] = 0.f;
-      if (i < M) {
-        const float yc = cen + P.ss * P.cy[i];
-        float g5[5], d5[5];
-#pragma unroll
-        for (int t = -2; t <= 2; ++t) {
-          const float ty = (float)min(max(u + t, 0), N - 1) - yc;
-          g5[t + 2] = expf(-0.5f * ty * ty * inv_s2);
-          d5[t + 2] = g5[t + 2] * ty * inv_s2;
-        }
-        gy[i] = g5[2];
-        dgy[i] = d5[2];
-        sgy[i] = b0 * g5[0] + b1 * g5[1] + b2 * g5[2] + b1 * g5[3] + b0 * g5[4];
-        sdgy[i] = b0 * d5[0] + b1 * d5[1] + b2 * d5[2] + b1 * d5[3] + b0 * d5[4];
-        const float ab = abar[i] * nrm2;
-        Pv = fmaf(ab, gy[i] * gx[i * N + v], Pv);
-        Cv = fmaf(ab, sgy[i] * sgx[i * N + v], Cv);
-      }
+    for (int t = -2; t <= 2; ++t) {
+      const float ty = (float)min(max(u + t, 0), N - 1) - yc;
+      g5[t + 2] = expf(-0.5f * ty * ty * inv_s2);
+      d5[t + 2] = g5[t + 2] * ty * inv_s2;
     }
-    const float d = Pv - Cv;
-    const float lw = P.W0 ? P.lam_pts * P.W0[k] : P.lam_pts * P.norms[0];
-    const float sp = (d > 0.f) ? lw : ((d < 0.f) ? -lw : 0.f);
-    sums[3 * kMaxSources] += lw * fabsf(d);
+    gy = g5[2];
+    dgy = d5[2];
+    sgy = b0 * g5[0] + b1 * g5[1] + b2 * g5[2] + b1 * g5[3] + b0 * g5[4];
+    sdgy = b0 * d5[0] + b1 * d5[1] + b2 * d5[2] + b1 * d5[3] + b0 * d5[4];
+  };
+  float sp[MAXQ], val = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxSources; ++i) {
-      if (i < M) {
-        const float x0 = gx[i * N + v], x1 = sgx[i * N + v], x2 = dgx[i * N + v], x3 = sdgx[i * N + v];
-        sums[3 * i] += sp * nrm2 * (gy[i] * x0 - sgy[i] * x1);
-        sums[3 * i + 1] += sp * nrm2 * (gy[i] * x2 - sgy[i] * x3);
-        sums[3 * i + 2] += sp * nrm2 * (dgy[i] * x0 - sdgy[i] * x1);
+  for (int q = 0; q < MAXQ; ++q) {
+    sp[q] = 0.f;
+    if (q < nq) {
+      const int k = pb * PX + q * NT + tid, u = k / N, v = k % N;
+      float Pv = 0.f, Cv = 0.f;
+      for (int i = 0; i < M; ++i) {
+        float gy, sgy, dgy, sdgy;
+        yterms(u, i, gy, sgy, dgy, sdgy);
+        const float ab = abar[i] * nrm2;
+        Pv = fmaf(ab, gy * gx[i * N + v], Pv);
+        Cv = fmaf(ab, sgy * sgx[i * N + v], Cv);
       }
+      const float d = Pv - Cv;
+      const float lw = P.W0 ? P.lam_pts * P.W0[k] : P.lam_pts * P.norms[0];
+      sp[q] = (d > 0.f) ? lw : ((d < 0.f) ? -lw : 0.f);
+      val += lw * fabsf(d);
     }
   }
+  val = wave_sum_shfl(val);
+  if (lane == 0) red[wid][3 * kMaxSources] = val;
+  for (int i = 0; i < M; ++i) {
+    float sa = 0.f, sx = 0.f, sy = 0.f;
 #pragma unroll
-  for (int q = 0; q < kPtsStride; ++q) {
-    if (q < 3 * M || q == 3 * kMaxSources) {
-      const float t = wave_sum_shfl(sums[q]);
-      if (lane == 0) red[wid][q] = t;
+    for (int q = 0; q < MAXQ; ++q) {
+      if (q < nq) {
+        const int k = pb * PX + q * NT + tid, u = k / N, v = k % N;
+        float gy, sgy, dgy, sdgy;
+        yterms(u, i, gy, sgy, dgy, sdgy);
+        const float x0 = gx[i * N + v], x1 = sgx[i * N + v], x2 = dgx[i * N + v], x3 = sdgx[i * N + v];
+        sa += sp[q] * nrm2 * (gy * x0 - sgy * x1);
+        sx += sp[q] * nrm2 * (gy * x2 - sgy * x3);
+        sy += sp[q] * nrm2 * (dgy * x0 - sdgy * x1);
+      }
+    }
+    sa = wave_sum_shfl(sa);
+    sx = wave_sum_shfl(sx);
+    sy = wave_sum_shfl(sy);
+    if (lane == 0) {
+      red[wid][3 * i] = sa;
+      red[wid][3 * i + 1] = sx;
+      red[wid][3 * i + 2] = sy;
     }
   }
   __syncthreads();
