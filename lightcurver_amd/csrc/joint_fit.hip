@@ -115,6 +115,9 @@ struct lc_joint {
   unsigned int pts_seq = 0;
   bool pts_tail_used = false;
   bool planes_pred = false, reg_planes = false, reg_noflag = false;
+  // reg_counter: this iteration's chain ends in a launch that counts its blocks into reg_flag; defer_event: lc_joint_step_update
+  // left the cross-stream wait for the chain to launch_update, which drops it when the consumer checks the counter itself
+  bool reg_counter = false, defer_event = false, gm_flag_used = false;
   RegPlanes planes;
   bool fuse_full = false;  // lc_joint_run_adabelief, background free: reduction over the epochs and update in one launch
   bool fuse_stencil = false;  // ... and the T_e^T step too: no phase D, no slabs (global-spectrum kernels, translated epochs)
@@ -794,10 +797,12 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
         j->reg_seq += (unsigned int)(mgrid.x * mgrid.y * mgrid.z);
         j->reg_planes = true;
       } else {
-        unsigned int *done = (j->planes_pred && j->reg_flag) ? j->reg_flag : nullptr;
+        // (the completion counter also serves the multi-block update of the sharded drive, which checks it in its kernel)
+        unsigned int *done = ((j->planes_pred || j->in_sharded_loop) && j->reg_flag) ? j->reg_flag : nullptr;
         hipLaunchKernelGGL(mreg_finish3_kernel, dim3(nb + 1), dim3(kGmThreads), 0, stream, NN, nb, j->M, P, j->greg, j->regs, done);
         if (done) j->reg_seq += (unsigned int)(nb + 1);
         else j->reg_noflag = true;
+        j->reg_counter = done != nullptr;
       }
       LC_HIP(j->ctx, hipGetLastError());
       return LC_OK;
@@ -888,6 +893,19 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   const JointVariant *v = j->v;
   bool gm_pts_done = false;
   if (reg_mode == 1 && j->mreg) return launch_reg_mfma(j, stream, j->pts_pending);
+  // a cross-stream wait for the chain that lc_joint_step_update left to this function: taken here by every consumer except the
+  // multi-block update, which checks the chain's completion counter in its kernel
+  auto take_event = [&]() -> int {
+    if (j->defer_event) {
+      j->defer_event = false;
+      LC_HIP(j->ctx, hipStreamWaitEvent(stream, j->evReg, 0));
+    }
+    return LC_OK;
+  };
+  if (j->defer_event && (j->fuse_full || j->fuse_pending)) {
+    int rc = take_event();
+    if (rc) return rc;
+  }
   // Behind the chain of a sharded / step-by-step iteration (reg_mode 2) the point-source starlet term is still to do - it needs
   // the all-reduced mean fluxes.  Where the separable form applies (N >= 128) it rides INSIDE the multi-block update launch
   // (PtsTail, joint_gm.h): no launch of its own on the tail behind the all-reduce (two before: gm_pts_direct_kernel and its
@@ -908,7 +926,9 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
     if ((reg_mode == 0 && (reg_h_on(j) || want_pts)) || (reg_mode == 2 && want_pts && !gm_pts_done)) {
       // inline (gradient evaluations, step-by-step / sharded drive): the mean fluxes come from the reduced block; behind a
       // chain that has already evaluated the background part (reg_mode 2) only the point-source term is left to do
-      int rc = launch_reg_gm(j, stream, want_pts, true, reg_mode == 2);
+      int rc = take_event();
+      if (rc) return rc;
+      rc = launch_reg_gm(j, stream, want_pts, true, reg_mode == 2);
       if (rc) return rc;
       reg_mode = 2;
       gm_pts_done = want_pts;
@@ -917,7 +937,9 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
     // LDS-spectrum sizes in the sharded drive: the chain on the second stream has the background part, the point-source
     // term follows the all-reduce here - and the multi-block update takes over from the one-workgroup kernel, which would
     // evaluate everything once more by itself (95 us at N = 128)
-    int rc = launch_reg_gm(j, stream, true, true, true);
+    int rc = take_event();
+    if (rc) return rc;
+    rc = launch_reg_gm(j, stream, true, true, true);
     if (rc) return rc;
     gm_pts_done = true;
   }
@@ -1019,6 +1041,13 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
       A.shared_w = j->shared;
       nblk = 1;
     }
+    if (j->defer_event) {   // the chain's counter instead of the event
+      j->defer_event = false;
+      A.wait_flag = j->reg_flag;
+      A.wait_seq = j->reg_seq;
+      A.wait_err = j->reg_flag + 1;
+      j->gm_flag_used = true;
+    }
     PtsTail T;
     std::memset(&T, 0, sizeof(T));
     size_t dyn = 0;
@@ -1039,6 +1068,10 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
     hipLaunchKernelGGL(joint_update_gm_kernel, dim3(nblk + (pts_tail ? kPtsBlocks : 0)), dim3(kGmThreads), dyn, stream, A, j->N, T);
     LC_HIP(j->ctx, hipGetLastError());
     return LC_OK;
+  }
+  {
+    int rc = take_event();
+    if (rc) return rc;
   }
   LC_HIP(j->ctx, hipFuncSetAttribute((const void *)v->uk, hipFuncAttributeMaxDynamicSharedMemorySize, v->u_lds));
   hipLaunchKernelGGL(v->uk, dim3(1), dim3(v->u_thr), v->u_lds, stream, A);
@@ -1543,7 +1576,7 @@ int lc_joint_step_local(lc_joint *j) {
   // inside lc_joint_run_adabelief (one GPU: the mean fluxes are all local) the point-source starlet term, which depends
   // on the current a, c_x, c_y only, is evaluated with the background regulariser on the second stream
   j->pts_pending = j->in_device_loop && j->cfg.lam_pts_source != 0.f && j->M > 0;
-  j->reg_planes = j->reg_noflag = false;
+  j->reg_planes = j->reg_noflag = j->reg_counter = j->defer_event = false;
   {
     // will the fused reduction + update consume this iteration's chain (the conditions of fuse_full / fuse_stencil below, as far
     // as they are known before the epoch launch)?  Then the chain leaves its planes for that kernel to add; a wrong guess is
@@ -1628,8 +1661,12 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   const bool few_blocks = ((j->N * j->N) / kRedPix) % 2 == 0 && (j->N * j->N) / kRedPix / 2 <= 2 * j->ctx->n_cu;
   if ((rc = planes_repair(j, j->fuse_full && !j->fuse_stencil))) return rc;
   j->flag_sync = j->reg_pending && j->fuse_full && j->mreg && j->reg_flag && few_blocks && !j->reg_noflag && !std::getenv("LCMI_EVENT_SYNC");
-  if (j->reg_pending && !j->flag_sync) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
+  // (sharded drive behind a counting chain: launch_update decides - the multi-block update polls the counter in its kernel,
+  //  every other consumer gets the event wait there)
+  j->defer_event = j->reg_pending && !j->flag_sync && j->in_sharded_loop && j->reg_counter && !std::getenv("LCMI_EVENT_SYNC");
+  if (j->reg_pending && !j->flag_sync && !j->defer_event) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
   rc = launch_update(j, 1, j->iters_done, cfg, true, false, j->reg_pending ? 2 : 0);
+  j->defer_event = false;
   if (rc) return rc;
   LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
   j->reg_pending = false;
@@ -1702,6 +1739,17 @@ static int chain_check(lc_joint *j) {
 
 // Update launches that carried the point-source blocks since the last check: did block 0 give up waiting for them?
 static int pts_tail_check(lc_joint *j) {
+  if (j->gm_flag_used && j->reg_flag) {  // updates that checked the chain's completion counter themselves: did a wait run out?
+    j->gm_flag_used = false;
+    unsigned int err = 0;
+    int rc = d2h(j, &err, j->reg_flag + 1, sizeof(err));
+    if (rc) return rc;
+    if (err) {
+      const unsigned int zero = 0;
+      (void)h2d(j, j->reg_flag + 1, &zero, sizeof(zero));
+      LC_FAIL(j->ctx, LC_ERR_DEVICE, "joint fit: the regulariser of an iteration did not complete in time on the second stream (sharded loop; set LCMI_EVENT_SYNC=1)");
+    }
+  }
   if (!j->pts_ctr || !j->pts_tail_used) return LC_OK;
   j->pts_tail_used = false;
   unsigned int err = 0;

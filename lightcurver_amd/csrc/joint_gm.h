@@ -657,8 +657,12 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
   const bool use_reg = (A.reg_mode == 2);
   const float lr = A.lr, bc1 = A.bc1, bc2 = A.bc2;
   const int k = bx * blockDim.x + tid;
+  // (sharded drive: the chain's finishing launch counts its blocks into *wait_flag; checking that here spares the cross-stream
+  //  event wait in front of this launch - 5 to 7 us on the tail behind the all-reduce.  This grid is at most N^2 / 256 + 64
+  //  blocks: a chain that runs late always finds room beside it.)
+  wait_for_flag(A.wait_flag, A.wait_seq, A.wait_err);
   if (k < NN) {
-    const float g = A.shared[k] + (use_reg ? A.greg[k] : 0.f);
+    const float g = A.shared[k] + (use_reg ? ld_coherent(A.greg + k, A.wait_flag != nullptr) : 0.f);
     if (A.mode == 0 && A.gout[LC_P_H]) A.gout[LC_P_H][k] = g;
     if (A.mode == 1 && A.free_mask[LC_P_H]) {
       float hv = A.h[k], m = A.mh[k], s = A.sh[k];
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
     R.on = 1; R.J = 0; R.ntile = 0; R.npts = kPtsBlocks;
     R.S0 = R.Z = R.vals = nullptr;
     R.pts_part = T.P.part;
-    if (tid < 2) regl[tid] = use_reg ? A.regs[tid] : 0.f;
+    if (tid < 2) regl[tid] = use_reg ? ld_coherent(A.regs + tid, A.wait_flag != nullptr) : 0.f;
     planes_regs_block(R, M, regl, true, 2);
     __syncthreads();
     gm_small_blocks(A, N, lr, bc1, bc2, A.shared + NN, 3, nullptr, regl);
