@@ -1,7 +1,8 @@
 """The cluster form of the 64 x 64 epoch kernel (csrc/joint_kernels.h, PHASE = 7; include/lcmi.h lc_joint_cluster_info):
 with few epochs per GPU - a rank's share of a sharded BASELINE configs[3] fit: 25 epochs - the six phases of an epoch run
-in ONE launch on several workgroups per epoch (LCMI_CLUSTER=<P> / auto; opt-in: see cluster_parts in csrc/joint_fit.hip for
-what was measured), separated by flag syncs in device memory, the spectrum handed over through the XCD's L2 (plain stores,
+in ONE launch on several workgroups per epoch (default since round 4: six per epoch up to 32 epochs per GPU, where it pays
+beside the four-launch regulariser chain; LCMI_CLUSTER=<P> forces a count, 0 switches the form off: see cluster_parts in
+csrc/joint_fit.hip for what was measured), separated by flag syncs in device memory, the spectrum handed over through the XCD's L2 (plain stores,
 L1-bypassing loads) when the workgroups of an epoch share an XCD, through write-through stores otherwise.  Same transforms per element as the one-workgroup kernel; the
 partial sums of chi2 and of the parameter gradients are added per workgroup, then in workgroup order.
 
@@ -75,6 +76,22 @@ def test_cluster_launch_equals_the_one_workgroup_kernel(ctx, E, parts):
     np.testing.assert_array_equal(b[0], c[0])                  # fixed summation orders: bitwise repeatable
     for k in FREE:
         np.testing.assert_array_equal(b[1][k], c[1][k])
+
+
+def test_default_is_the_cluster_form_where_it_pays(ctx):
+    """Without LCMI_CLUSTER in the environment: six workgroups per epoch while 6 E + 64 workgroups fit the machine's CUs (the
+    chain of the second stream keeps its own), the one-workgroup kernel beyond - cluster_parts in csrc/joint_fit.hip has the
+    measurements behind the rule."""
+    old = os.environ.pop('LCMI_CLUSTER', None)
+    try:
+        for E, want in ((7, 6), (40, 0)):
+            ds = make_roi_dataset(E=E, M=2, n=64, ss=2, seed=104)
+            r = _fit(ctx, ds, 2, 6)
+            assert r[2] == [(want, 0)], (E, r[2])
+            assert np.all(np.isfinite(r[0])) and r[0][-1] < r[0][0]
+    finally:
+        if old is not None:
+            os.environ['LCMI_CLUSTER'] = old
 
 
 def test_cluster_launch_rotated_epochs(ctx):
