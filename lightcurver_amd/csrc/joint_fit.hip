@@ -10,6 +10,7 @@
 
 #include "joint_kernels.h"
 #include "joint_gm.h"
+#include "joint_reduce_peer.h"
 #include "joint_reg_mfma.h"
 #include "joint_reg_fused.h"
 #include "joint_reg_rows.h"
@@ -138,6 +139,10 @@ struct lc_joint {
   unsigned int chain_base = 0;
   bool chain_off = false, chain_used = false;
   bool cluster_off = false, in_sharded_loop = false;
+  // sharded loop over the library's own peer group: the reduction over the epochs publishes straight into the exchange region
+  // (joint_reduce_peer_kernel: one launch for reduction + all-reduce); peer_fused_done: this iteration's launch did both
+  lc_peer_group *peer_fuse = nullptr;
+  bool peer_fused_done = false;
   int cl_parts_last = 0, cl_fallbacks = 0;
   // return_param_history: device-resident [phist_cap][phist_P] rows of the free blocks, one per AdaBelief update
   float *phist = nullptr;
@@ -487,6 +492,20 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
 
 int launch_reduce(lc_joint *j, int need_h) {
   const int NN = j->N * j->N;
+  if (j->peer_fuse) {
+    lc_peer::PeerArgs P;
+    unsigned int *arrive = nullptr, fcall = 0;
+    int rc = lc_peer_next_call(j->peer_fuse, j->shared_count, &P, &arrive, &fcall);
+    if (rc) {
+      j->ctx->err = j->peer_fuse->ctx->err;
+      return rc;
+    }
+    hipLaunchKernelGGL(joint_reduce_peer_kernel, dim3(NN / (kRedPix * kRpTiles) + 1), dim3(kRedThreads), 0, j->ctx->stream, j->E, j->M, NN,
+                       need_h, j->HG, j->g_cx_e, j->g_cy_e, j->chi2_e, j->par[LC_P_A], j->a_ref, j->shared, P, arrive, fcall);
+    LC_HIP(j->ctx, hipGetLastError());
+    j->peer_fused_done = true;
+    return LC_OK;
+  }
   const int nimg = NN / kRedPix;
   hipLaunchKernelGGL(joint_reduce_kernel, dim3(nimg + 1), dim3(kRedThreads), 0, j->ctx->stream, j->E, j->M, NN,
                      need_h, j->HG, j->g_cx_e, j->g_cy_e, j->chi2_e, j->par[LC_P_A], j->a_ref, j->shared);
@@ -1767,9 +1786,32 @@ int lc_joint_run_sharded(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg, l
   int rc = ensure_hist(j, j->iters_done + n_iter + 2);
   const bool may_cluster = j->cl_ctr && !j->cluster_off;
   j->in_sharded_loop = true;
+  // The library's own peer group as the transport: reduction over the epochs and exchange in one launch (LCMI_PEER_FUSED=1).
+  // Only where every block of that launch is resident at once (its blocks wait for the peers' flags after publishing; see
+  // joint_reduce_peer.h), the block is whole chunks of pixels plus the scalars, and the group is this context's.
+  // OPT-IN: measured at world size 1 on MI355X it saves 0.5 us per iteration of a 25-epoch shard (69.8 against 70.3), 2.0 us
+  // at 200 epochs (91.7 / 93.7), nothing at 125 x 128 x 128 (254.4 / 254.1) - the launch it removes is paid back by the longer
+  // kernel - and with peers all of its N^2 / 64 + 1 blocks poll the peers' flags over xGMI (17 - 65 pollers in the two-launch
+  // form), which a one-GPU box cannot price.  Same bits either way (tests/test_distributed_gpu.py runs both).
+  j->peer_fuse = nullptr;
+  if (allreduce == (lc_allreduce_fn)lc_peer_allreduce && user) {
+    lc_peer_group *g = (lc_peer_group *)user;
+    const int NN = j->N * j->N;
+    const char *pf = std::getenv("LCMI_PEER_FUSED");
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, joint_reduce_peer_kernel, kRedThreads, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      per_cu = 0;
+    }
+    if (g->ctx == j->ctx && g->count == j->shared_count && NN % lc_peer::kChunk == 0 && 4 * j->M + 2 <= lc_peer::kChunk &&
+        NN / (kRedPix * kRpTiles) + 1 <= per_cu * j->ctx->n_cu && pf && std::atoi(pf) != 0)
+      j->peer_fuse = g;
+  }
   for (int it = 0; it < n_iter && !rc; ++it) {
+    j->peer_fused_done = false;
     if ((rc = lc_joint_step_local(j))) break;
-    if (allreduce(user, j->shared, j->shared_count, (void *)j->ctx->stream)) {
+    if (j->peer_fused_done) {
+    } else if (allreduce(user, j->shared, j->shared_count, (void *)j->ctx->stream)) {
       j->ctx->err = "lc_joint_run_sharded: the all-reduce callback failed";
       rc = LC_ERR_DEVICE;
       break;
@@ -1777,6 +1819,7 @@ int lc_joint_run_sharded(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg, l
     rc = lc_joint_step_update(j, cfg);
   }
   j->in_sharded_loop = false;
+  j->peer_fuse = nullptr;
   if (!rc) rc = chain_check(j);
   if (!rc) rc = pts_tail_check(j);
   if (!rc && may_cluster && j->cl_parts_last > 0) {

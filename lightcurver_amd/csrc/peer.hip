@@ -15,22 +15,11 @@
 // which the peer raises after it has finished reading the previous one - so a buffer is never rewritten while it is read.
 #include <cstring>
 
-#include "lc_common.h"
+#include "peer_shared.h"
+
+using namespace lc_peer;
 
 namespace {
-
-constexpr int kMaxPeers = 16;
-constexpr int kChunk = 1024;  // floats per workgroup (256 threads x 4)
-
-struct PeerArgs {
-  int rank, world, count, cpad, nchunks;
-  unsigned int seq;
-  float *buf;               // the block, reduced in place
-  float *xch[kMaxPeers];    // exchange region of every rank: [2][cpad] floats, then [2][nchunks] flags
-  unsigned int *err;        // local: a wait ran out
-};
-
-__device__ __forceinline__ unsigned int *peer_flags(float *base, int cpad) { return (unsigned int *)(base + 2 * (size_t)cpad); }
 
 __global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs A) {
   const int c = blockIdx.x, tid = threadIdx.x, par = (int)(A.seq & 1u);
@@ -48,31 +37,15 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs A) {
   if (tid == 0) {
     const unsigned int want = A.seq + 1u;
     __hip_atomic_store(peer_flags(A.xch[A.rank], A.cpad) + par * A.nchunks + c, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    // once a wait has run out, every later call of this rank gives up at once: a broken exchange costs one time-out, not one per call
-    int good = (__hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) ? 1 : 0;
     // exit condition every workgroup reaches: a peer that never shows up is reported, not waited for - bounded by the
     // constant 100 MHz counter (s_memrealtime; 2 s), not by a spin count whose duration depends on the clock and on the
-    // latency of the xGMI hop
-    const long long t0 = wall_clock64();
-    for (int r = 0; r < A.world && good; ++r) {
-      if (r == A.rank) continue;
-      const unsigned int *fl = peer_flags(A.xch[r], A.cpad) + par * A.nchunks + c;
-      int spins = 0;
-      while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
-        __builtin_amdgcn_s_sleep(16);
-        if ((++spins & 63) == 0 && wall_clock64() - t0 > 200000000ll) {
-          good = 0;
-          __hip_atomic_store(A.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-    // One system-scope acquire by the polling lane, behind the last successful poll and in front of the workgroup barrier that
-    // releases the readers (the consumer side of the release the peers' flag stores carry).  The readers' loads are
-    // system-scope atomics - never served from a cache of this device - so the fence orders rather than invalidates for
-    // them; it is one buffer_inv per 4 KiB chunk, 16 - 64 of them per call (measured at world size 1: no change of the
-    // sharded loop's 90 us per iteration; an agent-scope acquire by every block of the 1 000-block update cost 33 us).
-    if (good && A.world > 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    // latency of the xGMI hop.  Then one system-scope acquire by the polling lane, behind the last successful poll and in front
+    // of the workgroup barrier that releases the readers (the consumer side of the release the peers' flag stores carry).
+    // The readers' loads are system-scope atomics - never served from a cache of this device - so the fence orders rather
+    // than invalidates for them; it is one buffer_inv per 4 KiB chunk, 16 - 64 of them per call (measured at world size 1:
+    // no change of the sharded loop's 90 us per iteration; an agent-scope acquire by every block of the 1 000-block update
+    // cost 33 us).  (peer_wait_chunk, peer_shared.h)
+    const int good = peer_wait_chunk(A, c, par);
     ok = good;
   }
   __syncthreads();
@@ -93,17 +66,6 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(PeerArgs A) {
 }
 
 }  // namespace
-
-struct lc_peer_group {
-  lc_ctx *ctx = nullptr;
-  int rank = 0, world = 1, count = 0, cpad = 0, nchunks = 0;
-  unsigned int seq = 0;
-  float *own = nullptr;                 // this rank's exchange region
-  float *peer[kMaxPeers] = {};          // mapped regions (peer[rank] == own)
-  bool opened[kMaxPeers] = {};
-  unsigned int *err = nullptr;
-  size_t bytes = 0;
-};
 
 extern "C" {
 
@@ -135,6 +97,8 @@ int lc_peer_group_create(lc_ctx *ctx, int count, int rank, int world, lc_peer_gr
   }
   LC_HIP(ctx, hipMemset(g->own, 0, g->bytes));
   LC_HIP(ctx, hipMemset(g->err, 0, sizeof(unsigned int)));
+  LC_HIP(ctx, hipMalloc((void **)&g->arrive, (size_t)g->nchunks * sizeof(unsigned int)));
+  LC_HIP(ctx, hipMemset(g->arrive, 0, (size_t)g->nchunks * sizeof(unsigned int)));
   g->peer[rank] = g->own;
   *out = g;
   return LC_OK;
@@ -223,7 +187,30 @@ void lc_peer_group_destroy(lc_peer_group *g) {
     if (g->opened[r]) (void)hipIpcCloseMemHandle(g->peer[r]);
   if (g->own) (void)hipFree(g->own);
   if (g->err) (void)hipFree(g->err);
+  if (g->arrive) (void)hipFree(g->arrive);
   delete g;
 }
 
 }  // extern "C"
+
+int lc_peer_next_call(lc_peer_group *g, int count, lc_peer::PeerArgs *A, unsigned int **arrive, unsigned int *fcall) {
+  if (!g || !A || !arrive || !fcall) return LC_ERR_INVALID;
+  LC_ENTER(g->ctx);
+  if (count != g->count) LC_FAIL(g->ctx, LC_ERR_INVALID, "peer exchange: the group was created for another block length");
+  for (int r = 0; r < g->world; ++r)
+    if (!g->peer[r]) LC_FAIL(g->ctx, LC_ERR_INVALID, "peer exchange: lc_peer_group_connect has not mapped every peer");
+  std::memset(A, 0, sizeof(*A));
+  A->rank = g->rank;
+  A->world = g->world;
+  A->count = g->count;
+  A->cpad = g->cpad;
+  A->nchunks = g->nchunks;
+  A->seq = g->seq;
+  for (int r = 0; r < g->world; ++r) A->xch[r] = g->peer[r];
+  A->err = g->err;
+  *arrive = g->arrive;
+  *fcall = g->fcalls;
+  g->seq += 1;
+  g->fcalls += 1;
+  return LC_OK;
+}

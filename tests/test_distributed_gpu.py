@@ -119,21 +119,28 @@ def test_two_hip_ranks_equal_the_unsharded_fit(ctx, tmp_path):
     pf, hf = full.get_params(), full.loss_history()
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_sharded_hip_worker.py')
     results = {}
-    for transport in ('gloo', 'peer'):
+    # 'peer_fused': the same transport with the reduction over the epochs and the exchange in ONE launch (LCMI_PEER_FUSED=1,
+    # csrc/joint_reduce_peer.h; opt-in)
+    for transport in ('gloo', 'peer', 'peer_fused'):
         out = tmp_path / f'sharded_{transport}.npz'
         for attempt in range(2):   # (a probed port can be taken before the ranks bind it: one more try with another port)
             port = _free_port()
             procs = []
             for r in range(2):
                 env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                           HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-                procs.append(subprocess.Popen([sys.executable, worker, str(out), str(E), str(M), str(n), str(T), transport], env=env))
+                           HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+                           LCMI_PEER_FUSED='1' if transport == 'peer_fused' else '0')
+                procs.append(subprocess.Popen([sys.executable, worker, str(out), str(E), str(M), str(n), str(T),
+                                               transport.split('_')[0]], env=env))
             codes = [pr.wait(timeout=600) for pr in procs]
             if codes == [0, 0]:
                 break
         assert codes == [0, 0], (transport, codes)
         results[transport] = np.load(out)
     g, gp = results['gloo'], results['peer']
+    for k in g.files:
+        if k not in ('transport', 'device_collective'):
+            np.testing.assert_array_equal(results['peer_fused'][k], g[k], err_msg='fused: ' + k)
     assert not bool(g['device_collective'])   # gloo staging here; the RCCL path is the world-size-1 test above
     assert str(g['transport']) == 'gloo' and str(gp['transport']) == 'peer'
     # the one-shot peer-memory all-reduce (each rank reads the other's block through HIP IPC and adds in rank order) gives
