@@ -115,6 +115,12 @@ struct lc_joint {
   unsigned int *pts_ctr = nullptr;   // [0] arrival counter of the point-source blocks inside the update launch, [1] a wait ran out
   unsigned int pts_seq = 0;
   bool pts_tail_used = false;
+  // "the update is complete" word ([0]: sequence number stored by the first thread of the following epoch launch; [1]: a gate
+  // wait ran out) and its host-side value; upd_gate_pending: no event was recorded for the last update (the next chain starts
+  // behind a gate kernel); upd_signal_due: a gate is waiting for the next epoch launch to raise the word
+  unsigned int *upd_ctr = nullptr;
+  unsigned int upd_seq = 0;
+  bool upd_gate_pending = false, upd_gate_used = false, upd_signal_due = false;
   bool planes_pred = false, reg_planes = false, reg_noflag = false;
   // reg_counter: this iteration's chain ends in a launch that counts its blocks into reg_flag; defer_event: lc_joint_step_update
   // left the cross-stream wait for the chain to launch_update, which drops it when the consumer checks the counter itself
@@ -402,6 +408,11 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   A.group = j->group_dev;
   A.skip_D = (mode == 0 && j->fuse_stencil) ? 1 : 0;
   A.tshift = j->tshift;
+  if (j->upd_signal_due && !ps_stream) {   // the first launch below opens the gate of this iteration's chain
+    A.upd_signal = j->upd_ctr;
+    A.upd_value = j->upd_seq;
+    j->upd_signal_due = false;
+  }
   // no background in the scene: separable Gaussian filtering of the epoch PSFs instead of the FFT pipeline
   if (!A.h_active && j->M > 0 && j->psf_dev && !std::getenv("LCMI_JOINT_FFT_ONLY")) {
     ps_fn pk = nullptr;
@@ -423,6 +434,8 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
       }
       if (e1 < 0) e1 = j->E;
       P.e_off = e0;
+      if (A.upd_signal)   // (this kernel does not raise the word itself)
+        hipLaunchKernelGGL(mreg_signal_kernel, dim3(1), dim3(64), 0, j->ctx->stream, A.upd_signal, A.upd_value);
       hipLaunchKernelGGL(pk, dim3(e1 - e0), dim3(kPsThreads), plds, ps_stream ? ps_stream : j->ctx->stream, P);
       LC_HIP(j->ctx, hipGetLastError());
       return 0;
@@ -476,6 +489,7 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
       const int np = col ? parts_col : parts;
       LC_HIP(j->ctx, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
       hipLaunchKernelGGL(pk, dim3(j->E, np), dim3(v->e_thr), plds, j->ctx->stream, A);
+      A.upd_signal = nullptr;   // (the first phase's launch has raised the word)
     }
     if (!(A.h_active && A.need_hgrad) || A.skip_D)  // (phase D's first workgroup of an epoch adds up the partial sums otherwise)
       hipLaunchKernelGGL(joint_epoch_finish_kernel, dim3(j->E), dim3(64), 0, j->ctx->stream, A, j->ss, parts);
@@ -906,6 +920,13 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
   return LC_OK;
 }
 
+// May the event behind an update be left out?  Inside the library's loops, on the main stream, where its only reader is the
+// next iteration's chain, which can start behind a gate kernel instead (LCMI_UPD_EVENT=1: the event, the cross-check; the
+// third stream of LCMI_PTS_SIDE waits for the event too).
+static bool upd_gate_ok(const lc_joint *j, hipStream_t stream) {
+  return j->upd_ctr && (j->in_device_loop || j->in_sharded_loop) && stream == j->ctx->stream && !std::getenv("LCMI_UPD_EVENT") &&
+         !std::getenv("LCMI_PTS_SIDE");
+}
 int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, bool write_hist, bool all_grads,
                   int reg_mode = 0, hipStream_t stream = nullptr) {
   if (!stream) stream = j->ctx->stream;
@@ -1274,6 +1295,7 @@ static int joint_create_impl(lc_ctx *ctx, int E, int M, int n, int ss, const flo
     TRY(dmalloc(j, &j->mr_pbar, NN));
     if (j->mreg->rows) TRY(dmalloc(j, &j->rr_Zp, (size_t)(N / kRrRows) * kRrMaxParts * NN));
     TRY(dmalloc(j, &j->pts_ctr, 4));
+    TRY(dmalloc(j, &j->upd_ctr, 4));
     TRY(dmalloc(j, &j->reg_flag, 4));  // [0] completion flag, [1] a wait ran out, [2] ticket of the finishing launch
     LC_HIP(ctx, hipFuncSetAttribute((const void *)j->mreg->fwd, hipFuncAttributeMaxDynamicSharedMemorySize, j->mreg->lds_fwd));
     LC_HIP(ctx, hipFuncSetAttribute((const void *)j->mreg->adj, hipFuncAttributeMaxDynamicSharedMemorySize, j->mreg->lds_adj));
@@ -1608,7 +1630,16 @@ int lc_joint_step_local(lc_joint *j) {
   if (reg_h_on(j) || j->pts_pending) {
     // starlet l1 + positivity of h depend on h alone: evaluate them on a second stream while the epoch
     // kernel (which leaves CUs idle whenever E < 256) runs; the update kernel joins the two
-    LC_HIP(j->ctx, hipStreamWaitEvent(j->streamB, j->evUpd, 0));
+    // the chain reads what the previous update wrote: behind that update's completion counter (a one-wave gate kernel at the
+    // head of this stream) when the update counted itself in, behind its event otherwise
+    if (j->upd_gate_pending) {
+      j->upd_seq += 1;
+      hipLaunchKernelGGL(mreg_gate_kernel, dim3(1), dim3(64), 0, j->streamB, j->upd_ctr, j->upd_seq, j->upd_ctr + 1);
+      j->upd_gate_used = true;
+      j->upd_signal_due = true;   // (the epoch launch below raises the word)
+    } else {
+      LC_HIP(j->ctx, hipStreamWaitEvent(j->streamB, j->evUpd, 0));
+    }
     if (j->tl_events) (void)hipEventRecord(j->tl_events[1], j->streamB);
     int rc = launch_update(j, 0, 0, nullptr, false, false, 1, j->streamB);
     if (rc) return rc;
@@ -1687,7 +1718,10 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   rc = launch_update(j, 1, j->iters_done, cfg, true, false, j->reg_pending ? 2 : 0);
   j->defer_event = false;
   if (rc) return rc;
-  LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
+  // (inside the library's loops no event: the record would sit between this update and the next epoch kernel on this stream,
+  //  4.7 - 6 us of every iteration; the next chain starts behind a gate kernel that the next epoch launch opens)
+  j->upd_gate_pending = upd_gate_ok(j, j->ctx->stream);
+  if (!j->upd_gate_pending) LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
   j->reg_pending = false;
   j->fuse_pending = false;
   j->fuse_full = false;
@@ -1757,6 +1791,23 @@ static int chain_check(lc_joint *j) {
 }
 
 // Update launches that carried the point-source blocks since the last check: did block 0 give up waiting for them?
+// End of a library loop: later calls order themselves behind the last update through its event again; a gate that gave up
+// waiting means the chain of some iteration may have read a half-written background.
+static int upd_gate_finish(lc_joint *j) {
+  if (j->upd_gate_pending) {
+    j->upd_gate_pending = false;
+    LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
+  }
+  if (!j->upd_gate_used || !j->upd_ctr) return LC_OK;
+  j->upd_gate_used = false;
+  LC_HIP(j->ctx, hipStreamSynchronize(j->streamB));
+  unsigned int err = 0;
+  int rc = d2h(j, &err, j->upd_ctr + 1, sizeof(err));
+  if (rc || !err) return rc;
+  const unsigned int zero = 0;
+  (void)h2d(j, j->upd_ctr + 1, &zero, sizeof(zero));
+  LC_FAIL(j->ctx, LC_ERR_DEVICE, "joint fit: the regulariser chain of an iteration gave up waiting for the previous update; this run's numbers are invalid (LCMI_UPD_EVENT=1 selects the event)");
+}
 static int pts_tail_check(lc_joint *j) {
   if (j->gm_flag_used && j->reg_flag) {  // updates that checked the chain's completion counter themselves: did a wait run out?
     j->gm_flag_used = false;
@@ -1820,6 +1871,10 @@ int lc_joint_run_sharded(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg, l
   }
   j->in_sharded_loop = false;
   j->peer_fuse = nullptr;
+  {
+    const int rg = upd_gate_finish(j);
+    if (!rc) rc = rg;
+  }
   if (!rc) rc = chain_check(j);
   if (!rc) rc = pts_tail_check(j);
   if (!rc && may_cluster && j->cl_parts_last > 0) {
@@ -2203,11 +2258,16 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
       j->iters_done = it0;
       j->phist_rows = ph0;
       j->reg_pending = j->fuse_pending = j->fuse_full = j->pts_pending = false;
+      j->upd_gate_pending = false;   // (the event recorded above orders the next chain)
       goto redo;
     }
   }
   j->in_device_loop = false;
   j->flag_sync = false;
+  {
+    const int rg = upd_gate_finish(j);
+    if (!rc) rc = rg;
+  }
   if (!rc) rc = chain_check(j);
   if (!rc && flags_used) {  // an update that gave up waiting for its regulariser would have used stale numbers: report it
     unsigned int err = 0;

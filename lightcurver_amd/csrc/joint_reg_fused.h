@@ -246,6 +246,27 @@ __global__ __launch_bounds__(kMmThreads) void mreg_mmx_kernel(MmxArgs Q) {
   }
 }
 
+// Head of the chain's stream inside the library's loops: one wave polls the word in which the first thread of the epoch launch
+// announces that the update before it is complete (JointArgs::upd_signal), and ends; the chain's first launch follows it in
+// stream order.  Replaces the cross-stream wait for an event that the main stream had to record between the update and the
+// next epoch kernel.  Bounded (~1 s): a wait that runs out is reported.
+__global__ void mreg_gate_kernel(const unsigned int *word, unsigned int target, unsigned int *err) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(16);
+      if (++spins > (1 << 21)) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+}
+// (where no epoch kernel follows - the point-source-only kernel - the signal is a launch of its own)
+__global__ void mreg_signal_kernel(unsigned int *word, unsigned int value) {
+  if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // For the consumers that take greg / regs: greg = S_0 + sum_s Z_s (blocks < nb), regs from the per-tile values (block nb).
 // done: completion counter of the chain (every block adds one; the stores before it write-through) when the consumer checks
 // it in its kernel - the fused update beside a one-workgroup epoch kernel, where the chain has time to spare and the update
