@@ -924,8 +924,10 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
 // next iteration's chain, which can start behind a gate kernel instead (LCMI_UPD_EVENT=1: the event, the cross-check; the
 // third stream of LCMI_PTS_SIDE waits for the event too).
 static bool upd_gate_ok(const lc_joint *j, hipStream_t stream) {
+  // (LCMI_EVENT_SYNC=1 - what counter collection sets, which runs one kernel at a time: a gate kernel alone on the machine
+  //  would wait for an epoch kernel that cannot start - keeps the event as well)
   return j->upd_ctr && (j->in_device_loop || j->in_sharded_loop) && stream == j->ctx->stream && !std::getenv("LCMI_UPD_EVENT") &&
-         !std::getenv("LCMI_PTS_SIDE");
+         !std::getenv("LCMI_EVENT_SYNC") && !std::getenv("LCMI_PTS_SIDE");
 }
 int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, bool write_hist, bool all_grads,
                   int reg_mode = 0, hipStream_t stream = nullptr) {
@@ -1065,7 +1067,7 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
         LC_HIP(j->ctx, hipGetLastError());
         return LC_OK;
       }
-      int tiles = j->flag_sync ? 2 : (NN / kRedPix >= 4096 ? 4 : 1);
+      int tiles = (NN / kRedPix >= 4096) ? 4 : (j->flag_sync ? 2 : 1);
       if (const char *tl = std::getenv("LCMI_UPDATE_TILES")) tiles = std::min(std::max(1, std::atoi(tl)), kUpdMaxTiles);
       if ((NN / kRedPix) % tiles) tiles = 1;
       const int nimg = NN / kRedPix / tiles;
@@ -1710,7 +1712,12 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   // per lane and SIMD), next to which every kernel of the chain fits
   const bool few_blocks = ((j->N * j->N) / kRedPix) % 2 == 0 && (j->N * j->N) / kRedPix / 2 <= 2 * j->ctx->n_cu;
   if ((rc = planes_repair(j, j->fuse_full && !j->fuse_stencil))) return rc;
-  j->flag_sync = j->reg_pending && j->fuse_full && j->mreg && j->reg_flag && few_blocks && !j->reg_noflag && !std::getenv("LCMI_EVENT_SYNC");
+  // (LCMI_FLAG_SYNC_ALL=1: the flag form at 256 x 256 too, where the update has more blocks than fit the machine at once.
+  //  Measured: a chain held back by 600 us is still scheduled beside the waiting blocks and the numbers are those of the event
+  //  form, but the gain is small - C5 shard 222.6 -> 221.8 us, 32 epochs 111.5 -> 108.6 - and how the dispatcher treats a second
+  //  queue while one kernel has hundreds of blocks pending is nothing this code can guarantee: opt-in.)
+  const bool all_sizes = std::getenv("LCMI_FLAG_SYNC_ALL") != nullptr;
+  j->flag_sync = j->reg_pending && j->fuse_full && j->mreg && j->reg_flag && (few_blocks || all_sizes) && !j->reg_noflag && !std::getenv("LCMI_EVENT_SYNC");
   // (sharded drive behind a counting chain: launch_update decides - the multi-block update polls the counter in its kernel,
   //  every other consumer gets the event wait there)
   j->defer_event = j->reg_pending && !j->flag_sync && j->in_sharded_loop && j->reg_counter && !std::getenv("LCMI_EVENT_SYNC");
