@@ -121,6 +121,9 @@ struct lc_joint {
   unsigned int *upd_ctr = nullptr;
   unsigned int upd_seq = 0;
   bool upd_gate_pending = false, upd_gate_used = false, upd_signal_due = false;
+  // epoch_wait_due: this iteration's chain ends in a counting launch and the epoch launch may carry the wait for it (an extra
+  // block: JointArgs::chain_flag); epoch_waited: it did - the update behind it needs no synchronisation of its own
+  bool epoch_wait_due = false, epoch_waited = false, epoch_wait_used = false;
   bool planes_pred = false, reg_planes = false, reg_noflag = false;
   // reg_counter: this iteration's chain ends in a launch that counts its blocks into reg_flag; defer_event: lc_joint_step_update
   // left the cross-stream wait for the chain to launch_update, which drops it when the consumer checks the counter itself
@@ -408,6 +411,16 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   A.group = j->group_dev;
   A.skip_D = (mode == 0 && j->fuse_stencil) ? 1 : 0;
   A.tshift = j->tshift;
+  // the LAST launch below carries the wait for this iteration's chain (one extra block), where one is due
+  const bool carry_wait = j->epoch_wait_due && !ps_stream && mode == 0;
+  j->epoch_wait_due = false;
+  auto attach_wait = [&](int wait_block) {
+    A.chain_flag = j->reg_flag;
+    A.chain_seq = j->reg_seq;
+    A.chain_err = j->reg_flag + 1;
+    A.wait_block = wait_block;
+    j->epoch_waited = j->epoch_wait_used = true;
+  };
   if (j->upd_signal_due && !ps_stream) {   // the first launch below opens the gate of this iteration's chain
     A.upd_signal = j->upd_ctr;
     A.upd_value = j->upd_seq;
@@ -456,7 +469,8 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
     A.cl_parts = P;
     const int groups = (j->E + 7) / 8;
     LC_HIP(j->ctx, hipFuncSetAttribute((const void *)v->ek_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, v->cl_lds));
-    hipLaunchKernelGGL(v->ek_cluster, dim3(8 * groups * P), dim3(v->cl_thr), v->cl_lds, j->ctx->stream, A);
+    if (carry_wait) attach_wait(8 * groups * P);
+    hipLaunchKernelGGL(v->ek_cluster, dim3(8 * groups * P + (carry_wait ? 1 : 0)), dim3(v->cl_thr), v->cl_lds, j->ctx->stream, A);
     LC_HIP(j->ctx, hipGetLastError());
     j->cl_base += (unsigned int)kClBarriers;
     j->cl_parts_last = P;
@@ -488,7 +502,9 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
       const int plds = lite ? (tl ? v->e_lds_lite_tile : v->e_lds_lite) : v->e_lds;
       const int np = col ? parts_col : parts;
       LC_HIP(j->ctx, hipFuncSetAttribute((const void *)pk, hipFuncAttributeMaxDynamicSharedMemorySize, plds));
-      hipLaunchKernelGGL(pk, dim3(j->E, np), dim3(v->e_thr), plds, j->ctx->stream, A);
+      const bool last = (ph == 5) && carry_wait;
+      if (last) attach_wait(j->E);
+      hipLaunchKernelGGL(pk, dim3(j->E + (last ? 1 : 0), np), dim3(v->e_thr), plds, j->ctx->stream, A);
       A.upd_signal = nullptr;   // (the first phase's launch has raised the word)
     }
     if (!(A.h_active && A.need_hgrad) || A.skip_D)  // (phase D's first workgroup of an epoch adds up the partial sums otherwise)
@@ -499,7 +515,8 @@ int launch_epochs(lc_joint *j, int mode, int isrc, bool want_hgrad, float *model
   epoch_fn ek = tile ? v->ek_tile : v->ek;
   const int e_lds = tile ? v->e_lds_tile : v->e_lds;
   LC_HIP(j->ctx, hipFuncSetAttribute((const void *)ek, hipFuncAttributeMaxDynamicSharedMemorySize, e_lds));
-  hipLaunchKernelGGL(ek, dim3(j->E), dim3(v->e_thr), e_lds, j->ctx->stream, A);
+  if (carry_wait) attach_wait(j->E);
+  hipLaunchKernelGGL(ek, dim3(j->E + (carry_wait ? 1 : 0)), dim3(v->e_thr), e_lds, j->ctx->stream, A);
   LC_HIP(j->ctx, hipGetLastError());
   return A.need_hgrad;
 }
@@ -1620,6 +1637,7 @@ int lc_joint_step_local(lc_joint *j) {
   // on the current a, c_x, c_y only, is evaluated with the background regulariser on the second stream
   j->pts_pending = j->in_device_loop && j->cfg.lam_pts_source != 0.f && j->M > 0;
   j->reg_planes = j->reg_noflag = j->reg_counter = j->defer_event = false;
+  j->epoch_wait_due = j->epoch_waited = false;
   {
     // will the fused reduction + update consume this iteration's chain (the conditions of fuse_full / fuse_stencil below, as far
     // as they are known before the epoch launch)?  Then the chain leaves its planes for that kernel to add; a wrong guess is
@@ -1648,6 +1666,14 @@ int lc_joint_step_local(lc_joint *j) {
     if (j->tl_events) (void)hipEventRecord(j->tl_events[2], j->streamB);
     LC_HIP(j->ctx, hipEventRecord(j->evReg, j->streamB));
     j->reg_pending = true;
+    // Inside the library's loops, behind a chain whose last launch counts itself into reg_flag: the epoch launch carries the
+    // wait for the chain (JointArgs::chain_flag) - where the chain is expected to be done well before the epochs are.  Measured
+    // (us per iteration, with / without): C4 66.9 / 68.7, C5 shard 223.3 / 225.6, 1000 x 128 x 128 1541 / 1548; NOT beside the
+    // cluster form, whose chain ends about when the epoch kernel does (the update's own poll overlaps its slab loads with
+    // the chain's tail: 25 epochs 53.1 / 52.8), and not for few epochs of 128 x 128 (32 epochs: 114.5 / 112.2).
+    j->epoch_wait_due = (j->in_device_loop || j->in_sharded_loop) && (j->reg_planes || j->reg_counter) && j->reg_flag &&
+                        cluster_parts(j) == 0 && (j->N <= 128 || j->E >= 64) &&
+                        !std::getenv("LCMI_EVENT_SYNC") && !std::getenv("LCMI_EPOCH_WAIT_OFF");
   }
   const bool gm_update = !j->v->uk || ((j->cfg.lam_pts_source == 0.f || j->pts_pending) && (j->reg_pending || !reg_h_on(j)));
   // global-spectrum kernels, every epoch a translation, reduction and update fused: the reduction can apply T_e^T itself
@@ -1717,11 +1743,13 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   //  form, but the gain is small - C5 shard 222.6 -> 221.8 us, 32 epochs 111.5 -> 108.6 - and how the dispatcher treats a second
   //  queue while one kernel has hundreds of blocks pending is nothing this code can guarantee: opt-in.)
   const bool all_sizes = std::getenv("LCMI_FLAG_SYNC_ALL") != nullptr;
-  j->flag_sync = j->reg_pending && j->fuse_full && j->mreg && j->reg_flag && (few_blocks || all_sizes) && !j->reg_noflag && !std::getenv("LCMI_EVENT_SYNC");
+  j->flag_sync = j->reg_pending && !j->epoch_waited && j->fuse_full && j->mreg && j->reg_flag && (few_blocks || all_sizes) && !j->reg_noflag && !std::getenv("LCMI_EVENT_SYNC");
   // (sharded drive behind a counting chain: launch_update decides - the multi-block update polls the counter in its kernel,
   //  every other consumer gets the event wait there)
-  j->defer_event = j->reg_pending && !j->flag_sync && j->in_sharded_loop && j->reg_counter && !std::getenv("LCMI_EVENT_SYNC");
-  if (j->reg_pending && !j->flag_sync && !j->defer_event) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
+  if (j->epoch_waited) j->gm_flag_used = true;   // (its error word is checked at the end of the loop)
+  j->defer_event = j->reg_pending && !j->epoch_waited && !j->flag_sync && j->in_sharded_loop && j->reg_counter && !std::getenv("LCMI_EVENT_SYNC");
+  // (epoch_waited: the epoch launch of this iteration ended only when the chain had - nothing to wait for here)
+  if (j->reg_pending && !j->epoch_waited && !j->flag_sync && !j->defer_event) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
   rc = launch_update(j, 1, j->iters_done, cfg, true, false, j->reg_pending ? 2 : 0);
   j->defer_event = false;
   if (rc) return rc;
@@ -2236,7 +2264,7 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
       (void)hipEventRecord(tl[4], j->ctx->stream);
       j->tl_events = nullptr;
     }
-    flags_used = flags_used || j->flag_sync;
+    flags_used = flags_used || j->flag_sync || j->epoch_waited;
   }
   if (tl_it >= 0 && !rc) {
     (void)hipStreamSynchronize(j->ctx->stream);

@@ -72,6 +72,15 @@ struct JointArgs {
   // polling against 514 atomic additions on the same word.)
   unsigned int *upd_signal;
   unsigned int upd_value;
+  // ... and in the other direction: the update behind this launch needs the chain's results.  One EXTRA block of the launch
+  // (blockIdx.x == wait_block) does nothing but poll the chain's completion word - so this launch is complete only when the
+  // chain is, and the update needs neither a cross-stream event wait in front of it (6.2 us in the rocprofv3 timeline of the
+  // C5 shard) nor a poll and cache-bypassing loads of its own.  The block holds one wave slot while it waits (bounded, ~1 s:
+  // *chain_err); the chain is normally long done when the epoch's last phase starts.
+  const unsigned int *chain_flag;
+  unsigned int chain_seq;
+  unsigned int *chain_err;
+  int wait_block;
 };
 constexpr int kClStride = 32;    // flag words per epoch (one 128-byte line; kMaxParts <= 16 of them in use)
 constexpr int kClBarriers = 6;   // start | A | B | C | B' | C' | D: every cluster launch passes exactly six syncs
@@ -305,6 +314,19 @@ __global__ __launch_bounds__(C::NTHR) void joint_epoch_kernel(JointArgs A) {
   static_assert(PHASE == 0 || (C::GSPEC && !AUX), "one phase per launch: spectrum in global memory");
   if (A.upd_signal && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)   // (JointArgs: the update before this launch is complete)
     __hip_atomic_store(A.upd_signal, A.upd_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (A.chain_flag && (int)blockIdx.x == A.wait_block) {   // (JointArgs: the extra block that waits for the regulariser chain)
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+      int spins = 0;
+      while ((int)(__hip_atomic_load(A.chain_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.chain_seq) < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > (1 << 21)) {
+          __hip_atomic_store(A.chain_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    return;
+  }
   // PHASE = 7, the CLUSTER form: all six phases in ONE launch by `cl_parts` workgroups per epoch that share the phases' rows /
   // columns / pixels exactly as the phased launches do, with an arrival counter per epoch where those have a launch boundary
   // (cluster_sync) and the spectrum handed over through write-through stores and L1-bypassing loads (xwg_*).  Built for
