@@ -134,6 +134,23 @@ def test_flag_synchronised_update_equals_the_event_synchronised_one(ctx):
         np.testing.assert_array_equal(a[1][k], b[1][k])
 
 
+@pytest.mark.parametrize('E,n,M', [(8, 64, 2), (40, 64, 2), (3, 128, 4), (5, 32, 2)])
+def test_loop_synchronisation_forms_give_the_same_bits(ctx, E, n, M):
+    """How the two streams of the device loop tell each other where they are changes no arithmetic: the regulariser chain of
+    an iteration starts behind a gate kernel that the next epoch launch opens (default) or behind an event recorded after the
+    update (LCMI_UPD_EVENT=1); the update learns that the chain is complete from an extra block of the epoch launch that waits
+    for it (default where the chain is the shorter path) or from its own poll / an event wait (LCMI_EPOCH_WAIT_OFF=1); all of
+    it as events (LCMI_EVENT_SYNC=1).  Identical histories and parameters."""
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=104)
+    a = _fit(ctx, ds, M, 20)
+    for env in ({'LCMI_UPD_EVENT': '1'}, {'LCMI_EPOCH_WAIT_OFF': '1'}, {'LCMI_EVENT_SYNC': '1'}):
+        b = _fit(ctx, ds, M, 20, env=env)
+        np.testing.assert_array_equal(a[0], b[0], err_msg=str(env))
+        for k in ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'):
+            np.testing.assert_array_equal(a[1][k], b[1][k], err_msg=str(env) + k)
+    assert a[0][-1] < a[0][0]
+
+
 @pytest.mark.parametrize('E,n,M,free', [(7, 32, 1, ('a', 'dx', 'dy', 'mean')), (5, 16, 2, ('a', 'mean')), (3, 64, 1, ('a', 'dx', 'dy'))])
 def test_persistent_star_photometry_loop_equals_the_launch_per_iteration_one(ctx, E, n, M, free):
     """Photometry at fixed positions (no background, only per-epoch parameters free, nothing coupling the epochs): the whole
