@@ -989,7 +989,12 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         else __hip_atomic_store(A.xflags + f * 2 + role, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 1, spins = 0;
         while (__hip_atomic_load(A.xflags + f * 2 + (1 - role), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it + 1) {
-          __builtin_amdgcn_s_sleep(2);
+          // (the interval between polls is no lever: s_sleep 0 / 2 / 6 / 14 measured at 14.8 - 15.0 us per iteration of C2 and
+          //  82.2 - 83.0 of the C3 shard, all within the run-to-run spread; -DLC_XPOLL_SLEEP=<n> for an A/B build)
+#ifndef LC_XPOLL_SLEEP
+#define LC_XPOLL_SLEEP 2
+#endif
+          __builtin_amdgcn_s_sleep(LC_XPOLL_SLEEP);
           ++spins;
           // exit condition every workgroup reaches: a partner that never shows up is reported, not waited for
           if (spins > (1 << 21) ||
