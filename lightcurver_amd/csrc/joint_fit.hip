@@ -354,7 +354,8 @@ void find_ps_kernel(int N, int ss, ps_fn *fn, int *lds, bool persist = false) {
 // DEFAULT ("auto", also when LCMI_CLUSTER is unset) since then: six workgroups per epoch whenever they leave kChainBlocks CUs
 // to the chain (6 E + 64 <= CUs: up to 32 epochs - a rank's share of a sharded C4).  Not beyond: clusters that fill the
 // machine starve the chain (42 epochs x 6: 87.5 us, 50 x 5: 101.9, 85 x 3: 122.5), and fewer workgroups per epoch gain
-// little or lose (36 x 5: 64.1, 40 x 4: 64.0, 56 x 3: 72.8, 80 x 2: 85.9 against 65 - 67 us).  LCMI_CLUSTER=0 switches the
+// little or lose (36 x 5: 64.1, 40 x 4: 64.0, 56 x 3: 72.8, 80 x 2: 85.9 against 65 - 67 us; again after the event behind the
+// update had gone: 34 x 5: 60.1, 40 x 4: 60.0, 48 x 4: 60.3, 56 x 3: 70.9 against 60.7 - 61.7).  LCMI_CLUSTER=0 switches the
 // form off, LCMI_CLUSTER=<P> forces P workgroups per epoch (as many as fit one per CU).
 int cluster_parts(const lc_joint *j) {
   const JointVariant *v = j->v;
