@@ -323,7 +323,7 @@ int launch_psf(lc_psf_batch *b, int mode, int n_iter, const lc_adabelief_cfg *cf
     if (!b->xch) {
       int rc = dmalloc(b, &b->xch, (size_t)b->F * 4 * ((size_t)b->N * b->N + 64));
       if (rc) return rc;
-      if ((rc = dmalloc(b, &b->xflags, (size_t)b->F * 2 + 16))) return rc;
+      if ((rc = dmalloc(b, &b->xflags, (size_t)b->F * 2 * kXFlagStride + 16))) return rc;
       if ((rc = dmalloc(b, &b->B1, FNN)) || (rc = dmalloc(b, &b->mB1, FNN)) || (rc = dmalloc(b, &b->sB1, FNN))) return rc;
       if ((rc = dmalloc(b, &b->bkB, FNN)) || (rc = dmalloc(b, &b->bkmB, FNN)) || (rc = dmalloc(b, &b->bksB, FNN)) ||
           (rc = dmalloc(b, &b->bkstars, FS4)) || (rc = dmalloc(b, &b->bkstars_m, FS4)) || (rc = dmalloc(b, &b->bkstars_s, FS4)))
@@ -331,7 +331,7 @@ int launch_psf(lc_psf_batch *b, int mode, int n_iter, const lc_adabelief_cfg *cf
     }
     hipStream_t q = b->ctx->stream;
     // the 2F iteration flags restart at zero; the abort word and the fall-back counter behind them are never cleared
-    LC_HIP(b->ctx, hipMemsetAsync(b->xflags, 0, (size_t)b->F * 2 * sizeof(int), q));
+    LC_HIP(b->ctx, hipMemsetAsync(b->xflags, 0, (size_t)b->F * 2 * kXFlagStride * sizeof(int), q));
     // pre-launch state, for the fall-back launch
     LC_HIP(b->ctx, hipMemcpyAsync(b->bkB, b->B, FNN * sizeof(float), hipMemcpyDeviceToDevice, q));
     LC_HIP(b->ctx, hipMemcpyAsync(b->bkmB, b->mB, FNN * sizeof(float), hipMemcpyDeviceToDevice, q));
@@ -341,8 +341,8 @@ int launch_psf(lc_psf_batch *b, int mode, int n_iter, const lc_adabelief_cfg *cf
     LC_HIP(b->ctx, hipMemcpyAsync(b->bkstars_s, b->stars_s, FS4 * sizeof(float), hipMemcpyDeviceToDevice, q));
     A.xch = b->xch;
     A.xflags = b->xflags;
-    A.xabort = b->xflags + (size_t)b->F * 2;
-    A.heal_count = b->xflags + (size_t)b->F * 2 + 1;
+    A.xabort = b->xflags + (size_t)b->F * 2 * kXFlagStride;
+    A.heal_count = b->xflags + (size_t)b->F * 2 * kXFlagStride + 1;
     A.B1 = b->B1;
     A.mB1 = b->mB1;
     A.sB1 = b->sB1;
@@ -376,7 +376,7 @@ int launch_psf(lc_psf_batch *b, int mode, int n_iter, const lc_adabelief_cfg *cf
 int read_split_fallbacks(lc_psf_batch *b, int *count) {
   *count = 0;
   if (!b->split_used) return LC_OK;
-  LC_HIP(b->ctx, hipMemcpyAsync(count, b->xflags + (size_t)b->F * 2 + 1, sizeof(int), hipMemcpyDeviceToHost, b->ctx->stream));
+  LC_HIP(b->ctx, hipMemcpyAsync(count, b->xflags + (size_t)b->F * 2 * kXFlagStride + 1, sizeof(int), hipMemcpyDeviceToHost, b->ctx->stream));
   LC_HIP(b->ctx, hipStreamSynchronize(b->ctx->stream));
   return LC_OK;
 }

@@ -13,7 +13,14 @@
 #include "lc_common.h"
 #include "starlet_device.h"
 
+#ifndef LC_XPOLL_SLEEP
+#define LC_XPOLL_SLEEP 2
+#endif
+#ifndef LC_PSF_WAVEFLAGS
+#define LC_PSF_WAVEFLAGS 0
+#endif
 namespace lc {
+constexpr int kXFlagStride = 16;   // flag words per (frame, role): one per wave in the per-wave form, word 0 in the workgroup form
 
 #ifdef LC_STAMPS
 __device__ long long g_stamps[128];  // [0, 64): block 0, [64, 128): block 8 (role 1 of frame 0 in the two-workgroup form)
@@ -345,6 +352,11 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
     compute_taps(tid);
   };
   if (conv_role) compute_taps(tid0);  // (visible behind the barrier that opens the first group of stars)
+#if LC_PSF_WAVEFLAGS
+  if constexpr (SPLIT) {
+    if (tid0 == 0) ((int *)(SCAL + 5))[0] = 1;  // (per-wave hand-off: only ever cleared; read behind the iteration's barriers)
+  }
+#endif
   // (measured and left out: s_setprio 1 for the second-dispatched half of the workgroup - MI355X_MICROARCH.md, two waves per
   //  SIMD - C2 16.2 us per iteration with and without, C3 shard 86.8 / 86.9)
   for (int it = 0; it < A.n_iter; ++it) {
@@ -979,21 +991,54 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
       if (tid == 0 && it == 0) store_sc1_f(mine + N * N + 1, __int_as_float(my_xcc + 1));
       // role 0: the stars' step and the next tap tables need nothing from the partner: done while the stores drain
       if (role == 0 && A.mode == 1) update_stars_and_taps(tid);
+#if LC_PSF_WAVEFLAGS
+      // (-DLC_PSF_WAVEFLAGS=1; built in round 4 and measured NOT faster: C2 14.8 against 14.8 - 14.9 us per iteration (54.0 - 54.2
+      //  against 53.7 - 53.9 M cutouts/s), C3 shard 90.4 against 82.7 - sixteen polling lanes per workgroup at N = 128.  The one-lane
+      //  form below stays the default.)
+      // Per-WAVE flags: wave w of role 0 and wave w of role 1 own the same 64 PX pixels, so a wave hands over as soon as ITS
+      // stores have drained and reads as soon as its partner wave has published - no workgroup barrier in front of the flag,
+      // eight polling lanes instead of one, and a wave does not wait for the slowest wave of either workgroup.  One barrier
+      // remains behind the reads: it makes the give-up decision uniform (a wave whose partner does not show up clears OK[0];
+      // nobody leaves the loop before everybody has seen it) and publishes what the first hand-off found out about the XCDs.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      LC_STAMP(45);
+      int *OK = (int *)(SCAL + 5);
+      int wave_ok = 1;
+      if (lane == 0) {
+        int *myflag = A.xflags + ((size_t)f * 2 + role) * kXFlagStride + wid;
+        const int *theirflag = A.xflags + ((size_t)f * 2 + (1 - role)) * kXFlagStride + wid;
+        if (same_xcd) asm volatile("global_store_dword %0, %1, off" ::"v"(myflag), "v"(it + 1) : "memory");
+        else __hip_atomic_store(myflag, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(theirflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it + 1) {
+          __builtin_amdgcn_s_sleep(LC_XPOLL_SLEEP);
+          ++spins;
+          // exit condition every wave reaches: a partner that never shows up is reported, not waited for
+          if (spins > (1 << 21) ||
+              ((spins & 255) == 0 && __hip_atomic_load(A.xabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.launch_seq)) {
+            __hip_atomic_store(A.xabort, A.launch_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wave_ok = 0;
+            OK[0] = 0;
+            break;
+          }
+        }
+        if (tid == 0 && it == 0 && wave_ok)
+          OK[1] = (A.xcd_fast && __float_as_int(load_sc1_f(theirs + N * N + 1)) == my_xcc + 1) ? 1 : 0;
+      }
+      wave_ok = __builtin_amdgcn_readfirstlane(wave_ok);
+#else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       LC_STAMP(45);
       int *OK = (int *)(SCAL + 5);
       if (tid == 0) {
         // (same XCD: the flag too stays in the shared L2, where the partner's L1-bypassing poll finds it)
-        if (same_xcd) asm volatile("global_store_dword %0, %1, off" ::"v"(A.xflags + f * 2 + role), "v"(it + 1) : "memory");
-        else __hip_atomic_store(A.xflags + f * 2 + role, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (same_xcd) asm volatile("global_store_dword %0, %1, off" ::"v"(A.xflags + ((size_t)f * 2 + role) * kXFlagStride), "v"(it + 1) : "memory");
+        else __hip_atomic_store(A.xflags + ((size_t)f * 2 + role) * kXFlagStride, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 1, spins = 0;
-        while (__hip_atomic_load(A.xflags + f * 2 + (1 - role), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it + 1) {
+        while (__hip_atomic_load(A.xflags + ((size_t)f * 2 + (1 - role)) * kXFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it + 1) {
           // (the interval between polls is no lever: s_sleep 0 / 2 / 6 / 14 measured at 14.8 - 15.0 us per iteration of C2 and
           //  82.2 - 83.0 of the C3 shard, all within the run-to-run spread; -DLC_XPOLL_SLEEP=<n> for an A/B build)
-#ifndef LC_XPOLL_SLEEP
-#define LC_XPOLL_SLEEP 2
-#endif
           __builtin_amdgcn_s_sleep(LC_XPOLL_SLEEP);
           ++spins;
           // exit condition every workgroup reaches: a partner that never shows up is reported, not waited for
@@ -1011,10 +1056,13 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
       }
+#endif
+#if !LC_PSF_WAVEFLAGS
       __syncthreads();
       LC_STAMP(46);
       if (*OK == 0) break;
       if (it == 0) same_xcd = OK[1];
+#endif
       // (measured and left out: a first look at the partner's flag requested while the own stores drain, so that the role
       //  that arrives second skips its first poll - 15.2 against 15.0 us per iteration on one box, C3 shard 83.8 / 82.6)
       // (measured and left out: role 0, the longer of the two, asking for the partner's half BEFORE publishing its own - the
@@ -1040,6 +1088,12 @@ __global__ __launch_bounds__(C::NTHR) void psf_fit_kernel(PsfArgs A) {
         if (role) gB[p] = other[p]; else z[p] = other[p];
       }
       if (tid == 0 && role == 0) tl1 = (PX == 8) ? tl1_other : load_sc1_f(theirs + N * N);
+#if LC_PSF_WAVEFLAGS
+      __syncthreads();
+      LC_STAMP(46);
+      if (*OK == 0) break;
+      if (it == 0) same_xcd = OK[1];
+#endif
       LC_STAMP(47);
     }
     if (tid == 0 && conv_role) {
