@@ -340,7 +340,8 @@ class EmbeddedJointFit(JointFit):
     the window is then not zero any more and convolves into it: three times further from the native model.)  Also
     different from a fit at a kernel of its own: the regulariser sees the larger grid (J = log2 of it, other edges), and
     the ring pixels of h are free, held at zero by the regulariser alone.  The noise levels W of the regulariser are propagated with the ring at the stamps'
-    median variance (a ring of 'infinite' noise would inflate every coarse scale)."""
+    median variance (a ring of 'infinite' noise would inflate every coarse scale).  Sharded over ranks like a native-size fit
+    (tests/test_joint_sizes_gpu.py)."""
     RING_VARIANCE = 1e20
 
     def __init__(self, data, sigma2, psf, ss, M, ctx, n_fit):
@@ -466,7 +467,12 @@ class EmbeddedJointFit(JointFit):
             parts.append(blk)
         return np.ascontiguousarray(np.concatenate(parts, axis=1))
 
-    def _no_shards(self, *a, **k):
-        raise NotImplementedError('an embedded joint fit is not sharded over ranks: use a stamp size with a kernel of its own')
-
-    step_local = step_grad = shared_buffer = shared_get = shared_set = run_sharded = step_update = _no_shards
+    # Sharded over ranks (round 4): every rank embeds its epochs in the same larger frame, so the shared block - the gradient of
+    # h on the LARGER grid, the sums over the sources - means the same on all of them and step_local / the all-reduce /
+    # step_update / run_sharded are the native-size calls unchanged; only what crosses to the caller changes size.
+    def step_grad(self, names=('a', 'c_x', 'c_y', 'dx', 'dy', 'h', 'mean')):
+        with self._dev():
+            loss, bufs = super().step_grad(names)
+        if 'h' in bufs:
+            bufs['h'] = self._crop_h(bufs['h'])
+        return loss, bufs

@@ -152,7 +152,7 @@ def model_roi_cutouts_sharded(data, noisemap, psf, subsampling_factor, xs_pixels
     import torch
     import torch.distributed as dist
     from ..distributed import PeerGroup, ShardedJointOptimizer, gather_epoch_blocks, host_group
-    from ..joint import JointFit
+    from ..joint import make_joint_fit
     from .. import _lib
     reg = dict(DEFAULT_REGULARIZATION)
     reg.update(regularization or {})
@@ -163,7 +163,8 @@ def model_roi_cutouts_sharded(data, noisemap, psf, subsampling_factor, xs_pixels
     ys = np.atleast_1d(np.asarray(ys_pixels, dtype=np.float64))
     M, ss = xs.size, int(subsampling_factor)
     offset = (n - 1) / 2.0
-    fit = JointFit(data, noisemap ** 2, psf, ss, M, ctx or _lib.default_context())
+    # (a stamp size without an epoch kernel of its own is fitted embedded in the next one, on every rank alike)
+    fit = make_joint_fit(data, noisemap ** 2, psf, ss, M, ctx or _lib.default_context())
     peer = None
     try:
         fit.set_params(a=np.tile(np.asarray(initial_a, np.float64) / scale, E), c_x=xs - offset, c_y=ys - offset, dx=np.zeros(E),

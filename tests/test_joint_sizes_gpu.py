@@ -166,3 +166,63 @@ def test_batched_star_photometry_at_a_size_without_a_kernel_equals_the_one_star_
         assert np.allclose(a['fluxes'], b['fluxes'], rtol=1e-5, atol=0.0)
         assert np.allclose(a['fluxes_uncertainties'], b['fluxes_uncertainties'], rtol=1e-4)
         assert abs(a['chi2'] - b['chi2']) < 1e-4 * abs(a['chi2'])
+
+
+def test_embedded_fit_through_the_sharded_drive(ctx):
+    """A stamp size without an epoch kernel, sharded over ranks (round 4): every rank embeds its epochs in the same larger frame,
+    so the sharded primitives are the native-size ones and only what crosses to the caller changes size.  World size 1 here
+    (one GPU): the step-by-step drive - step_local, the all-reduce that has nothing to add, step_update - against the device
+    loop of the same fit (same kernels in other launch shapes: fp32 rounding of the sums), the gradients of step_grad at the
+    caller's size, and the C++ sharded loop over the library's peer group."""
+    from lightcurver_amd.joint import make_joint_fit, EmbeddedJointFit
+    from lightcurver_amd.distributed import PeerGroup, ShardedJointOptimizer
+    n, ss, E, M, T = 28, 2, 5, 2, 12
+    ds = make_roi_dataset(E=E, M=M, n=n, ss=ss, seed=9)
+    free = ['a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h']
+
+    def make():
+        j = make_joint_fit(ds['data'], ds['noisemap'].astype(np.float64) ** 2, ds['psf'], ss, M, ctx)
+        assert isinstance(j, EmbeddedJointFit)
+        p = dict(ds['truth'])
+        p['a'] = np.asarray(p['a']) * 0.9
+        j.set_params(**p)
+        j.set_loss(lam_scales=1.0, lam_hf=1.0, lam_positivity=10.0, lam_pts_source=0.01, lam_flux_uniformity=10.0)
+        j.set_free(free)
+        return j
+
+    a = make()
+    a.run_adabelief(T, init_learning_rate=1e-3, schedule_learning_rate=False)
+    ha, pa = np.asarray(a.loss_history(), np.float64), a.get_params()
+    a.close()
+    b = make()
+    b.step_local()
+    loss, g = b.step_grad()
+    assert g['h'].shape == ((n * ss) ** 2,) and np.isfinite(loss) and np.all(np.isfinite(g['h']))
+    for _ in range(T):
+        b.step_local()
+        b.step_update(init_learning_rate=1e-3, schedule_learning_rate=False)
+    hb, pb = np.asarray(b.loss_history(), np.float64), b.get_params()
+    b.close()
+    assert pb['h'].shape == ((n * ss) ** 2,)
+    assert np.abs(hb[:T] - ha[:T]).max() <= 2e-5 * np.abs(ha).max()
+    for k in ('a', 'c_x', 'c_y', 'dx', 'dy'):
+        assert np.abs(pb[k] - pa[k]).max() <= 2e-4 * max(np.abs(pa[k]).max(), 1e-3), k
+    assert np.abs(pb['h'] - pa['h']).max() <= 0.02 * T * 1e-3 + 1e-7
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    try:
+        c = make()
+        peer = PeerGroup(c)
+        opt = ShardedJointOptimizer(c, None, peer=peer)
+        opt.run(T, init_learning_rate=1e-3, schedule_learning_rate=False)
+        hc, pc = np.asarray(c.loss_history(), np.float64), c.get_params()
+        peer.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+    assert np.abs(hc[:T] - hb[:T]).max() <= 2e-5 * np.abs(hb).max()
+    assert np.abs(pc['h'] - pb['h']).max() <= 0.02 * T * 1e-3 + 1e-7
