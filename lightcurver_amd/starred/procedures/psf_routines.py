@@ -107,9 +107,6 @@ def build_psf_batch(images, noisemaps, subsampling_factor, masks=None, n_iter_an
     n_fit = _fit_size(n, ss)
     pad = (n_fit - n) // 2
     if pad:
-        if field_distortion:
-            raise _lib.LcError(f'build_psf(field_distortion=True): no kernel for {n}x{n} stamps at subsampling {ss} '
-                               f'(the embedded form covers the plain fit only)')
         big = np.zeros((F, S, n_fit, n_fit), np.float64)
         big[..., pad:pad + n, pad:pad + n] = data
         data = big
@@ -120,9 +117,11 @@ def build_psf_batch(images, noisemaps, subsampling_factor, masks=None, n_iter_an
         if stamp_coordinates is None:
             raise ValueError('field_distortion=True needs stamp_coordinates (rescaled frame positions of the stamps)')
         coords = stamp_coordinates if F > 1 or np.asarray(stamp_coordinates[0]).ndim == 2 else [stamp_coordinates]
-        return _fit_with_distortion(images, data, weight, norms, stars, moffat, S_list, coords, ss, n, ctx,
+        # (embedded sizes: the two batches run at the fitted size - same centre, zero-weight ring - and the outputs are cut back)
+        return _fit_with_distortion(images, data, weight, norms, stars, moffat, S_list, coords, ss, n_fit, ctx,
                                     int(n_iter_analytic), int(n_iter_adabelief), float(regularization_strength_scales),
-                                    float(regularization_strength_hf), init_learning_rate, schedule_learning_rate)
+                                    float(regularization_strength_hf), init_learning_rate, schedule_learning_rate,
+                                    n_user=n)
     b = PsfBatch(data, weight, ss, ctx)
     try:
         b.set_moffat(moffat)
@@ -209,11 +208,14 @@ def quadratic_forms(theta, xy, ss):
 
 
 def _fit_with_distortion(images, data, weight, norms, stars, moffat, S_list, coords, ss, n, ctx, n_iter_analytic,
-                         n_iter_adabelief, lam_scales, lam_hf, init_learning_rate, schedule_learning_rate):
-    """build_psf(field_distortion=True): see include/lcmi.h ("build_psf(field_distortion=True)") for the two-batch scheme."""
+                         n_iter_adabelief, lam_scales, lam_hf, init_learning_rate, schedule_learning_rate, n_user=None):
+    """build_psf(field_distortion=True): see include/lcmi.h ("build_psf(field_distortion=True)") for the two-batch scheme.
+    n: the size the device fits at; n_user (<= n, same parity): the caller's stamp size when the stamps are embedded."""
     import ctypes as C
     F, S = data.shape[0], data.shape[1]
     N = n * ss
+    n_user = n if n_user is None else int(n_user)
+    pad = (n - n_user) // 2
     xy = np.zeros((F, S, 2))
     for f in range(F):
         cf = np.asarray(coords[f], dtype=np.float64).reshape(-1, 2)
@@ -233,12 +235,12 @@ def _fit_with_distortion(images, data, weight, norms, stars, moffat, S_list, coo
         x[:, 13 + S:13 + 2 * S] = stars[..., 1]
         x[:, 13 + 2 * S:] = stars[..., 2]
         lo, hi = np.empty((F, D)), np.empty((F, D))
-        lo[:, 0:2], hi[:, 0:2] = 0.5 / ss, n / 2.0
+        lo[:, 0:2], hi[:, 0:2] = 0.5 / ss, n_user / 2.0
         lo[:, 2], hi[:, 2] = -math.pi, math.pi
         lo[:, 3], hi[:, 3] = 1.1, 50.0
         lo[:, 4:13], hi[:, 4:13] = -DISTORTION_BOUND, DISTORTION_BOUND
         lo[:, 13:13 + S], hi[:, 13:13 + S] = 0.0, np.inf
-        lo[:, 13 + S:], hi[:, 13 + S:] = -n / 4.0, n / 4.0
+        lo[:, 13 + S:], hi[:, 13 + S:] = -n_user / 4.0, n_user / 4.0
         sky = stars[..., 3].copy()
 
         def push(X):
@@ -324,6 +326,16 @@ def _fit_with_distortion(images, data, weight, norms, stars, moffat, S_list, coo
 
     out = []
     resid_all = res_s['residuals'].reshape(F, S, n, n)
+    if pad:   # back to the caller's size (the ring carried no weight: chi2 counts the caller's pixels only)
+        P, Nu = pad * ss, n_user * ss
+        resid_all = resid_all[..., pad:pad + n_user, pad:pad + n_user]
+        weight = weight[..., pad:pad + n_user, pad:pad + n_user]
+        res_f = dict(res_f)
+        for key in ('narrow_psf', 'full_psf'):
+            cut = res_f[key][:, P:P + Nu, P:P + Nu]
+            res_f[key] = cut / cut.sum(axis=(-1, -2), keepdims=True)
+        grid = np.ascontiguousarray(grid[:, P:P + Nu, P:P + Nu])
+        N = Nu
     for f in range(F):
         Sf = S_list[f]
         wf = weight[f, :Sf]

@@ -160,3 +160,33 @@ def test_build_psf_with_field_distortion(ctx):
     assert abs(kd['dilation_x'][1] - 0.16) < 0.05 and abs(kd['dilation_y'][2] + 0.12) < 0.05
     star_psf = apply_distortion(res['narrow_psf'], kd, xy[:1], ctx=ctx)   # the star-photometry call shape
     assert star_psf.shape == (N, N) and abs(star_psf.sum() - 1.0) < 1e-5
+
+
+def test_build_psf_with_field_distortion_at_a_size_without_a_kernel(ctx):
+    """stamp_size_stars is a free integer in the reference's configuration (config.yaml:205): 20 x 20 stamps have no kernel of
+    their own and are fitted embedded in 24 x 24 frames (zero-weight ring), since round 4 with field_distortion=True too - the
+    two batches of the distortion fit run at the fitted size, every output comes back at the caller's."""
+    from lightcurver_amd.starred.procedures.psf_routines import build_psf
+    S, n, ss = 8, 20, 2
+    N = n * ss
+    rng = np.random.default_rng(78)
+    xy = rng.uniform(-0.5, 0.5, (S, 2))
+    true = np.array([0.0, 0.16, 0.0, 0.0, 0.0, -0.12, 0.0, 0.0, 0.0])
+    p = dict(fwhm_x=om.T(3.0), fwhm_y=om.T(2.8), phi=om.T(0.3), beta=om.T(3.0), B=om.T(np.zeros(N * N)),
+             a=om.T(rng.uniform(2e5, 6e5, S)), x0=om.T(rng.uniform(-0.4, 0.4, S)), y0=om.T(rng.uniform(-0.4, 0.4, S)),
+             sky=om.T(np.zeros(S)), dist=om.T(true))
+    clean = om.psf_model_distorted(p, xy, ss, n).numpy()
+    noise = np.sqrt(5.0 ** 2 + np.abs(clean))
+    data = clean + noise * rng.standard_normal(clean.shape)
+    kw = dict(image=data, noisemap=noise, subsampling_factor=ss, masks=np.ones_like(data), n_iter_analytic=150,
+              n_iter_adabelief=300, guess_method_star_position='center', guess_fwhm_pixels=3.3)
+    plain = build_psf(field_distortion=False, **kw)
+    res = build_psf(field_distortion=True, stamp_coordinates=xy, **kw)
+    kd = res['kwargs_psf']['kwargs_distortion']
+    assert res['residuals'].shape == data.shape and res['models'].shape == data.shape
+    assert res['narrow_psf'].shape == (N, N) and abs(res['narrow_psf'].sum() - 1.0) < 1e-4
+    assert res['full_psf'].shape == (N, N)
+    assert np.asarray(res['kwargs_psf']['kwargs_background']['background']).shape == (N * N,)
+    print('chi2 plain', plain['chi2'], 'with distortion', res['chi2'], 'coefficients', kd)
+    assert res['chi2'] < 0.8 * plain['chi2'] and res['chi2'] < 1.5
+    assert abs(kd['dilation_x'][1] - 0.16) < 0.06 and abs(kd['dilation_y'][2] + 0.12) < 0.06
