@@ -121,6 +121,7 @@ struct lc_joint {
   unsigned int *upd_ctr = nullptr;
   unsigned int upd_seq = 0;
   bool upd_gate_pending = false, upd_gate_used = false, upd_signal_due = false;
+  int streams_overlap = -1;   // -1: not probed yet; 1: the chain's stream runs beside the main stream; 0: they share a hardware queue
   // epoch_wait_due: this iteration's chain ends in a counting launch and the epoch launch may carry the wait for it (an extra
   // block: JointArgs::chain_flag); epoch_waited: it did - the update behind it needs no synchronisation of its own
   bool epoch_wait_due = false, epoch_waited = false, epoch_wait_used = false;
@@ -941,7 +942,26 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
 // May the event behind an update be left out?  Inside the library's loops, on the main stream, where its only reader is the
 // next iteration's chain, which can start behind a gate kernel instead (LCMI_UPD_EVENT=1: the event, the cross-check; the
 // third stream of LCMI_PTS_SIDE waits for the event too).
+// One probe per object (mreg_probe_kernel): do the chain's stream and the main stream run side by side?
+static int probe_streams(lc_joint *j) {
+  if (j->streams_overlap >= 0 || !j->upd_ctr) return LC_OK;
+  unsigned int *word = j->upd_ctr + 2, *seen = j->upd_ctr + 3;
+  LC_HIP(j->ctx, hipMemsetAsync(word, 0, 2 * sizeof(unsigned int), j->ctx->stream));
+  LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+  LC_HIP(j->ctx, hipStreamSynchronize(j->streamB));
+  hipLaunchKernelGGL(mreg_probe_kernel, dim3(1), dim3(64), 0, j->streamB, word, seen, 50000ll);   // at most 500 us
+  hipLaunchKernelGGL(mreg_signal_kernel, dim3(1), dim3(64), 0, j->ctx->stream, word, 1u);
+  LC_HIP(j->ctx, hipGetLastError());
+  LC_HIP(j->ctx, hipStreamSynchronize(j->streamB));
+  unsigned int ok = 0;
+  int rc = d2h(j, &ok, seen, sizeof(ok));
+  if (rc) return rc;
+  j->streams_overlap = ok ? 1 : 0;
+  if (std::getenv("LCMI_DEBUG_STREAMS")) std::fprintf(stderr, "lc_joint: second stream beside the main stream: %s\n", ok ? "yes" : "NO (shared hardware queue): events instead of the gate kernel");
+  return LC_OK;
+}
 static bool upd_gate_ok(const lc_joint *j, hipStream_t stream) {
+  if (j->streams_overlap != 1) return false;
   // (LCMI_EVENT_SYNC=1 - what counter collection sets, which runs one kernel at a time: a gate kernel alone on the machine
   //  would wait for an epoch kernel that cannot start - keeps the event as well)
   return j->upd_ctr && (j->in_device_loop || j->in_sharded_loop) && stream == j->ctx->stream && !std::getenv("LCMI_UPD_EVENT") &&
@@ -1873,6 +1893,7 @@ int lc_joint_run_sharded(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg, l
   int rc = ensure_hist(j, j->iters_done + n_iter + 2);
   const bool may_cluster = j->cl_ctr && !j->cluster_off;
   j->in_sharded_loop = true;
+  if (!rc) rc = probe_streams(j);
   // The library's own peer group as the transport: reduction over the epochs and exchange in one launch (LCMI_PEER_FUSED=1).
   // Only where every block of that launch is resident at once (its blocks wait for the peers' flags after publishing; see
   // joint_reduce_peer.h), the block is whole chunks of pixels plus the scalars, and the group is this context's.
@@ -2245,6 +2266,7 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
     const unsigned int one = 1;
     if ((rc = h2d(j, j->cl_ctr + (size_t)j->E * kClStride, &one, sizeof(one)))) return rc;
   }
+  if ((rc = probe_streams(j))) return rc;
   j->in_device_loop = true;
   bool flags_used = false;
  redo:

@@ -262,6 +262,26 @@ __global__ void mreg_gate_kernel(const unsigned int *word, unsigned int target, 
     }
   }
 }
+// Can a kernel on the chain's stream run WHILE a later-enqueued kernel of the main stream starts?  Normally yes - two HIP
+// streams, two hardware queues - but the runtime has only a few hardware queues (four by default) and maps further streams
+// onto the same ones: a process that holds several objects can find the two streams of one of them behind each other in ONE
+// queue, and there a gate kernel would wait for an epoch launch that cannot start before the gate has ended.  Probed once per
+// object: this kernel waits (bounded: `ticks` of the 100 MHz counter) for a word that a kernel enqueued AFTERWARDS on the
+// main stream sets, and reports whether it saw it.
+__global__ void mreg_probe_kernel(const unsigned int *word, unsigned int *seen, long long ticks) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    unsigned int ok = 0;
+    while (wall_clock64() - t0 < ticks) {
+      if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        ok = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+    __hip_atomic_store(seen, ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 // (where no epoch kernel follows - the point-source-only kernel - the signal is a launch of its own)
 __global__ void mreg_signal_kernel(unsigned int *word, unsigned int value) {
   if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

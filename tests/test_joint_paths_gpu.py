@@ -387,3 +387,27 @@ def test_point_source_term_behind_the_all_reduce_in_one_launch(ctx, E, M, n):
         ref = max(np.abs(p_loop[k]).max(), 1e-3)
         assert np.abs(p_direct[k] - p_chain[k]).max() <= 2e-5 * ref, k
         assert np.abs(p_direct[k] - p_loop[k]).max() <= 2e-4 * ref, k
+
+
+def test_device_loop_on_one_hardware_queue(ctx):
+    """The runtime has a few hardware queues (four by default) and maps further streams onto the same ones.  With the two streams
+    of a fit in ONE queue a gate kernel on the second stream would wait for an epoch launch that cannot start before the gate
+    has ended; the library probes once per object whether its streams run side by side (probe_streams, csrc/joint_fit.hip) and
+    keeps the events where they do not.  GPU_MAX_HW_QUEUES=1 forces that case (it must be set before HIP starts: a process of
+    its own): same numbers as the default run, no time-out."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tools', 'queue_sharing.py')
+    outs = {}
+    for q in ('1', None):
+        env = dict(os.environ)
+        env.pop('GPU_MAX_HW_QUEUES', None)
+        if q:
+            env['GPU_MAX_HW_QUEUES'] = q
+        r = subprocess.run([sys.executable, tool, '1'], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[q] = (r.stdout, r.stderr)
+    assert 'NO (shared hardware queue)' in outs['1'][1]
+    assert 'beside the main stream: yes' in outs[None][1]
+    loss = {q: [ln.split('loss')[1].strip() for ln in o[0].splitlines() if 'loss' in ln] for q, o in outs.items()}
+    assert loss['1'] == loss[None] and len(loss['1']) == 1
