@@ -757,7 +757,9 @@ int launch_reg_mfma(lc_joint *j, hipStream_t stream, bool with_pts) {
     // to the batched form to fp32 rounding (tests/test_joint_paths_gpu.py).  Built to take the Pbar launch off a chain that
     // ends just after the epoch kernel; measured SLOWER and not the default: C4 81.0 against 70.9 us per iteration, its
     // 25-epoch shard 66.4 / 64.4, the C5 shard 235.5 / 230.7 - the third stream's fork and join (two more cross-stream event
-    // waits per iteration, a third hardware queue) cost more than the launch they remove.
+    // waits per iteration, a third hardware queue) cost more than the launch they remove.  (In a process that has created many
+    // streams the runtime may map two of the three onto one hardware queue; with the update's in-kernel wait for the chain
+    // (the default) a run of this form then timed out once in the test suite: use it with LCMI_EVENT_SYNC=1.)
     const char *ps_env = std::getenv("LCMI_PTS_SIDE");
     const bool pts_side = with_pts && stream == j->streamB && N % kPtT == 0 && ps_env && std::atoi(ps_env) != 0 && !std::getenv("LCMI_REG_CHAIN");
     if (pts_side) {

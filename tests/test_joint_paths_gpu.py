@@ -216,7 +216,10 @@ def test_point_source_term_beside_the_chain_equals_the_batched_form(ctx, E, n, M
     measured slower, opt-in) against the same term as one more product in each batch of the chain (default): other summation
     order of the scale-0 stencil, same numbers to fp32 rounding."""
     ds = make_roi_dataset(E=E, M=M, n=n, ss=2, seed=104)
-    a = _fit(ctx, ds, M, 25, env={'LCMI_PTS_SIDE': '1'})
+    # (LCMI_EVENT_SYNC=1: this opt-in form joins a THIRD stream into the chain with events; in a process that has created many
+    #  streams before, the runtime may put two of the three onto one hardware queue, and the update's in-kernel wait for a chain
+    #  that is held up there ran out once in a full-suite run.  What is compared here is the arithmetic of the two forms.)
+    a = _fit(ctx, ds, M, 25, env={'LCMI_PTS_SIDE': '1', 'LCMI_EVENT_SYNC': '1'})
     b = _fit(ctx, ds, M, 25)
     _compare(a, b, ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'), 25, 1e-4)
 
