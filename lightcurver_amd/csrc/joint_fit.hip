@@ -121,6 +121,10 @@ struct lc_joint {
   unsigned int *upd_ctr = nullptr;
   unsigned int upd_seq = 0;
   bool upd_gate_pending = false, upd_gate_used = false, upd_signal_due = false;
+  // force_events: an in-kernel wait of this object ran out once (a stream held up for longer than its bound: ~1 s); the run was
+  // redone from a copy of the state and the object synchronises its streams with events only from then on
+  bool force_events = false;
+  int wait_fallbacks = 0;
   int streams_overlap = -1;   // -1: not probed yet; 1: the chain's stream runs beside the main stream; 0: they share a hardware queue
   // epoch_wait_due: this iteration's chain ends in a counting launch and the epoch launch may carry the wait for it (an extra
   // block: JointArgs::chain_flag); epoch_waited: it did - the update behind it needs no synchronisation of its own
@@ -963,7 +967,7 @@ static int probe_streams(lc_joint *j) {
   return LC_OK;
 }
 static bool upd_gate_ok(const lc_joint *j, hipStream_t stream) {
-  if (j->streams_overlap != 1) return false;
+  if (j->streams_overlap != 1 || j->force_events) return false;
   // (LCMI_EVENT_SYNC=1 - what counter collection sets, which runs one kernel at a time: a gate kernel alone on the machine
   //  would wait for an epoch kernel that cannot start - keeps the event as well)
   return j->upd_ctr && (j->in_device_loop || j->in_sharded_loop) && stream == j->ctx->stream && !std::getenv("LCMI_UPD_EVENT") &&
@@ -1695,7 +1699,7 @@ int lc_joint_step_local(lc_joint *j) {
     // cluster form, whose chain ends about when the epoch kernel does (the update's own poll overlaps its slab loads with
     // the chain's tail: 25 epochs 53.1 / 52.8), and not for few epochs of 128 x 128 (32 epochs: 114.5 / 112.2).
     j->epoch_wait_due = (j->in_device_loop || j->in_sharded_loop) && (j->reg_planes || j->reg_counter) && j->reg_flag &&
-                        cluster_parts(j) == 0 && (j->N <= 128 || j->E >= 64) &&
+                        cluster_parts(j) == 0 && (j->N <= 128 || j->E >= 64) && !j->force_events &&
                         !std::getenv("LCMI_EVENT_SYNC") && !std::getenv("LCMI_EPOCH_WAIT_OFF");
   }
   const bool gm_update = !j->v->uk || ((j->cfg.lam_pts_source == 0.f || j->pts_pending) && (j->reg_pending || !reg_h_on(j)));
@@ -1766,11 +1770,13 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   //  form, but the gain is small - C5 shard 222.6 -> 221.8 us, 32 epochs 111.5 -> 108.6 - and how the dispatcher treats a second
   //  queue while one kernel has hundreds of blocks pending is nothing this code can guarantee: opt-in.)
   const bool all_sizes = std::getenv("LCMI_FLAG_SYNC_ALL") != nullptr;
-  j->flag_sync = j->reg_pending && !j->epoch_waited && j->fuse_full && j->mreg && j->reg_flag && (few_blocks || all_sizes) && !j->reg_noflag && !std::getenv("LCMI_EVENT_SYNC");
+  j->flag_sync = j->reg_pending && !j->epoch_waited && j->fuse_full && j->mreg && j->reg_flag && (few_blocks || all_sizes) && !j->reg_noflag && !j->force_events &&
+                 !std::getenv("LCMI_EVENT_SYNC");
   // (sharded drive behind a counting chain: launch_update decides - the multi-block update polls the counter in its kernel,
   //  every other consumer gets the event wait there)
   if (j->epoch_waited) j->gm_flag_used = true;   // (its error word is checked at the end of the loop)
-  j->defer_event = j->reg_pending && !j->epoch_waited && !j->flag_sync && j->in_sharded_loop && j->reg_counter && !std::getenv("LCMI_EVENT_SYNC");
+  j->defer_event = j->reg_pending && !j->epoch_waited && !j->flag_sync && j->in_sharded_loop && j->reg_counter && !j->force_events &&
+                   !std::getenv("LCMI_EVENT_SYNC");
   // (epoch_waited: the epoch launch of this iteration ended only when the chain had - nothing to wait for here)
   if (j->reg_pending && !j->epoch_waited && !j->flag_sync && !j->defer_event) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
   rc = launch_update(j, 1, j->iters_done, cfg, true, false, j->reg_pending ? 2 : 0);
@@ -2263,7 +2269,10 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
       }
     return LC_OK;
   };
-  if (may_cluster && (rc = snapshot(false))) return rc;
+  // (the same copy serves the in-kernel waits of the loop's stream synchronisation - completion flags, the gate kernel: bounded,
+  //  ~1 s; a run in which one ran out is redone with events, and the object keeps to events afterwards)
+  const bool may_wait = j->mreg != nullptr && !j->force_events;
+  if ((may_cluster || may_wait) && (rc = snapshot(false))) return rc;
   if (may_cluster && std::getenv("LCMI_CLUSTER_TEST_ABORT")) {  // test hook: the first cluster launch finds the abort word set
     const unsigned int one = 1;
     if ((rc = h2d(j, j->cl_ctr + (size_t)j->E * kClStride, &one, sizeof(one)))) return rc;
@@ -2322,6 +2331,46 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
       goto redo;
     }
   }
+  // in-kernel waits of this run that ran out (the update's wait for the chain or the epoch launch's extra block: reg_flag + 1;
+  // the gate kernel: upd_ctr + 1): the numbers of the run cannot be trusted.  Once per object: restore the state copied at
+  // the start, switch the object to events, and run the same iterations again.
+  {
+    unsigned int err_flag = 0, err_gate = 0;
+    if (!rc && flags_used && j->reg_flag) {
+      (void)hipStreamSynchronize(j->streamB);
+      rc = d2h(j, &err_flag, j->reg_flag + 1, sizeof(err_flag));
+    }
+    if (!rc && j->upd_gate_used && j->upd_ctr) {
+      (void)hipStreamSynchronize(j->streamB);
+      rc = d2h(j, &err_gate, j->upd_ctr + 1, sizeof(err_gate));
+    }
+    if (!rc && (err_flag || err_gate)) {
+      const unsigned int zero = 0;
+      if (err_flag) (void)h2d(j, j->reg_flag + 1, &zero, sizeof(zero));
+      if (err_gate) (void)h2d(j, j->upd_ctr + 1, &zero, sizeof(zero));
+      if (may_wait && snap.p && !j->force_events) {
+        j->force_events = true;
+        j->wait_fallbacks += 1;
+        if (std::getenv("LCMI_DEBUG_STREAMS")) std::fprintf(stderr, "lc_joint: an in-kernel wait ran out (flag %u, gate %u): run redone with events\n", err_flag, err_gate);
+        LC_HIP(j->ctx, hipStreamSynchronize(j->ctx->stream));
+        LC_HIP(j->ctx, hipStreamSynchronize(j->streamB));
+        if ((rc = snapshot(true))) return rc;
+        LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
+        j->iters_done = it0;
+        j->phist_rows = ph0;
+        j->reg_pending = j->fuse_pending = j->fuse_full = j->pts_pending = false;
+        j->upd_gate_pending = j->upd_gate_used = j->upd_signal_due = false;
+        flags_used = false;
+        goto redo;
+      }
+      unsigned int seen = 0;
+      if (j->reg_flag) (void)d2h(j, &seen, j->reg_flag, sizeof(seen));
+      static thread_local char msg[256];
+      std::snprintf(msg, sizeof(msg), "joint fit: the regulariser of an iteration did not complete in time on the second stream (set LCMI_EVENT_SYNC=1); completion word %u, expected %u", seen, j->reg_seq);
+      j->ctx->err = msg;
+      rc = LC_ERR_DEVICE;
+    }
+  }
   j->in_device_loop = false;
   j->flag_sync = false;
   {
@@ -2329,20 +2378,6 @@ int lc_joint_run_adabelief(lc_joint *j, int n_iter, const lc_adabelief_cfg *cfg)
     if (!rc) rc = rg;
   }
   if (!rc) rc = chain_check(j);
-  if (!rc && flags_used) {  // an update that gave up waiting for its regulariser would have used stale numbers: report it
-    unsigned int err = 0;
-    if ((rc = d2h(j, &err, j->reg_flag + 1, sizeof(err)))) return rc;
-    if (err) {
-      const unsigned int zero = 0;
-      h2d(j, j->reg_flag + 1, &zero, sizeof(zero));
-      unsigned int seen = 0;
-      (void)d2h(j, &seen, j->reg_flag, sizeof(seen));
-      static thread_local char msg[256];
-      std::snprintf(msg, sizeof(msg), "joint fit: the regulariser of an iteration did not complete in time on the second stream (set LCMI_EVENT_SYNC=1); completion word %u, expected %u", seen, j->reg_seq);
-      j->ctx->err = msg;
-      return LC_ERR_DEVICE;
-    }
-  }
   return rc;
 }
 int lc_joint_iterations_done(lc_joint *j) { return j ? j->iters_done : LC_ERR_INVALID; }

@@ -414,3 +414,16 @@ def test_device_loop_on_one_hardware_queue(ctx):
     assert 'beside the main stream: yes' in outs[None][1]
     loss = {q: [ln.split('loss')[1].strip() for ln in o[0].splitlines() if 'loss' in ln] for q, o in outs.items()}
     assert loss['1'] == loss[None] and len(loss['1']) == 1
+
+
+def test_an_in_kernel_wait_that_runs_out_is_redone_with_events(ctx):
+    """The waits inside kernels that synchronise the two streams of the device loop are bounded (~1 - 3 s).  A second stream that is
+    held up for longer - LCMI_REG_DELAY_US holds the regulariser chain back by five seconds per iteration here - makes the
+    update's wait run out; the library notices at the end of the run, restores the state it copied at the start, switches the
+    object to events and runs the same iterations again (lc_joint_run_adabelief): the numbers of the undisturbed fit, no error."""
+    ds = make_roi_dataset(E=8, M=2, n=64, ss=2, seed=104)
+    a = _fit(ctx, ds, 2, 2)
+    b = _fit(ctx, ds, 2, 2, env={'LCMI_REG_DELAY_US': '5000000'})
+    np.testing.assert_array_equal(a[0], b[0])
+    for k in ('a', 'c_x', 'c_y', 'dx', 'dy', 'mean', 'h'):
+        np.testing.assert_array_equal(a[1][k], b[1][k])
