@@ -515,8 +515,11 @@ __device__ __forceinline__ void gm_flux_preload(const JointUpdArgs &A, FluxPre &
 }
 // rl: (optional, LDS) the 4 + 3 M values of A.regs, fetched by the caller in one round trip behind the flag; without it every
 // use below is a coherent load of its own
+// mode_ov / t_ov (>= 0): mode and iteration of this launch where A is a view kept in device memory (batched star photometry)
 __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, float lr, float bc1, float bc2, const float *sc,
-                                                int parts, const FluxPre *pre = nullptr, const float *rl = nullptr) {
+                                                int parts, const FluxPre *pre = nullptr, const float *rl = nullptr,
+                                                int mode_ov = -1, int t_ov = -1) {
+  const int mode = mode_ov >= 0 ? mode_ov : A.mode, t_now = t_ov >= 0 ? t_ov : A.t;
   auto reg_at = [&](int k) { return rl ? rl[k] : ld_coherent(A.regs + k, A.wait_flag != nullptr); };
   __shared__ float red[kGmThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -538,7 +541,7 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
       if (sd > 0.f) ga += A.lam_fu * ((av - A.a_ref[i]) - meanc) / (Etot * sd);
     }
     if (pts) ga += reg_at(4 + i * 3) / Etot;
-    if (A.mode == 0) {
+    if (mode == 0) {
       if (A.gout[LC_P_A]) A.gout[LC_P_A][idx] = ga;
     } else if (A.free_mask[LC_P_A]) {
       adabelief_step(av, pmv, psv, ga, lr, bc1, bc2, A.ab);
@@ -564,7 +567,7 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
     const int which = (idx / E == 0) ? LC_P_DX : (idx / E == 1) ? LC_P_DY : LC_P_MEAN;
     const int e = idx % E;
     const float gv = (which == LC_P_DX) ? A.g_dx[e] : (which == LC_P_DY) ? A.g_dy[e] : A.g_mean[e];
-    if (A.mode == 0) {
+    if (mode == 0) {
       if (A.gout[which]) A.gout[which][e] = gv;
     } else if (A.free_mask[which]) {
       float pv_ = A.par[which][e];
@@ -587,7 +590,7 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
       const double zz = ((double)cv - mu) / sg;
       prior_loss = 0.5 * zz * zz;
     }
-    if (A.mode == 0) {
+    if (mode == 0) {
       if (A.gout[which]) A.gout[which][i] = gv;
     } else if (A.free_mask[which]) {
       adabelief_step(cv, A.pm[which][i], A.ps[which][i], gv, lr, bc1, bc2, A.ab);
@@ -612,7 +615,7 @@ __device__ __forceinline__ void gm_small_blocks(const JointUpdArgs &A, int N, fl
         const double var = fmax((double)sc[3 * M + i] / Etot - meanc * meanc, 0.0);
         loss += A.lam_fu * sqrt(var);
       }
-    if (A.hist) A.hist[A.t] = (float)loss;
+    if (A.hist) A.hist[t_now] = (float)loss;
     if (A.out_loss) *A.out_loss = (float)loss;
   }
 }
@@ -696,28 +699,26 @@ __global__ __launch_bounds__(kGmThreads) void joint_update_gm_kernel(JointUpdArg
 // one-block launch of joint_update_gm_kernel applies to a fit of that star alone: the same scalar reduction over its
 // epochs, the same gradient rules, the same AdaBelief step, its own loss history.  Same operands in the same order, so a
 // star of the batch ends bit for bit where its separate fit ends (tests/test_star_batch_gpu.py).
-__global__ __launch_bounds__(kGmThreads) void joint_update_groups_kernel(const JointUpdArgs *views, int mode, int t, float lr,
-                                                                         float bc1, float bc2) {
+__global__ __launch_bounds__(kGmThreads) void joint_update_groups_kernel(const JointUpdArgs *__restrict__ views, int mode, int t,
+                                                                         float lr, float bc1, float bc2) {
   __shared__ double lanes[kGmThreads];
   // two blocks per star, as in the one-fit launch (joint_reduce_update_kernel): the shifts and sky levels need nothing from
   // the reduction over the epochs and step in a block of their own beside it
-  JointUpdArgs A = views[blockIdx.x >> 1];  // (block-uniform: scalar loads)
-  A.mode = mode;
-  A.t = t;
-  A.lr = lr;
-  A.bc1 = bc1;
-  A.bc2 = bc2;
+  // The star's view is READ IN PLACE (block-uniform scalar loads; mode and iteration of the launch go to the rules as
+  // arguments): a private copy with the launch's fields patched in lived on the stack - 672 bytes of scratch per lane, every
+  // field of it a memory access - and the kernel took 15.4 us for two short blocks per star.
+  const JointUpdArgs &A = views[blockIdx.x >> 1];
   __shared__ float scl[4 * kMaxSources + 2];  // (the sums also go to LDS: the rules below read them without a trip through L2)
   // (the fluxes with their moments are requested first and arrive while the reduction's loads are in flight)
   if (blockIdx.x & 1) {
-    gm_small_blocks(A, 0, lr, bc1, bc2, nullptr, 2);
+    gm_small_blocks(A, 0, lr, bc1, bc2, nullptr, 2, nullptr, nullptr, mode, t);
     return;
   }
   FluxPre pre;
   gm_flux_preload(A, pre);
   reduce_scalars(A.E, A.M, 0, A.g_cx_e, A.g_cy_e, A.chi2_e, A.par[LC_P_A], A.a_ref, A.shared_w, lanes, threadIdx.x, scl);
   __syncthreads();
-  gm_small_blocks(A, 0, lr, bc1, bc2, scl, 1, &pre);
+  gm_small_blocks(A, 0, lr, bc1, bc2, scl, 1, &pre, nullptr, mode, t);
 }
 
 // The reduction over the epochs and the update in ONE launch (the device loop of a single GPU, where nothing has to
