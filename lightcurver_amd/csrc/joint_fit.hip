@@ -1679,6 +1679,11 @@ int lc_joint_step_local(lc_joint *j) {
     // kernel (which leaves CUs idle whenever E < 256) runs; the update kernel joins the two
     // the chain reads what the previous update wrote: behind that update's completion counter (a one-wave gate kernel at the
     // head of this stream) when the update counted itself in, behind its event otherwise
+    if (j->upd_gate_pending && !upd_gate_ok(j, j->ctx->stream)) {
+      // (no event was recorded behind the last update because no chain was expected: record it now, behind that update)
+      j->upd_gate_pending = false;
+      LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
+    }
     if (j->upd_gate_pending) {
       j->upd_seq += 1;
       hipLaunchKernelGGL(mreg_gate_kernel, dim3(1), dim3(64), 0, j->streamB, j->upd_ctr, j->upd_seq, j->upd_ctr + 1);
@@ -1784,7 +1789,13 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   if (rc) return rc;
   // (inside the library's loops no event: the record would sit between this update and the next epoch kernel on this stream,
   //  4.7 - 6 us of every iteration; the next chain starts behind a gate kernel that the next epoch launch opens)
-  j->upd_gate_pending = upd_gate_ok(j, j->ctx->stream);
+  // ... and no event at all where no chain will follow: a fit without background regulariser and point-source starlet term
+  // (the reference's default star photometry) has nobody waiting for it, and the record cost 4 of its 18.8 us per iteration
+  {
+    const bool in_loop = (j->in_device_loop || j->in_sharded_loop) && !std::getenv("LCMI_UPD_EVENT");
+    const bool will_chain = reg_h_on(j) || (j->in_device_loop && j->cfg.lam_pts_source != 0.f && j->M > 0);
+    j->upd_gate_pending = will_chain ? upd_gate_ok(j, j->ctx->stream) : in_loop;
+  }
   if (!j->upd_gate_pending) LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));
   j->reg_pending = false;
   j->fuse_pending = false;
