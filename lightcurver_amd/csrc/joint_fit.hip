@@ -121,6 +121,7 @@ struct lc_joint {
   unsigned int *upd_ctr = nullptr;
   unsigned int upd_seq = 0;
   bool upd_gate_pending = false, upd_gate_used = false, upd_signal_due = false;
+  bool evreg_recorded = true;   // evReg stands behind the last chain enqueued on the second stream
   // force_events: an in-kernel wait of this object ran out once (a stream held up for longer than its bound: ~1 s); the run was
   // redone from a copy of the state and the object synchronises its streams with events only from then on
   bool force_events = false;
@@ -973,6 +974,17 @@ static bool upd_gate_ok(const lc_joint *j, hipStream_t stream) {
   return j->upd_ctr && (j->in_device_loop || j->in_sharded_loop) && stream == j->ctx->stream && !std::getenv("LCMI_UPD_EVENT") &&
          !std::getenv("LCMI_EVENT_SYNC") && !std::getenv("LCMI_PTS_SIDE");
 }
+// Wait (on `stream`) for the regulariser chain of this iteration through its event.  The event is recorded HERE, behind the chain
+// on its own stream, the first time somebody needs it - the iterations whose consumer learns of the chain's completion in a
+// kernel (completion counter, the epoch launch's extra block) never record it.
+static int wait_for_chain_event(lc_joint *j, hipStream_t stream) {
+  if (!j->evreg_recorded) {
+    LC_HIP(j->ctx, hipEventRecord(j->evReg, j->streamB));
+    j->evreg_recorded = true;
+  }
+  LC_HIP(j->ctx, hipStreamWaitEvent(stream, j->evReg, 0));
+  return LC_OK;
+}
 int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, bool write_hist, bool all_grads,
                   int reg_mode = 0, hipStream_t stream = nullptr) {
   if (!stream) stream = j->ctx->stream;
@@ -984,7 +996,7 @@ int launch_update(lc_joint *j, int mode, int t, const lc_adabelief_cfg *cfg, boo
   auto take_event = [&]() -> int {
     if (j->defer_event) {
       j->defer_event = false;
-      LC_HIP(j->ctx, hipStreamWaitEvent(stream, j->evReg, 0));
+      return wait_for_chain_event(j, stream);
     }
     return LC_OK;
   };
@@ -1696,7 +1708,7 @@ int lc_joint_step_local(lc_joint *j) {
     int rc = launch_update(j, 0, 0, nullptr, false, false, 1, j->streamB);
     if (rc) return rc;
     if (j->tl_events) (void)hipEventRecord(j->tl_events[2], j->streamB);
-    LC_HIP(j->ctx, hipEventRecord(j->evReg, j->streamB));
+    j->evreg_recorded = false;   // (recorded by the first consumer that waits for it: wait_for_chain_event)
     j->reg_pending = true;
     // Inside the library's loops, behind a chain whose last launch counts itself into reg_flag: the epoch launch carries the
     // wait for the chain (JointArgs::chain_flag) - where the chain is expected to be done well before the epochs are.  Measured
@@ -1748,7 +1760,10 @@ int lc_joint_shared_set(lc_joint *j, const float *host, int count) {
 static int planes_repair(lc_joint *j, bool consumer_adds_planes) {
   if (!j->reg_planes || consumer_adds_planes) return LC_OK;
   const int NN = j->N * j->N, nb = (NN + kGmThreads - 1) / kGmThreads;
-  LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
+  {
+    int rc = wait_for_chain_event(j, j->ctx->stream);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(mreg_finish3_kernel, dim3(nb + 1), dim3(kGmThreads), 0, j->ctx->stream, NN, nb, j->M, j->planes, j->greg, j->regs,
                      (unsigned int *)nullptr);
   LC_HIP(j->ctx, hipGetLastError());
@@ -1783,7 +1798,7 @@ int lc_joint_step_update(lc_joint *j, const lc_adabelief_cfg *cfg) {
   j->defer_event = j->reg_pending && !j->epoch_waited && !j->flag_sync && j->in_sharded_loop && j->reg_counter && !j->force_events &&
                    !std::getenv("LCMI_EVENT_SYNC");
   // (epoch_waited: the epoch launch of this iteration ended only when the chain had - nothing to wait for here)
-  if (j->reg_pending && !j->epoch_waited && !j->flag_sync && !j->defer_event) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
+  if (j->reg_pending && !j->epoch_waited && !j->flag_sync && !j->defer_event && (rc = wait_for_chain_event(j, j->ctx->stream))) return rc;
   rc = launch_update(j, 1, j->iters_done, cfg, true, false, j->reg_pending ? 2 : 0);
   j->defer_event = false;
   if (rc) return rc;
@@ -1813,7 +1828,7 @@ int lc_joint_step_grad(lc_joint *j, float *loss, float *const grads[LC_P_COUNT])
   if (j->G > 0) LC_FAIL(j->ctx, LC_ERR_UNSUPPORTED, "lc_joint_step_grad: not available on a batched star-photometry object");
   int rc = planes_repair(j, false);
   if (rc) return rc;
-  if (j->reg_pending) LC_HIP(j->ctx, hipStreamWaitEvent(j->ctx->stream, j->evReg, 0));
+  if (j->reg_pending && (rc = wait_for_chain_event(j, j->ctx->stream))) return rc;
   rc = launch_update(j, 0, 0, nullptr, false, true, j->reg_pending ? 2 : 0);
   if (rc) return rc;
   LC_HIP(j->ctx, hipEventRecord(j->evUpd, j->ctx->stream));  // (the next lc_joint_step_local's chain waits for this one)
